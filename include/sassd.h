@@ -1,0 +1,189 @@
+/*
+ * sassd.h -- C ABI of the MI355X-native SA-SSD hot path (libsassd.so, gfx950 only).
+ *
+ * This is the drop-in boundary.  Every entry point replaces one operator surface of the reference
+ * (skyhehe123/SA-SSD; file:line relative to /root/reference) -- the reference binds those through pybind11 /
+ * numba / the spconv Python package; a maintainer binds these through ctypes.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a `void* stream` that is a hipStream_t (NULL = default).
+ *   - return 0 on success, negative SASSD_E* otherwise.  No function allocates, frees or synchronises:
+ *     the caller owns every buffer (use the *_workspace_bytes queries) and every count that is data
+ *     dependent lives in DEVICE memory (int32 scalars), so a whole frame is a fixed launch sequence
+ *     (hipGraph-capturable).  The reference, by contrast, exit()s on CUDA errors (iou3d.cpp:13-21) and
+ *     syncs on every boolean index (ssd_rotate_head.py:336-356).
+ *   - "cap" arguments are row capacities of caller buffers; if a device count exceeds its capacity the
+ *     kernel clamps, and sets bit i of the int32 at `status` (see SASSD_ST_*) when a status pointer is given.
+ *   - all floating point is IEEE fp32; all index math int32 (linear voxel indices must fit 2^32-2).
+ */
+#ifndef SASSD_H
+#define SASSD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SASSD_OK       0
+#define SASSD_EINVAL  -1   /* bad argument / unsupported configuration   */
+#define SASSD_ENOSPC  -2   /* caller workspace or capacity too small     */
+#define SASSD_EHIP    -3   /* HIP runtime / launch error (sassd_last_hip_error) */
+
+#define SASSD_ST_VOXEL_OVERFLOW   1   /* more rows than an output capacity      */
+#define SASSD_ST_HASH_FULL        2   /* hash table probe exhausted             */
+#define SASSD_ST_BOX_OVERFLOW     4   /* more candidate boxes than capK / capD  */
+
+#define SASSD_MAX_POINTS_PER_VOXEL 8   /* max_points supported by sassd_voxelize */
+
+const char *sassd_version(void);
+int sassd_last_hip_error(void);
+const char *sassd_last_hip_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a1+a2) Hard voxelisation + per-voxel mean.
+ * Replaces mmdet/ops/points_op/points_ops.py:104-164 `points_to_voxel` (numba kernel :5-50, zyx order) and
+ * mmdet/models/backbones/vxnet.py:110-116 `SimpleVoxel.forward`.  Bit-exact with the serial reference:
+ * voxels in first-touch order, <= max_points points per voxel in arrival order, the max_voxels `break`.
+ *   points      [n_points, ndim] f32 (ndim >= 3; xyz first)            device
+ *   voxel_size  3 f32, coors_range 6 f32                               HOST
+ *   voxels      [cap, max_points, ndim] f32 zero padded, or NULL
+ *   coors       [cap, coors_cols] i32; coors_cols 3 -> (z,y,x); 4 -> (batch_idx,z,y,x)
+ *   num_points  [cap] i32, or NULL
+ *   mean        [cap, nfeat] f32 (nfeat <= ndim), or NULL
+ *   row_offset  device int32[2] or NULL: rows are written starting at row_offset[0] (0 if NULL) and
+ *               row_offset[1] = row_offset[0] + voxel_num is written back (batch concatenation,
+ *               detectors/single_stage.py:52-73 merge_second_batch).
+ *   voxel_num   device int32 scalar: number of voxels of THIS cloud
+ * ---------------------------------------------------------------------------------------------- */
+size_t sassd_voxelize_workspace_bytes(int n_points, int max_points);
+int sassd_voxelize(const float *points, int n_points, int ndim, const float *voxel_size,
+                   const float *coors_range, int max_points, int max_voxels, int batch_idx,
+                   float *voxels, int32_t *coors, int coors_cols, int32_t *num_points, float *mean,
+                   int nfeat, int32_t *row_offset, int32_t *voxel_num, int cap, int32_t *status,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* SimpleVoxel.forward alone (vxnet.py:110-116): mean[v,f] = sum_t voxels[v,t,f] / num_points[v]. */
+int sassd_voxel_mean(const float *voxels, const int32_t *num_points, int m, int max_points, int ndim,
+                     int nfeat, float *mean, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a5) Rulebook build.  Replaces spconv v1.0 `get_indice_pairs` as invoked by SubMConv3d / SparseConv3d
+ * (call sites mmdet/models/necks/cmn.py:147-173).  The rulebook is a gather table
+ *   nbr[row_out, 27]  = input row feeding output row_out through kernel offset k=(kz*3+ky)*3+kx, or -1
+ * (each (out,k) has at most one input); sassd_rulebook_pairs converts it to spconv's
+ * indice_pairs[27,2,P] / indice_pair_num[27] form (pairs in ascending out row).
+ *   indices [n,4] i32 (batch,z,y,x); n_ptr device int32 row count; cap = row capacity of indices/nbr.
+ * ---------------------------------------------------------------------------------------------- */
+size_t sassd_hash_bytes(int cap_rows);                 /* table for cap_rows keys                      */
+int sassd_hash_build(const int32_t *indices, const int32_t *n_ptr, int cap, int D, int H, int W,
+                     int batch_size, void *table, size_t table_bytes, int32_t *status, void *stream);
+int sassd_rulebook_subm(const int32_t *indices, const int32_t *n_ptr, int cap, int D, int H, int W,
+                        int batch_size, const void *table, size_t table_bytes, int32_t *nbr,
+                        void *stream);
+/* SparseConv3d(k=3, s=2, p=1): out dims (in+2-2-1)/2+1; out rows ascending in linear (b,z,y,x). */
+size_t sassd_rulebook_conv_workspace_bytes(int D, int H, int W, int batch_size);
+int sassd_rulebook_conv(const int32_t *in_indices, const int32_t *n_in_ptr, int cap_in, int D, int H,
+                        int W, int batch_size, const void *in_table, size_t in_table_bytes,
+                        int32_t *out_indices, int32_t *n_out_ptr, int cap_out, int32_t *nbr,
+                        int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+int sassd_rulebook_pairs(const int32_t *nbr, const int32_t *n_out_ptr, int cap_out, int K,
+                         int32_t *pairs /*[K,2,cap_out]*/, int32_t *pair_num /*[K]*/, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a6+a7) Sparse convolution forward with fused per-channel affine (folded eval BatchNorm1d) + ReLU.
+ * Replaces spconv `indice_conv_fp32` (+ nn.BatchNorm1d + nn.ReLU, cmn.py:138-173,208-212).
+ *   y[o,:] = act( (sum_k x[nbr[o,k],:] @ w[k]) * scale + shift )
+ *   w        [K, Cin, Cout] f32 (spconv layout [kz,ky,kx,Cin,Cout] flattened) -> pack once with
+ *            sassd_spconv_pack_weight (sassd_spconv_packed_floats floats).
+ *   nbr NULL = identity rulebook with K=1 (the 1x1x1 `extra_conv` shortcut, cmn.py:208-212).
+ *   scale/shift may be NULL (1 / 0).  (Cin,Cout) in {(4,16),(16,16),(16,32),(32,32),(32,64),(64,64)}.
+ * ---------------------------------------------------------------------------------------------- */
+size_t sassd_spconv_packed_floats(int K, int Cin, int Cout);
+int sassd_spconv_pack_weight(const float *w, int K, int Cin, int Cout, float *packed, void *stream);
+int sassd_spconv_fwd(const float *x, const int32_t *nbr, const int32_t *n_out_ptr, int cap_out,
+                     const float *w_packed, int K, int Cin, int Cout, const float *scale,
+                     const float *shift, int relu, float *y, void *stream);
+
+/* (a8) SparseConvTensor.dense() + view (cmn.py:112-114): out [B, C*D, H, W] f32, zero filled here.
+ * channel_order 0: channel = c*D + d (reference); 1: channel = d*C + c (internal, conv0 weights permuted). */
+int sassd_densify(const float *feats, const int32_t *indices, const int32_t *n_ptr, int cap, int C,
+                  int D, int H, int W, int batch_size, int channel_order, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a9,a10,a12) Dense 2-D convolution (3x3 pad 1 or 1x1), NCHW fp32, on fp32 MFMA (v_mfma_f32_32x32x2_f32),
+ * fused per-channel affine (folded BatchNorm2d / bias) + optional ReLU.  Replaces torch.nn.Conv2d +
+ * BatchNorm2d + ReLU in BEVNet (cmn.py:233-282), SSDRotateHead (ssd_rotate_head.py:120-125) and
+ * PSWarpHead.convs (:424-429).   w torch layout [Cout,Cin,k,k]; pack once.
+ * ---------------------------------------------------------------------------------------------- */
+size_t sassd_conv2d_packed_floats(int Cin, int Cout, int ksize);
+int sassd_conv2d_pack_weight(const float *w, int Cout, int Cin, int ksize, float *packed, void *stream);
+int sassd_conv2d_fwd(const float *x, const float *w_packed, const float *scale, const float *shift,
+                     int relu, float *y, int batch, int Cin, int Cout, int H, int W, int ksize,
+                     void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (f-1) anchors_mask: mmdet/datasets/kitti.py:333-343 with geometry.py:676-710
+ * (sparse_sum_for_anchors_mask -> cumsum -> fused_get_anchors_area > area_threshold).
+ *   coors [n,4] (b,z,y,x) rows of ONE batch element are selected by batch_idx
+ *   anchors_bv [A,4] f32 (xmin,ymin,xmax,ymax); mask [A] u8
+ * ---------------------------------------------------------------------------------------------- */
+size_t sassd_anchor_mask_workspace_bytes(int H0, int W0);
+int sassd_anchor_mask(const int32_t *coors, const int32_t *row_begin_ptr, const int32_t *row_end_ptr,
+                      int H0, int W0, const float *anchors_bv, int n_anchors, const float *voxel_size,
+                      const float *coors_range, float area_threshold, uint8_t *mask, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (a11) get_guided_anchors, test path (ssd_rotate_head.py:307-372) + second_box_decode (:53-91).
+ *   box/cls/dir: raw conv outputs [B, ncls*A*7 | ncls*A*ncls | ncls*A*2, H, W] (NCHW), channel strides
+ *   given in floats via *_batch_stride (lets the three heads live in one fused conv output).
+ *   anchors [Atot,7] (Atot = ncls*H*W*A), mask [B,Atot] u8.  Keeps anchors with mask && max-class
+ *   sigmoid score > thr, in ascending anchor order; applies the direction flip.
+ *   out: guided [B,capK,7], labels [B,capK] i32, scores [B,capK] f32 (rpn score, extra), counts [B] i32.
+ * ---------------------------------------------------------------------------------------------- */
+size_t sassd_decode_filter_workspace_bytes(int batch, int n_anchors_total);
+int sassd_decode_filter(const float *box, const float *cls, const float *dir, size_t batch_stride,
+                        int batch, int num_class, int anchors_per_loc, int H, int W,
+                        const float *anchors, const uint8_t *mask, float thr, float *guided,
+                        int32_t *labels, float *scores, int32_t *counts, int capK, int32_t *status,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* (a12) PSWarpHead sampling (ssd_rotate_head.py:374-414,438-442): feat [B,parts,H,W] (parts = 4*7),
+ * guided [B,capK,7], counts [B] -> logits [B,capK] = mean_k bilinear(feat[k], grid point k). */
+int sassd_pswarp_sample(const float *feat, int batch, int H, int W, const float *guided,
+                        const int32_t *counts, int capK, float grid_off_x, float grid_off_y,
+                        float spatial_scale, float *logits, void *stream);
+
+/* (a13+a14) get_rescore_bboxes (ssd_rotate_head.py:487-533): sigmoid, > score_thr, BEV boxes
+ * (iou3d_utils.py:47-60), stable descending sort, rotated NMS (iou3d_kernel.cu:250-292 + iou3d.cpp:100-116).
+ *   out_boxes [B,capD,7], out_scores [B,capD], out_labels [B,capD] i32, out_counts [B] i32. */
+size_t sassd_rescore_nms_workspace_bytes(int batch, int capK);
+int sassd_rescore_nms(const float *guided, const float *logits, const int32_t *labels,
+                      const int32_t *counts, int batch, int capK, float score_thr, float iou_thr,
+                      float *out_boxes, float *out_scores, int32_t *out_labels, int32_t *out_counts,
+                      int capD, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * iou3d_cuda operator surface (mmdet/ops/iou3d/src/iou3d.cpp:31,52,73; kernels iou3d_kernel.cu:223-292).
+ * boxes (x1,y1,x2,y2,ry) f32.  nms: boxes sorted by descending score; keep [n] i64 and num_keep are DEVICE
+ * buffers (the reference fills a CPU LongTensor after a blocking D2H of the mask, iou3d.cpp:92-94).
+ * ---------------------------------------------------------------------------------------------- */
+int sassd_boxes_overlap_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
+                            float *ans_overlap, void *stream);
+int sassd_boxes_iou_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
+                        float *ans_iou, void *stream);
+size_t sassd_nms_workspace_bytes(int n);
+int sassd_nms_gpu(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* Hardware self-test helper used by tests: D = A(32x2k) * B(2k x32) through v_mfma_f32_32x32x2_f32 and
+ * D = A(16x4k) * B(4k x16) through v_mfma_f32_16x16x4_f32 with the lane maps the kernels assume. */
+int sassd_mfma_probe(const float *a32, const float *b32, float *d32, const float *a16, const float *b16,
+                     float *d16, int ksteps, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SASSD_H */

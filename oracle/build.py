@@ -23,6 +23,8 @@ _PRELUDE = r"""
 #define __global__
 #define __shared__
 using std::min; using std::max;
+// CUDA resolves cos/sin/atan2/fabs on float arguments to the float overloads; do the same on the host
+using std::cos; using std::sin; using std::atan2; using std::fabs;
 """
 _WRAP = r"""
 extern "C" float ref_box_overlap(const float* a, const float* b) { return box_overlap(a, b); }

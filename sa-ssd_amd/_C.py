@@ -1,0 +1,103 @@
+"""ctypes binding of libsassd.so (C ABI declared in include/sassd.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsassd.so")
+_lib = None
+
+OK, EINVAL, ENOSPC, EHIP = 0, -1, -2, -3
+ST_VOXEL_OVERFLOW, ST_HASH_FULL, ST_BOX_OVERFLOW = 1, 2, 4
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into lib/libsassd.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if force:
+        subprocess.check_call(cmd + ["clean"], stdout=subprocess.DEVNULL)
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise RuntimeError("building libsassd.so failed")
+    return LIB_PATH
+
+
+_SZ = C.c_size_t
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+
+_SIGS = {
+    "sassd_version": (C.c_char_p, []),
+    "sassd_last_hip_error": (_I, []),
+    "sassd_last_hip_error_string": (C.c_char_p, []),
+    "sassd_voxelize_workspace_bytes": (_SZ, [_I, _I]),
+    "sassd_voxelize": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _SZ, _P]),
+    "sassd_voxel_mean": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "sassd_hash_bytes": (_SZ, [_I]),
+    "sassd_hash_build": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
+    "sassd_rulebook_subm": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
+    "sassd_rulebook_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "sassd_rulebook_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P, _I, _P, _P, _P, _SZ, _P]),
+    "sassd_rulebook_pairs": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "sassd_spconv_packed_floats": (_SZ, [_I, _I, _I]),
+    "sassd_spconv_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
+    "sassd_spconv_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "sassd_densify": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "sassd_conv2d_packed_floats": (_SZ, [_I, _I, _I]),
+    "sassd_conv2d_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
+    "sassd_conv2d_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sassd_anchor_mask_workspace_bytes": (_SZ, [_I, _I]),
+    "sassd_anchor_mask": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _F, _P, _P, _SZ, _P]),
+    "sassd_decode_filter_workspace_bytes": (_SZ, [_I, _I]),
+    "sassd_decode_filter": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
+    "sassd_pswarp_sample": (_I, [_P, _I, _I, _I, _P, _P, _I, _F, _F, _F, _P, _P]),
+    "sassd_rescore_nms_workspace_bytes": (_SZ, [_I, _I]),
+    "sassd_rescore_nms": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
+    "sassd_boxes_overlap_bev": (_I, [_P, _I, _P, _I, _P, _P]),
+    "sassd_boxes_iou_bev": (_I, [_P, _I, _P, _I, _P, _P]),
+    "sassd_nms_workspace_bytes": (_SZ, [_I]),
+    "sassd_nms_gpu": (_I, [_P, _I, _F, _P, _P, _P, _SZ, _P]),
+    "sassd_mfma_probe": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libsassd.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)            # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != OK:
+        l = lib()
+        extra = ""
+        if rc == EHIP:
+            extra = ": " + l.sassd_last_hip_error_string().decode()
+        raise RuntimeError("%s failed with code %d%s" % (what, rc, extra))
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

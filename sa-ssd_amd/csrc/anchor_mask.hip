@@ -1,0 +1,132 @@
+// anchor_mask.hip -- device-side anchors_mask (the step immediately before the path).
+//
+// Replaces, per frame, mmdet/datasets/kitti.py:333-343: sparse_sum_for_anchors_mask (geometry.py:676-682),
+// cumsum(0).cumsum(1) (a 9 MB float integral image built on the host) and fused_get_anchors_area (:685-710).
+// Counts are exact integers (the reference's float32 cumsum is exact below 2^24), the anchor->cell arithmetic is
+// the same fp32 sequence (subtract, IEEE divide, floor, clamp); the missing "-1" on the lower corner of the
+// integral-image lookup (geometry.py:693-709) is reproduced literally.
+#include "common.h"
+
+namespace {
+
+__global__ void am_scatter_kernel(const int32_t *__restrict__ coors, const int32_t *__restrict__ rb,
+                                  const int32_t *__restrict__ re, int W0, unsigned *__restrict__ grid)
+{
+    const int begin = rb ? *rb : 0, end = *re;
+    const int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= end) return;
+    const int4 c = ((const int4 *)coors)[i];
+    atomicAdd(&grid[(size_t)c.z * W0 + c.w], 1u);
+}
+
+// inclusive row scan, one block per row
+__global__ void __launch_bounds__(256) am_rowscan_kernel(unsigned *__restrict__ grid, int W0)
+{
+    __shared__ int wsum[17];
+    unsigned *row = grid + (size_t)blockIdx.x * W0;
+    const int per = (W0 + 255) / 256;
+    const int x0 = threadIdx.x * per;
+    int s = 0;
+    for (int k = 0; k < per; ++k) if (x0 + k < W0) s += (int)row[x0 + k];
+    int tot;
+    int run = block_exclusive_scan(s, wsum, &tot);
+    for (int k = 0; k < per; ++k)
+        if (x0 + k < W0) { run += (int)row[x0 + k]; row[x0 + k] = (unsigned)run; }
+}
+
+constexpr int kRB = 32;   // rows per column segment
+
+// per (row segment, column): in-place inclusive column scan inside the segment, segment total -> seg[rs][x]
+__global__ void __launch_bounds__(256) am_colseg_kernel(unsigned *__restrict__ grid, int H0, int W0,
+                                                        unsigned *__restrict__ seg)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W0) return;
+    const int y0 = blockIdx.y * kRB;
+    unsigned run = 0;
+    for (int k = 0; k < kRB; ++k) {
+        const int y = y0 + k;
+        if (y >= H0) break;
+        run += grid[(size_t)y * W0 + x];
+        grid[(size_t)y * W0 + x] = run;
+    }
+    seg[(size_t)blockIdx.y * W0 + x] = run;
+}
+
+__global__ void __launch_bounds__(256) am_segscan_kernel(unsigned *__restrict__ seg, int nseg, int W0)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W0) return;
+    unsigned run = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const unsigned v = seg[(size_t)s * W0 + x];
+        seg[(size_t)s * W0 + x] = run;           // exclusive
+        run += v;
+    }
+}
+
+struct AmParams { float vs0, vs1, off0, off1, thr; int H0, W0, n; };
+
+__device__ __forceinline__ unsigned am_I(const unsigned *grid, const unsigned *seg, int W0, int y, int x)
+{
+    return grid[(size_t)y * W0 + x] + seg[(size_t)(y / kRB) * W0 + x];
+}
+
+__global__ void __launch_bounds__(256) am_anchor_kernel(const float *__restrict__ bv, AmParams P,
+                                                        const unsigned *__restrict__ grid,
+                                                        const unsigned *__restrict__ seg, uint8_t *__restrict__ mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const float4 a = ((const float4 *)bv)[i];
+    int c0 = (int)floorf(__fdiv_rn(a.x - P.off0, P.vs0));
+    int c1 = (int)floorf(__fdiv_rn(a.y - P.off1, P.vs1));
+    int c2 = (int)floorf(__fdiv_rn(a.z - P.off0, P.vs0));
+    int c3 = (int)floorf(__fdiv_rn(a.w - P.off1, P.vs1));
+    c0 = max(c0, 0); c1 = max(c1, 0);
+    c2 = min(c2, P.W0 - 1); c3 = min(c3, P.H0 - 1);
+    // like numba's unchecked indexing the reference would wrap negatives; clamp defensively instead
+    c2 = max(c2, 0); c3 = max(c3, 0); c0 = min(c0, P.W0 - 1); c1 = min(c1, P.H0 - 1);
+    const int ID = (int)am_I(grid, seg, P.W0, c3, c2);
+    const int IA = (int)am_I(grid, seg, P.W0, c1, c0);
+    const int IB = (int)am_I(grid, seg, P.W0, c3, c0);
+    const int IC = (int)am_I(grid, seg, P.W0, c1, c2);
+    mask[i] = ((float)(ID - IB - IC + IA) > P.thr) ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" size_t sassd_anchor_mask_workspace_bytes(int H0, int W0)
+{
+    const int nseg = cdiv(H0, kRB);
+    return align_up((size_t)H0 * W0 * 4, 256) + align_up((size_t)nseg * W0 * 4, 256);
+}
+
+extern "C" int sassd_anchor_mask(const int32_t *coors, const int32_t *row_begin_ptr, const int32_t *row_end_ptr,
+                                 int H0, int W0, const float *anchors_bv, int n_anchors, const float *voxel_size,
+                                 const float *coors_range, float area_threshold, uint8_t *mask, void *workspace,
+                                 size_t workspace_bytes, void *stream_)
+{
+    if (!coors || !row_end_ptr || !anchors_bv || !voxel_size || !coors_range || !mask || !workspace) return SASSD_EINVAL;
+    if (H0 < 1 || W0 < 1 || n_anchors < 1) return SASSD_EINVAL;
+    if (workspace_bytes < sassd_anchor_mask_workspace_bytes(H0, W0)) return SASSD_ENOSPC;
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned *grid = (unsigned *)workspace;
+    unsigned *seg = (unsigned *)((char *)workspace + align_up((size_t)H0 * W0 * 4, 256));
+    const int nseg = cdiv(H0, kRB);
+    int rc;
+    if ((rc = sassd_hip(hipMemsetAsync(grid, 0, (size_t)H0 * W0 * 4, stream)))) return rc;
+    // the voxel count of one cloud never exceeds H0*W0*D; launch for a generous fixed bound and exit early
+    const int max_rows = 1 << 18;
+    hipLaunchKernelGGL(am_scatter_kernel, dim3(cdiv(max_rows, 256)), dim3(256), 0, stream, coors, row_begin_ptr,
+                       row_end_ptr, W0, grid);
+    hipLaunchKernelGGL(am_rowscan_kernel, dim3(H0), dim3(256), 0, stream, grid, W0);
+    hipLaunchKernelGGL(am_colseg_kernel, dim3(cdiv(W0, 256), nseg), dim3(256), 0, stream, grid, H0, W0, seg);
+    hipLaunchKernelGGL(am_segscan_kernel, dim3(cdiv(W0, 256)), dim3(256), 0, stream, seg, nseg, W0);
+    AmParams P;
+    P.vs0 = voxel_size[0]; P.vs1 = voxel_size[1]; P.off0 = coors_range[0]; P.off1 = coors_range[1];
+    P.thr = area_threshold; P.H0 = H0; P.W0 = W0; P.n = n_anchors;
+    hipLaunchKernelGGL(am_anchor_kernel, dim3(cdiv(n_anchors, 256)), dim3(256), 0, stream, anchors_bv, P,
+                       (const unsigned *)grid, (const unsigned *)seg, mask);
+    return sassd_launch_status();
+}

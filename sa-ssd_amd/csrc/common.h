@@ -1,0 +1,106 @@
+// common.h -- shared device helpers for libsassd (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sassd.h"
+
+#define SASSD_WAVE 64
+
+extern int g_sassd_last_hip_error;
+
+static inline int sassd_launch_status()
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_sassd_last_hip_error = (int)e;
+        return SASSD_EHIP;
+    }
+    return SASSD_OK;
+}
+
+static inline int sassd_hip(hipError_t e)
+{
+    if (e != hipSuccess) {
+        g_sassd_last_hip_error = (int)e;
+        return SASSD_EHIP;
+    }
+    return SASSD_OK;
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline unsigned next_pow2(unsigned x)
+{
+    unsigned p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// ---- open-addressing hash: u32 key -> i32 value, linear probing, EMPTY = 0xFFFFFFFF ---------------
+#define SASSD_HASH_EMPTY 0xFFFFFFFFu
+
+__device__ __forceinline__ unsigned hash_u32(unsigned k)
+{
+    k ^= k >> 16;
+    k *= 0x7feb352du;
+    k ^= k >> 15;
+    k *= 0x846ca68bu;
+    k ^= k >> 16;
+    return k;
+}
+
+// returns slot index of `key` (inserting it if absent) or -1 if the table is full
+__device__ __forceinline__ int hash_insert(unsigned *keys, unsigned mask, unsigned key)
+{
+    unsigned h = hash_u32(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        unsigned prev = atomicCAS(&keys[h], SASSD_HASH_EMPTY, key);
+        if (prev == SASSD_HASH_EMPTY || prev == key) return (int)h;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ int hash_find(const unsigned *keys, unsigned mask, unsigned key)
+{
+    unsigned h = hash_u32(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        unsigned k = keys[h];
+        if (k == key) return (int)h;
+        if (k == SASSD_HASH_EMPTY) return -1;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// ---- block-wide exclusive scan of one int per thread (blockDim.x multiple of 64, <= 1024) ---------
+// `wsum` is shared scratch of >= 17 ints. Returns the exclusive prefix; *total = block sum.
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    if (wid == 0) {
+        int s = (lane < nw) ? wsum[lane] : 0;
+        int si = s;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            int t = __shfl_up(si, o, 64);
+            if (lane >= o) si += t;
+        }
+        if (lane < nw) wsum[lane] = si - s;      // exclusive prefix of wave sums
+        if (lane == nw - 1) wsum[16] = si;       // block total
+    }
+    __syncthreads();
+    int res = wsum[wid] + inc - v;
+    *total = wsum[16];
+    __syncthreads();                              // wsum may be reused by the caller
+    return res;
+}

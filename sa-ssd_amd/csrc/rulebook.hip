@@ -1,0 +1,305 @@
+// rulebook.hip -- hash/bitmap rulebook construction for submanifold and strided sparse 3-D convolution.
+//
+// Replaces spconv v1.0 get_indice_pairs (prepareSubMGridKernel/getSubMIndicePairsKernel and
+// prepareIndicePairsKernel -> thrust sort/unique -> assign*Kernel) as reached from
+// mmdet/models/necks/cmn.py:147-173.  spconv v1.0 memsets a dense int32 grid of B*D*H*W cells per rulebook
+// (360 MB at level 0); here
+//   * coordinate -> row lookup is an open-addressing hash (8 B/row * 2),
+//   * the strided conv's sorted-unique output set comes from a 1-bit-per-cell bitmap + popcount prefix sum
+//     (ascending linear (b,z,y,x) order falls out of the scan -- no sort),
+//   * the rulebook is an output-stationary gather table nbr[row_out][27] (one coalesced 108-B record per row).
+// Algorithmic HBM bytes: subm 16*Nin + 8*P ; strided 16*Nin + 16*Nout + 8*P.
+#include "common.h"
+
+namespace {
+
+struct HashView {
+    unsigned *keys;
+    int *vals;
+    unsigned mask;
+};
+
+inline unsigned hash_cap(int cap_rows)
+{
+    unsigned h = next_pow2((unsigned)(cap_rows > 0 ? cap_rows : 1) * 2u);
+    return h < 1024 ? 1024 : h;
+}
+
+inline HashView hash_view(const void *table, int cap_rows)
+{
+    HashView v;
+    unsigned h = hash_cap(cap_rows);
+    v.keys = (unsigned *)table;
+    v.vals = (int *)((char *)table + (size_t)h * 4);
+    v.mask = h - 1;
+    return v;
+}
+
+__global__ void hash_build_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ n_ptr, int cap, int D,
+                                  int H, int W, HashView hv, int32_t *status)
+{
+    const int n = min(*n_ptr, cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = ((const int4 *)idx)[i];
+    const unsigned key = (((unsigned)c.x * D + c.y) * H + c.z) * W + c.w;
+    const int e = hash_insert(hv.keys, hv.mask, key);
+    if (e < 0) { if (status) atomicOr(status, SASSD_ST_HASH_FULL); return; }
+    hv.vals[e] = i;
+}
+
+// one thread per (output row, kernel offset): nbr[row*27+k] = row of voxel at c + (k-1) or -1
+__global__ void nbr_subm_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ n_ptr, int cap, int D,
+                                int H, int W, HashView hv, int32_t *__restrict__ nbr)
+{
+    const int n = min(*n_ptr, cap);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 27) return;
+    const int row = t / 27, k = t - row * 27;
+    const int4 c = ((const int4 *)idx)[row];
+    const int z = c.y + k / 9 - 1, y = c.z + (k / 3) % 3 - 1, x = c.w + k % 3 - 1;
+    int r = -1;
+    if (k == 13) r = row;
+    else if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
+        const unsigned key = (((unsigned)c.x * D + z) * H + y) * W + x;
+        const int e = hash_find(hv.keys, hv.mask, key);
+        if (e >= 0) r = hv.vals[e];
+    }
+    nbr[t] = r;
+}
+
+struct DownDims { int D, H, W, OD, OH, OW, B; };
+
+// per axis: input coord i reaches outputs (i+1-kk)/2 for kk in {0,1,2} with i+1-kk even and in range
+__device__ __forceinline__ int axis_outs(int i, int od, int o[2])
+{
+    int n = 0;
+    if (i & 1) {
+        int a = (i + 1) >> 1, b = (i - 1) >> 1;
+        if (a < od) o[n++] = a;
+        if (b >= 0 && b < od) o[n++] = b;
+    } else {
+        int a = i >> 1;
+        if (a < od) o[n++] = a;
+    }
+    return n;
+}
+
+__global__ void down_mark_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ n_ptr, int cap,
+                                 DownDims d, unsigned *__restrict__ bitmap)
+{
+    const int n = min(*n_ptr, cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = ((const int4 *)idx)[i];
+    int oz[2], oy[2], ox[2];
+    const int nz = axis_outs(c.y, d.OD, oz), ny = axis_outs(c.z, d.OH, oy), nx = axis_outs(c.w, d.OW, ox);
+    for (int a = 0; a < nz; ++a)
+        for (int b = 0; b < ny; ++b)
+            for (int e = 0; e < nx; ++e) {
+                const unsigned lin = (((unsigned)c.x * d.OD + oz[a]) * d.OH + oy[b]) * d.OW + ox[e];
+                atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+            }
+}
+
+constexpr int kWordsPerBlock = 1024;     // 256 threads x 4 words
+
+__global__ void __launch_bounds__(256) bitmap_count_kernel(const unsigned *__restrict__ bitmap, int nwords,
+                                                           int *__restrict__ bsum)
+{
+    __shared__ int wsum[17];
+    const int base = blockIdx.x * kWordsPerBlock + threadIdx.x * 4;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < nwords) s += __popc(bitmap[base + k]);
+    int tot;
+    block_exclusive_scan(s, wsum, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(1024) blocksum_scan_kernel(const int *__restrict__ bsum, int *__restrict__ bbase,
+                                                             int nblk, int32_t *n_out_ptr, int cap_out,
+                                                             int32_t *status)
+{
+    __shared__ int wsum[17];
+    int running = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        int v = (b < nblk) ? bsum[b] : 0;
+        int tot;
+        int ex = block_exclusive_scan(v, wsum, &tot);
+        if (b < nblk) bbase[b] = running + ex;
+        running += tot;
+    }
+    if (threadIdx.x == 0) {
+        if (running > cap_out) { if (status) atomicOr(status, SASSD_ST_VOXEL_OVERFLOW); running = cap_out; }
+        *n_out_ptr = running;
+    }
+}
+
+// emits out_indices in ascending linear order and records, per bitmap word, the row of its first set bit
+__global__ void __launch_bounds__(256) down_emit_kernel(const unsigned *__restrict__ bitmap, int nwords,
+                                                        const int *__restrict__ bbase, DownDims d, int cap_out,
+                                                        int32_t *__restrict__ out_idx)
+{
+    __shared__ int wsum[17];
+    const int base = blockIdx.x * kWordsPerBlock + threadIdx.x * 4;
+    unsigned w[4];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { w[k] = (base + k < nwords) ? bitmap[base + k] : 0u; s += __popc(w[k]); }
+    int tot;
+    int row = bbase[blockIdx.x] + block_exclusive_scan(s, wsum, &tot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned m = w[k];
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            if (row < cap_out) {
+                unsigned lin = (unsigned)(base + k) * 32u + bit;
+                const int x = lin % d.OW; lin /= d.OW;
+                const int y = lin % d.OH; lin /= d.OH;
+                const int z = lin % d.OD; lin /= d.OD;
+                ((int4 *)out_idx)[row] = make_int4((int)lin, z, y, x);
+            }
+            ++row;
+        }
+    }
+}
+
+// one thread per (out row, k): input coord = 2*o - 1 + kk per axis
+__global__ void nbr_down_kernel(const int32_t *__restrict__ out_idx, const int32_t *__restrict__ n_out_ptr,
+                                int cap_out, DownDims d, HashView hv, int32_t *__restrict__ nbr)
+{
+    const int n = min(*n_out_ptr, cap_out);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 27) return;
+    const int row = t / 27, k = t - row * 27;
+    const int4 c = ((const int4 *)out_idx)[row];
+    const int z = 2 * c.y - 1 + k / 9, y = 2 * c.z - 1 + (k / 3) % 3, x = 2 * c.w - 1 + k % 3;
+    int r = -1;
+    if (z >= 0 && z < d.D && y >= 0 && y < d.H && x >= 0 && x < d.W) {
+        const unsigned key = (((unsigned)c.x * d.D + z) * d.H + y) * d.W + x;
+        const int e = hash_find(hv.keys, hv.mask, key);
+        if (e >= 0) r = hv.vals[e];
+    }
+    nbr[t] = r;
+}
+
+// spconv-format pairs: one block per kernel offset, ordered compaction over output rows
+__global__ void __launch_bounds__(1024) pairs_kernel(const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_ptr,
+                                                     int cap, int K, int32_t *__restrict__ pairs,
+                                                     int32_t *__restrict__ pair_num)
+{
+    __shared__ int wsum[17];
+    const int n = min(*n_ptr, cap);
+    const int k = blockIdx.x;
+    int32_t *pin = pairs + (size_t)k * 2 * cap, *pout = pin + cap;
+    int running = 0;
+    for (int r0 = 0; r0 < n; r0 += 1024) {
+        const int r = r0 + threadIdx.x;
+        const int v = (r < n) ? nbr[(size_t)r * K + k] : -1;
+        int tot;
+        const int ex = block_exclusive_scan(v >= 0 ? 1 : 0, wsum, &tot);
+        if (v >= 0) { pin[running + ex] = v; pout[running + ex] = r; }
+        running += tot;
+    }
+    if (threadIdx.x == 0) pair_num[k] = running;
+}
+
+inline bool lin_fits(int D, int H, int W, int B) { return (double)D * H * W * B < 4294967294.0; }
+
+}  // namespace
+
+extern "C" size_t sassd_hash_bytes(int cap_rows) { return (size_t)hash_cap(cap_rows) * 8; }
+
+extern "C" int sassd_hash_build(const int32_t *indices, const int32_t *n_ptr, int cap, int D, int H, int W,
+                                int batch_size, void *table, size_t table_bytes, int32_t *status, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!indices || !n_ptr || !table || cap <= 0 || !lin_fits(D, H, W, batch_size)) return SASSD_EINVAL;
+    if (table_bytes < sassd_hash_bytes(cap)) return SASSD_ENOSPC;
+    HashView hv = hash_view(table, cap);
+    int rc;
+    if ((rc = sassd_hip(hipMemsetAsync(hv.keys, 0xFF, (size_t)(hv.mask + 1) * 4, stream)))) return rc;
+    hipLaunchKernelGGL(hash_build_kernel, dim3(cdiv(cap, 256)), dim3(256), 0, stream, indices, n_ptr, cap, D, H, W,
+                       hv, status);
+    return sassd_launch_status();
+}
+
+extern "C" int sassd_rulebook_subm(const int32_t *indices, const int32_t *n_ptr, int cap, int D, int H, int W,
+                                   int batch_size, const void *table, size_t table_bytes, int32_t *nbr,
+                                   void *stream_)
+{
+    if (!indices || !n_ptr || !table || !nbr || cap <= 0 || !lin_fits(D, H, W, batch_size)) return SASSD_EINVAL;
+    if (table_bytes < sassd_hash_bytes(cap)) return SASSD_ENOSPC;
+    HashView hv = hash_view(table, cap);
+    hipLaunchKernelGGL(nbr_subm_kernel, dim3(cdiv(cap * 27, 256)), dim3(256), 0, (hipStream_t)stream_, indices, n_ptr,
+                       cap, D, H, W, hv, nbr);
+    return sassd_launch_status();
+}
+
+namespace {
+struct DownLayout { size_t bitmap, bsum, bbase, total; int nwords, nblk; };
+DownLayout down_layout(int D, int H, int W, int B)
+{
+    DownLayout L;
+    const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const size_t cells = (size_t)B * OD * OH * OW;
+    L.nwords = (int)((cells + 31) / 32);
+    L.nblk = cdiv(L.nwords, kWordsPerBlock);
+    size_t o = 0;
+    L.bitmap = o; o += align_up((size_t)L.nwords * 4, 256);
+    L.bsum = o;   o += align_up((size_t)L.nblk * 4, 256);
+    L.bbase = o;  o += align_up((size_t)L.nblk * 4, 256);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+extern "C" size_t sassd_rulebook_conv_workspace_bytes(int D, int H, int W, int batch_size)
+{
+    return down_layout(D, H, W, batch_size).total;
+}
+
+extern "C" int sassd_rulebook_conv(const int32_t *in_indices, const int32_t *n_in_ptr, int cap_in, int D, int H,
+                                   int W, int batch_size, const void *in_table, size_t in_table_bytes,
+                                   int32_t *out_indices, int32_t *n_out_ptr, int cap_out, int32_t *nbr,
+                                   int32_t *status, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!in_indices || !n_in_ptr || !in_table || !out_indices || !n_out_ptr || !nbr || !workspace) return SASSD_EINVAL;
+    if (cap_in <= 0 || cap_out <= 0 || !lin_fits(D, H, W, batch_size)) return SASSD_EINVAL;
+    if (in_table_bytes < sassd_hash_bytes(cap_in)) return SASSD_ENOSPC;
+    const DownLayout L = down_layout(D, H, W, batch_size);
+    if (workspace_bytes < L.total) return SASSD_ENOSPC;
+    DownDims d;
+    d.D = D; d.H = H; d.W = W; d.B = batch_size;
+    d.OD = (D - 1) / 2 + 1; d.OH = (H - 1) / 2 + 1; d.OW = (W - 1) / 2 + 1;
+    char *w = (char *)workspace;
+    unsigned *bitmap = (unsigned *)(w + L.bitmap);
+    int *bsum = (int *)(w + L.bsum), *bbase = (int *)(w + L.bbase);
+    HashView hv = hash_view(in_table, cap_in);
+    int rc;
+    if ((rc = sassd_hip(hipMemsetAsync(bitmap, 0, (size_t)L.nwords * 4, stream)))) return rc;
+    hipLaunchKernelGGL(down_mark_kernel, dim3(cdiv(cap_in, 256)), dim3(256), 0, stream, in_indices, n_in_ptr, cap_in,
+                       d, bitmap);
+    hipLaunchKernelGGL(bitmap_count_kernel, dim3(L.nblk), dim3(256), 0, stream, bitmap, L.nwords, bsum);
+    hipLaunchKernelGGL(blocksum_scan_kernel, dim3(1), dim3(1024), 0, stream, bsum, bbase, L.nblk, n_out_ptr, cap_out,
+                       status);
+    hipLaunchKernelGGL(down_emit_kernel, dim3(L.nblk), dim3(256), 0, stream, bitmap, L.nwords, bbase, d, cap_out,
+                       out_indices);
+    hipLaunchKernelGGL(nbr_down_kernel, dim3(cdiv(cap_out * 27, 256)), dim3(256), 0, stream, out_indices, n_out_ptr,
+                       cap_out, d, hv, nbr);
+    return sassd_launch_status();
+}
+
+extern "C" int sassd_rulebook_pairs(const int32_t *nbr, const int32_t *n_out_ptr, int cap_out, int K,
+                                    int32_t *pairs, int32_t *pair_num, void *stream_)
+{
+    if (!nbr || !n_out_ptr || !pairs || !pair_num || cap_out <= 0 || K <= 0) return SASSD_EINVAL;
+    hipLaunchKernelGGL(pairs_kernel, dim3(K), dim3(1024), 0, (hipStream_t)stream_, nbr, n_out_ptr, cap_out, K, pairs,
+                       pair_num);
+    return sassd_launch_status();
+}

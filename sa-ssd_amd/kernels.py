@@ -1,0 +1,326 @@
+"""Thin torch-tensor front-end over the C ABI (include/sassd.h).  torch is used only for device memory and
+the current HIP stream; every function here launches hand-written HIP kernels from libsassd.so and raises if
+the library is missing or a call fails (no CPU fallback, no eager-PyTorch fallback)."""
+import numpy as np
+import torch
+
+from . import _C
+
+_ws_cache = {}
+
+
+def workspace(name, nbytes, device):
+    """Grow-only cached scratch buffer (uint8) per (name, device)."""
+    key = (name, str(device))
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _chk_cuda(*ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.is_contiguous()):
+            raise RuntimeError("sassd kernels need contiguous CUDA(HIP) tensors")
+
+
+def new_status(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+# --------------------------------------------------------------------------------------------------
+def voxelize(points, voxel_size, coors_range, max_points, max_voxels, batch_idx=0, coors_cols=3,
+             want_voxels=True, want_mean=True, nfeat=4, out=None, row_offset=None, status=None, cap=None):
+    """points [N,ndim] f32 cuda.  Returns dict(voxels, coors, num_points, mean, voxel_num) of capacity-sized
+    tensors (rows [0, voxel_num) valid; voxel_num is a device int32 scalar)."""
+    _chk_cuda(points)
+    L = _C.lib()
+    n, ndim = points.shape
+    dev = points.device
+    vs, cr = _f32(voxel_size), _f32(coors_range)
+    cap = int(cap if cap is not None else max_voxels)
+    out = out or {}
+    voxels = out.get("voxels")
+    if want_voxels and voxels is None:
+        voxels = torch.empty(cap, max_points, ndim, dtype=torch.float32, device=dev)
+    coors = out.get("coors")
+    if coors is None:
+        coors = torch.empty(cap, coors_cols, dtype=torch.int32, device=dev)
+    num = out.get("num_points")
+    if num is None:
+        num = torch.empty(cap, dtype=torch.int32, device=dev)
+    mean = out.get("mean")
+    nfeat = min(nfeat, ndim)
+    if want_mean and mean is None:
+        mean = torch.empty(cap, nfeat, dtype=torch.float32, device=dev)
+    vnum = out.get("voxel_num")
+    if vnum is None:
+        vnum = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = L.sassd_voxelize_workspace_bytes(n, max_points)
+    ws = workspace("voxelize", wsb, dev)
+    rc = L.sassd_voxelize(_C.ptr(points), n, ndim, vs.ctypes.data, cr.ctypes.data, int(max_points), int(max_voxels),
+                          int(batch_idx), _C.ptr(voxels) if want_voxels else None, _C.ptr(coors), coors_cols,
+                          _C.ptr(num), _C.ptr(mean) if want_mean else None, nfeat, _C.ptr(row_offset), _C.ptr(vnum),
+                          cap, _C.ptr(status), _C.ptr(ws), wsb, _C.stream())
+    _C.check(rc, "sassd_voxelize")
+    return dict(voxels=voxels, coors=coors, num_points=num, mean=mean, voxel_num=vnum)
+
+
+def voxel_mean(voxels, num_points, nfeat=4):
+    _chk_cuda(voxels, num_points)
+    m, t, ndim = voxels.shape
+    out = torch.empty(m, nfeat, dtype=torch.float32, device=voxels.device)
+    rc = _C.lib().sassd_voxel_mean(_C.ptr(voxels), _C.ptr(num_points.int().contiguous()), m, t, ndim, nfeat,
+                                   _C.ptr(out), _C.stream())
+    _C.check(rc, "sassd_voxel_mean")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+class HashTable:
+    """coordinate -> row lookup table for one sparse level."""
+
+    def __init__(self, cap, device):
+        self.cap = int(cap)
+        self.nbytes = _C.lib().sassd_hash_bytes(self.cap)
+        self.buf = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+
+    def build(self, indices, n_ptr, shape, batch_size, status=None):
+        d, h, w = shape
+        rc = _C.lib().sassd_hash_build(_C.ptr(indices), _C.ptr(n_ptr), self.cap, d, h, w, batch_size,
+                                       _C.ptr(self.buf), self.nbytes, _C.ptr(status), _C.stream())
+        _C.check(rc, "sassd_hash_build")
+        return self
+
+
+def rulebook_subm(indices, n_ptr, cap, shape, batch_size, table, nbr=None):
+    d, h, w = shape
+    if nbr is None:
+        nbr = torch.empty(cap, 27, dtype=torch.int32, device=indices.device)
+    rc = _C.lib().sassd_rulebook_subm(_C.ptr(indices), _C.ptr(n_ptr), cap, d, h, w, batch_size, _C.ptr(table.buf),
+                                      table.nbytes, _C.ptr(nbr), _C.stream())
+    _C.check(rc, "sassd_rulebook_subm")
+    return nbr
+
+
+def conv_out_shape(shape):
+    return tuple((int(x) - 1) // 2 + 1 for x in shape)
+
+
+def rulebook_conv(indices, n_in_ptr, cap_in, shape, batch_size, table, cap_out, out_indices=None, n_out_ptr=None,
+                  nbr=None, status=None):
+    d, h, w = shape
+    dev = indices.device
+    L = _C.lib()
+    if out_indices is None:
+        out_indices = torch.empty(cap_out, 4, dtype=torch.int32, device=dev)
+    if n_out_ptr is None:
+        n_out_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+    if nbr is None:
+        nbr = torch.empty(cap_out, 27, dtype=torch.int32, device=dev)
+    wsb = L.sassd_rulebook_conv_workspace_bytes(d, h, w, batch_size)
+    ws = workspace("rulebook_conv", wsb, dev)
+    rc = L.sassd_rulebook_conv(_C.ptr(indices), _C.ptr(n_in_ptr), cap_in, d, h, w, batch_size, _C.ptr(table.buf),
+                               table.nbytes, _C.ptr(out_indices), _C.ptr(n_out_ptr), cap_out, _C.ptr(nbr),
+                               _C.ptr(status), _C.ptr(ws), wsb, _C.stream())
+    _C.check(rc, "sassd_rulebook_conv")
+    return out_indices, n_out_ptr, nbr
+
+
+def rulebook_pairs(nbr, n_out_ptr, cap_out):
+    dev = nbr.device
+    k = nbr.shape[1]
+    pairs = torch.full((k, 2, cap_out), -1, dtype=torch.int32, device=dev)
+    num = torch.zeros(k, dtype=torch.int32, device=dev)
+    rc = _C.lib().sassd_rulebook_pairs(_C.ptr(nbr), _C.ptr(n_out_ptr), cap_out, k, _C.ptr(pairs), _C.ptr(num),
+                                       _C.stream())
+    _C.check(rc, "sassd_rulebook_pairs")
+    return pairs, num
+
+
+# --------------------------------------------------------------------------------------------------
+def spconv_pack_weight(w):
+    """w [K, Cin, Cout] f32 cuda (spconv layout flattened) -> packed MFMA-fragment order."""
+    _chk_cuda(w)
+    k, cin, cout = w.shape
+    packed = torch.empty(_C.lib().sassd_spconv_packed_floats(k, cin, cout), dtype=torch.float32, device=w.device)
+    rc = _C.lib().sassd_spconv_pack_weight(_C.ptr(w), k, cin, cout, _C.ptr(packed), _C.stream())
+    _C.check(rc, "sassd_spconv_pack_weight")
+    return packed
+
+
+def spconv_fwd(x, nbr, n_out_ptr, cap_out, w_packed, k, cin, cout, scale=None, shift=None, relu=False, y=None):
+    _chk_cuda(x, nbr, w_packed, scale, shift)
+    if y is None:
+        y = torch.empty(cap_out, cout, dtype=torch.float32, device=x.device)
+    rc = _C.lib().sassd_spconv_fwd(_C.ptr(x), _C.ptr(nbr), _C.ptr(n_out_ptr), cap_out, _C.ptr(w_packed), k, cin, cout,
+                                   _C.ptr(scale), _C.ptr(shift), 1 if relu else 0, _C.ptr(y), _C.stream())
+    _C.check(rc, "sassd_spconv_fwd")
+    return y
+
+
+def densify(feats, indices, n_ptr, cap, shape, batch_size, channel_order=0, out=None):
+    d, h, w = shape
+    c = feats.shape[1]
+    if out is None:
+        out = torch.empty(batch_size, c * d, h, w, dtype=torch.float32, device=feats.device)
+    rc = _C.lib().sassd_densify(_C.ptr(feats), _C.ptr(indices), _C.ptr(n_ptr), cap, c, d, h, w, batch_size,
+                                channel_order, _C.ptr(out), _C.stream())
+    _C.check(rc, "sassd_densify")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+def conv2d_pack_weight(w):
+    """w [Cout, Cin, k, k] f32 cuda (torch layout) -> packed [Cin/8][k*k][8][CoutPad]."""
+    _chk_cuda(w)
+    cout, cin, ks, _ = w.shape
+    packed = torch.empty(_C.lib().sassd_conv2d_packed_floats(cin, cout, ks), dtype=torch.float32, device=w.device)
+    rc = _C.lib().sassd_conv2d_pack_weight(_C.ptr(w), cout, cin, ks, _C.ptr(packed), _C.stream())
+    _C.check(rc, "sassd_conv2d_pack_weight")
+    return packed
+
+
+def conv2d_fwd(x, w_packed, cout, ksize, scale=None, shift=None, relu=False, y=None):
+    _chk_cuda(x, w_packed, scale, shift)
+    b, cin, h, w = x.shape
+    if y is None:
+        y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
+    rc = _C.lib().sassd_conv2d_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
+                                   _C.ptr(y), b, cin, cout, h, w, ksize, _C.stream())
+    _C.check(rc, "sassd_conv2d_fwd")
+    return y
+
+
+# --------------------------------------------------------------------------------------------------
+def anchor_mask(coors, row_begin_ptr, row_end_ptr, h0, w0, anchors_bv, voxel_size, coors_range, area_threshold,
+                mask=None):
+    dev = coors.device
+    L = _C.lib()
+    n = anchors_bv.shape[0]
+    if mask is None:
+        mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    vs, cr = _f32(voxel_size), _f32(coors_range)
+    wsb = L.sassd_anchor_mask_workspace_bytes(h0, w0)
+    ws = workspace("anchor_mask", wsb, dev)
+    rc = L.sassd_anchor_mask(_C.ptr(coors), _C.ptr(row_begin_ptr), _C.ptr(row_end_ptr), h0, w0, _C.ptr(anchors_bv),
+                             n, vs.ctypes.data, cr.ctypes.data, float(area_threshold), _C.ptr(mask), _C.ptr(ws), wsb,
+                             _C.stream())
+    _C.check(rc, "sassd_anchor_mask")
+    return mask
+
+
+def decode_filter(box, cls, dirp, batch_stride, batch, num_class, anchors_per_loc, h, w, anchors, mask, thr, cap_k,
+                  out=None, status=None):
+    dev = box.device
+    L = _C.lib()
+    out = out or {}
+    guided = out.get("guided")
+    if guided is None:
+        guided = torch.empty(batch, cap_k, 7, dtype=torch.float32, device=dev)
+    labels = out.get("labels")
+    if labels is None:
+        labels = torch.empty(batch, cap_k, dtype=torch.int32, device=dev)
+    scores = out.get("scores")
+    if scores is None:
+        scores = torch.empty(batch, cap_k, dtype=torch.float32, device=dev)
+    counts = out.get("counts")
+    if counts is None:
+        counts = torch.zeros(batch, dtype=torch.int32, device=dev)
+    atot = num_class * h * w * anchors_per_loc
+    wsb = L.sassd_decode_filter_workspace_bytes(batch, atot)
+    ws = workspace("decode_filter", wsb, dev)
+    rc = L.sassd_decode_filter(_C.ptr(box), _C.ptr(cls), _C.ptr(dirp), int(batch_stride), batch, num_class,
+                               anchors_per_loc, h, w, _C.ptr(anchors), _C.ptr(mask), float(thr), _C.ptr(guided),
+                               _C.ptr(labels), _C.ptr(scores), _C.ptr(counts), cap_k, _C.ptr(status), _C.ptr(ws), wsb,
+                               _C.stream())
+    _C.check(rc, "sassd_decode_filter")
+    return dict(guided=guided, labels=labels, scores=scores, counts=counts)
+
+
+def pswarp_sample(feat, guided, counts, cap_k, grid_offsets, spatial_scale, logits=None):
+    b, parts, h, w = feat.shape
+    assert parts == 28, "PSWarp window is 4x7 (ssd_rotate_head.py:374)"
+    if logits is None:
+        logits = torch.zeros(b, cap_k, dtype=torch.float32, device=feat.device)
+    rc = _C.lib().sassd_pswarp_sample(_C.ptr(feat), b, h, w, _C.ptr(guided), _C.ptr(counts), cap_k,
+                                      float(grid_offsets[0]), float(grid_offsets[1]), float(spatial_scale),
+                                      _C.ptr(logits), _C.stream())
+    _C.check(rc, "sassd_pswarp_sample")
+    return logits
+
+
+def rescore_nms(guided, logits, labels, counts, score_thr, iou_thr, cap_d, out=None, status=None):
+    dev = guided.device
+    L = _C.lib()
+    b, cap_k, _ = guided.shape
+    out = out or {}
+    boxes = out.get("boxes")
+    if boxes is None:
+        boxes = torch.empty(b, cap_d, 7, dtype=torch.float32, device=dev)
+    scores = out.get("scores")
+    if scores is None:
+        scores = torch.empty(b, cap_d, dtype=torch.float32, device=dev)
+    olabels = out.get("labels")
+    if olabels is None:
+        olabels = torch.empty(b, cap_d, dtype=torch.int32, device=dev)
+    ocounts = out.get("counts")
+    if ocounts is None:
+        ocounts = torch.zeros(b, dtype=torch.int32, device=dev)
+    wsb = L.sassd_rescore_nms_workspace_bytes(b, cap_k)
+    ws = workspace("rescore_nms", wsb, dev)
+    rc = L.sassd_rescore_nms(_C.ptr(guided), _C.ptr(logits), _C.ptr(labels), _C.ptr(counts), b, cap_k,
+                             float(score_thr), float(iou_thr), _C.ptr(boxes), _C.ptr(scores), _C.ptr(olabels),
+                             _C.ptr(ocounts), cap_d, _C.ptr(status), _C.ptr(ws), wsb, _C.stream())
+    _C.check(rc, "sassd_rescore_nms")
+    return dict(boxes=boxes, scores=scores, labels=olabels, counts=ocounts)
+
+
+# --------------------------------------------------------------------------------------------------
+def boxes_overlap_bev(a, b, out=None):
+    _chk_cuda(a, b)
+    if out is None:
+        out = torch.zeros(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
+    rc = _C.lib().sassd_boxes_overlap_bev(_C.ptr(a), a.shape[0], _C.ptr(b), b.shape[0], _C.ptr(out), _C.stream())
+    _C.check(rc, "sassd_boxes_overlap_bev")
+    return out
+
+
+def boxes_iou_bev(a, b, out=None):
+    _chk_cuda(a, b)
+    if out is None:
+        out = torch.zeros(a.shape[0], b.shape[0], dtype=torch.float32, device=a.device)
+    rc = _C.lib().sassd_boxes_iou_bev(_C.ptr(a), a.shape[0], _C.ptr(b), b.shape[0], _C.ptr(out), _C.stream())
+    _C.check(rc, "sassd_boxes_iou_bev")
+    return out
+
+
+def nms_gpu(boxes_sorted, thresh):
+    """boxes [N,5] sorted by descending score -> (keep int64 device [N], num_keep int32 device [1])."""
+    _chk_cuda(boxes_sorted)
+    n = boxes_sorted.shape[0]
+    dev = boxes_sorted.device
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = _C.lib()
+    wsb = L.sassd_nms_workspace_bytes(n)
+    ws = workspace("nms", wsb, dev)
+    rc = L.sassd_nms_gpu(_C.ptr(boxes_sorted), n, float(thresh), _C.ptr(keep), _C.ptr(num), _C.ptr(ws), wsb,
+                         _C.stream())
+    _C.check(rc, "sassd_nms_gpu")
+    return keep, num
+
+
+def mfma_probe(a32, b32, a16, b16, ksteps):
+    dev = a32.device
+    d32 = torch.zeros(32, 32, dtype=torch.float32, device=dev)
+    d16 = torch.zeros(16, 16, dtype=torch.float32, device=dev)
+    rc = _C.lib().sassd_mfma_probe(_C.ptr(a32), _C.ptr(b32), _C.ptr(d32), _C.ptr(a16), _C.ptr(b16), _C.ptr(d16),
+                                   ksteps, _C.stream())
+    _C.check(rc, "sassd_mfma_probe")
+    return d32, d16

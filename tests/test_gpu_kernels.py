@@ -1,0 +1,204 @@
+"""-m gpu parity tests: every HIP kernel (through the C ABI) against the CPU oracle / golden fixtures."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sassd
+from sassd import kernels as K, synth
+from oracle import clib, nets as onets, rulebook as orb
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_mfma_lane_maps(dev):
+    g = torch.Generator().manual_seed(0)
+    ks = 5
+    a32 = torch.randn(32, 2 * ks, generator=g); b32 = torch.randn(2 * ks, 32, generator=g)
+    a16 = torch.randn(16, 4 * ks, generator=g); b16 = torch.randn(4 * ks, 16, generator=g)
+    d32, d16 = K.mfma_probe(a32.to(dev), b32.to(dev), a16.to(dev), b16.to(dev), ks)
+    assert torch.allclose(d32.cpu(), a32 @ b32, atol=1e-5), (d32.cpu() - a32 @ b32).abs().max()
+    assert torch.allclose(d16.cpu(), a16 @ b16, atol=1e-5), (d16.cpu() - a16 @ b16).abs().max()
+
+
+def _run_vox(dev, pts, vs, cr, t, mv, **kw):
+    p = torch.from_numpy(np.ascontiguousarray(pts)).to(dev)
+    st = K.new_status(dev)
+    r = K.voxelize(p, vs, cr, t, mv, status=st, **kw)
+    m = int(r["voxel_num"].item())
+    assert int(st.item()) == 0
+    return m, r
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "voxelizer_*.npz"))))
+def test_voxelizer_golden(dev, path):
+    g = np.load(path)
+    if "points" not in g:
+        pytest.skip("digest file")
+    m, r = _run_vox(dev, g["points"], g["voxel_size"], g["coors_range"], int(g["max_points"]), int(g["max_voxels"]))
+    assert m == len(g["coors"])
+    assert np.array_equal(r["coors"][:m].cpu().numpy(), g["coors"])
+    assert np.array_equal(r["num_points"][:m].cpu().numpy(), g["num_points"])
+    assert np.array_equal(r["voxels"][:m].cpu().numpy(), g["voxels"])          # bit exact payload
+    mean = clib.voxel_mean(g["voxels"], g["num_points"]) if m else np.zeros((0, 4), np.float32)
+    assert np.array_equal(r["mean"][:m].cpu().numpy(), mean)
+
+
+@pytest.mark.parametrize("name,seed", [("k21", 0), ("k17", 0), ("k21", 3)])
+def test_voxelizer_full_frame(dev, name, seed):
+    pts = H.frame(name, seed)
+    v, c, n = clib.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 20000)
+    m, r = _run_vox(dev, pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 20000, coors_cols=4, batch_idx=3)
+    assert m == len(c)
+    co = r["coors"][:m].cpu().numpy()
+    assert np.all(co[:, 0] == 3) and np.array_equal(co[:, 1:], c)
+    assert np.array_equal(r["num_points"][:m].cpu().numpy(), n)
+    assert np.array_equal(r["voxels"][:m].cpu().numpy(), v)
+    assert np.array_equal(r["mean"][:m].cpu().numpy(), clib.voxel_mean(v, n))
+    if name == "k21" and seed == 0:
+        assert m == 16111
+
+
+def test_voxelizer_waymo_scale_break(dev):
+    pts = synth.waymo_synth(0)[:180000]
+    v, c, n = clib.points_to_voxel(pts, synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, True, 60000)   # break triggers
+    m, r = _run_vox(dev, pts, synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, 60000)
+    assert m == 60000 == len(c)
+    assert np.array_equal(r["coors"][:m].cpu().numpy(), c)
+    assert np.array_equal(r["num_points"][:m].cpu().numpy(), n)
+    assert np.array_equal(r["voxels"][:m].cpu().numpy(), v)
+
+
+def _pairs_set(pairs, num, k):
+    return set(zip(pairs[k, 0, :num[k]].tolist(), pairs[k, 1, :num[k]].tolist()))
+
+
+def _level0(dev, name="k21", seed=0, batch=1):
+    idx = []
+    for b in range(batch):
+        _, c, _ = clib.points_to_voxel(H.frame(name, seed + b), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 20000)
+        idx.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+    return np.concatenate(idx, 0)
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_rulebooks(dev, batch):
+    idx = _level0(dev, "k21", 0, batch)
+    shape = (40, 1600, 1408)
+    for level in range(3):
+        n = len(idx)
+        cap = n + 100
+        di = torch.zeros(cap, 4, dtype=torch.int32, device=dev)
+        di[:n] = torch.from_numpy(idx).to(dev)
+        nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+        st = K.new_status(dev)
+        tab = K.HashTable(cap, dev).build(di, nptr, shape, batch, st)
+        nbr = K.rulebook_subm(di, nptr, cap, shape, batch, tab)
+        _, onbr = orb.subm_rulebook(idx, shape)
+        assert np.array_equal(nbr[:n].cpu().numpy(), onbr), "subm level %d" % level
+        # spconv-format pairs derived on device
+        pairs, num = K.rulebook_pairs(nbr, nptr, cap)
+        op, onum = orb.nbr_to_pairs(onbr)
+        assert np.array_equal(num.cpu().numpy(), onum)
+        pc = pairs.cpu().numpy()
+        for k in (0, 13, 26):
+            assert _pairs_set(pc, onum, k) == set(zip(op[k][0].tolist(), op[k][1].tolist()))
+        # strided conv
+        cap_out = 2 * n + 64
+        oi, on, onb = K.rulebook_conv(di, nptr, cap, shape, batch, tab, cap_out, status=st)
+        ref_oi, ref_nbr, oshape = orb.conv_rulebook(idx, shape, batch)
+        m = int(on.item())
+        assert int(st.item()) == 0
+        assert m == len(ref_oi), "down level %d" % level
+        assert np.array_equal(oi[:m].cpu().numpy(), ref_oi)
+        assert np.array_equal(onb[:m].cpu().numpy(), ref_nbr)
+        idx, shape = ref_oi, oshape
+    assert shape == (5, 200, 176)
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64)])
+def test_spconv_layer(dev, cin, cout):
+    idx = _level0(dev, "small", 1)
+    shape = (40, 1600, 1408)
+    # use a coarser level so neighbourhoods are dense enough to exercise multi-chunk offsets
+    idx, nbr1, shape = orb.conv_rulebook(idx, shape, 1)
+    idx, nbr2, shape = orb.conv_rulebook(idx, shape, 1)
+    _, nbr = orb.subm_rulebook(idx, shape)
+    n = len(idx)
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(27, cin, cout, generator=g) * 0.2
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = torch.relu(onets.sparse_conv(x, nbr, w) * scale + shift)
+    cap = n + 37
+    nb = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+    nb[:n] = torch.from_numpy(nbr).to(dev)
+    nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+    wp = K.spconv_pack_weight(w.to(dev))
+    y = K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout, scale.to(dev), shift.to(dev), True)
+    err = (y[:n].cpu() - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+    # raw conv (no epilogue) and the 1x1x1 identity path
+    y2 = K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout)
+    assert (y2[:n].cpu() - onets.sparse_conv(x, nbr, w)).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    w1 = torch.randn(1, cin, cout, generator=g) * 0.2
+    y3 = K.spconv_fwd(x.to(dev), None, nptr, cap, K.spconv_pack_weight(w1.to(dev)), 1, cin, cout)
+    assert (y3[:n].cpu() - x @ w1[0]).abs().max().item() < 1e-4
+
+
+def test_densify(dev):
+    g = torch.Generator().manual_seed(0)
+    n, c, shape, b = 500, 64, (5, 200, 176), 2
+    lin = torch.randperm(b * 5 * 200 * 176, generator=g)[:n].sort()[0]
+    idx = torch.stack([lin // (5 * 200 * 176), (lin // (200 * 176)) % 5, (lin // 176) % 200, lin % 176], 1).int()
+    f = torch.randn(n, c, generator=g)
+    ref = onets.densify(f, idx.numpy(), shape, b)
+    nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+    out = K.densify(f.to(dev), idx.to(dev), nptr, n, shape, b, 0)
+    assert torch.equal(out.cpu(), ref)
+    out1 = K.densify(f.to(dev), idx.to(dev), nptr, n, shape, b, 1).cpu()
+    ref1 = ref.view(b, c, 5, 200, 176).permute(0, 2, 1, 3, 4).reshape(b, c * 5, 200, 176)
+    assert torch.equal(out1, ref1)
+
+
+@pytest.mark.parametrize("cin,cout,ks,h,w,b", [(16, 256, 3, 20, 176, 1), (320, 256, 3, 11, 176, 2), (256, 256, 1, 9, 176, 1),
+                                               (256, 28, 3, 13, 176, 1), (256, 20, 1, 7, 50, 2), (8, 128, 3, 200, 176, 1),
+                                               (24, 72, 1, 5, 31, 1)])
+def test_conv2d(dev, cin, cout, ks, h, w, b):
+    g = torch.Generator().manual_seed(cin + cout + ks)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, ks, ks, generator=g) * (1.0 / (cin * ks * ks)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = torch.relu(torch.nn.functional.conv2d(x, wt, None, 1, ks // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    wp = K.conv2d_pack_weight(wt.to(dev))
+    y = K.conv2d_fwd(x.to(dev), wp, cout, ks, scale.to(dev), shift.to(dev), True).cpu()
+    err = (y - ref).abs().max().item()
+    assert err < 1e-4, err
+    y2 = K.conv2d_fwd(x.to(dev), wp, cout, ks).cpu()
+    assert (y2 - torch.nn.functional.conv2d(x, wt, None, 1, ks // 2)).abs().max().item() < 1e-4
+
+
+def test_iou_matrices_and_nms(dev):
+    g = np.load(os.path.join(GOLD, "iou_ref.npz"))
+    a, b = torch.from_numpy(g["a"]).to(dev), torch.from_numpy(g["b"]).to(dev)
+    ov = K.boxes_overlap_bev(a, b).cpu().numpy()
+    iou = K.boxes_iou_bev(a, b).cpu().numpy()
+    assert np.abs(ov - g["overlap"]).max() < 1e-4, np.abs(ov - g["overlap"]).max()
+    assert np.abs(iou - g["iou"]).max() < 1e-5, np.abs(iou - g["iou"]).max()
+    rng = np.random.default_rng(1)
+    for n in (1, 63, 64, 65, 200, 700):
+        boxes = H.rand_bev_boxes(rng, n, spread=25.0)
+        keep_ref, mask_ref = clib.nms_rotated(boxes, 0.1, return_mask=True)
+        keep, num = K.nms_gpu(torch.from_numpy(boxes).to(dev), 0.1)
+        k = int(num.item())
+        got = keep[:k].cpu().numpy()
+        if not np.array_equal(got, keep_ref):
+            # only IoU values within 1e-5 of the threshold may legitimately differ
+            iou_m = clib.boxes_iou_bev(boxes, boxes)
+            assert np.any(np.abs(iou_m - 0.1) < 1e-5), (n, got, keep_ref)

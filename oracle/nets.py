@@ -223,3 +223,23 @@ def rescore(guided, logits, labels, score_thr=0.3, iou_thr=0.1):
     keep = clib.nms_rotated(bev[order].numpy(), iou_thr)
     k = order[torch.as_tensor(keep)]
     return bp[k].numpy(), s[k].numpy(), lb[k].numpy()
+
+
+def anchors_mask(coors_zyx, anchors_bv, voxel_size, pc_range, grid_size_xyz, area_threshold=1):
+    """kitti.py:333-343 + geometry.py:676-710: occupancy integral image + per-anchor area > threshold.
+    coors_zyx [M,3] int32; anchors_bv [A,4] f32 (xmin,ymin,xmax,ymax); grid_size_xyz (W0,H0,D0)."""
+    w0, h0 = int(grid_size_xyz[0]), int(grid_size_xyz[1])
+    dense = np.zeros((h0, w0), np.float32)
+    np.add.at(dense, (coors_zyx[:, 1], coors_zyx[:, 2]), 1.0)
+    dense = dense.cumsum(0).cumsum(1)
+    vs = np.asarray(voxel_size, np.float32)
+    off = np.asarray(pc_range, np.float32)
+    bv = np.asarray(anchors_bv, np.float32)
+    c0 = np.floor((bv[:, 0] - off[0]) / vs[0]).astype(np.int32)
+    c1 = np.floor((bv[:, 1] - off[1]) / vs[1]).astype(np.int32)
+    c2 = np.floor((bv[:, 2] - off[0]) / vs[0]).astype(np.int32)
+    c3 = np.floor((bv[:, 3] - off[1]) / vs[1]).astype(np.int32)
+    c0 = np.maximum(c0, 0); c1 = np.maximum(c1, 0)
+    c2 = np.minimum(c2, w0 - 1); c3 = np.minimum(c3, h0 - 1)
+    area = dense[c3, c2] - dense[c3, c0] - dense[c1, c2] + dense[c1, c0]
+    return area > area_threshold

@@ -1,0 +1,277 @@
+"""Device-resident whole-frame inference plan: raw points (or reference-style voxel inputs) -> detections.
+
+This is the production path of the drop-in: the same kernels the per-op facades call, chained on ONE HIP stream
+with every data-dependent size kept in device memory, so a frame is a fixed launch sequence with zero host syncs
+between the first kernel and the final result read-back (the reference path has >= 6 syncs per sample,
+SURVEY.md 3.1).  Eval-mode BatchNorm is folded into per-channel (scale, shift) applied in the conv epilogues.
+
+Stages / reference lines:
+  voxelize + mean      points_ops.py:104-164, vxnet.py:110-116          sassd_voxelize
+  rulebooks x7         cmn.py:147-173 (spconv get_indice_pairs)         sassd_hash_build / rulebook_subm / rulebook_conv
+  sparse convs x14     cmn.py:192-231 (+BN1d+ReLU)                      sassd_spconv_fwd
+  dense()              cmn.py:112-114                                   sassd_densify (d-major channels, conv0 permuted)
+  BEVNet x8            cmn.py:233-282                                   sassd_conv2d_fwd (fp32 MFMA)
+  SSD head (fused 1x1) ssd_rotate_head.py:218-235                       sassd_conv2d_fwd
+  anchors_mask         kitti.py:333-343                                 sassd_anchor_mask
+  guided anchors       ssd_rotate_head.py:307-372                       sassd_decode_filter
+  PSWarp               ssd_rotate_head.py:416-447                       sassd_conv2d_fwd x2 + sassd_pswarp_sample
+  rescore + NMS        ssd_rotate_head.py:487-533                       sassd_rescore_nms
+"""
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import anchors as A
+
+BN_EPS = 1e-3
+
+# (state-dict prefix under neck.backbone, bn prefix, kind, Cin, Cout, rulebook key) -- VxNet, cmn.py:197-212
+VXNET = [
+    ("conv0.0", "conv0.1", "subm", 4, 16, "subm0"), ("conv0.3", "conv0.4", "subm", 16, 16, "subm0"),
+    ("down0.0", "down0.1", "down", 16, 32, "down0"),
+    ("conv1.0", "conv1.1", "subm", 32, 32, "subm1"), ("conv1.3", "conv1.4", "subm", 32, 32, "subm1"),
+    ("down1.0", "down1.1", "down", 32, 64, "down1"),
+    ("conv2.0", "conv2.1", "subm", 64, 64, "subm2"), ("conv2.3", "conv2.4", "subm", 64, 64, "subm2"),
+    ("conv2.6", "conv2.7", "subm", 64, 64, "subm2"),
+    ("down2.0", "down2.1", "down", 64, 64, "down2"),
+    ("conv3.0", "conv3.1", "subm", 64, 64, "subm3"), ("conv3.3", "conv3.4", "subm", 64, 64, "subm3"),
+    ("conv3.6", "conv3.7", "subm", 64, 64, "subm3"),
+    ("extra_conv.0", "extra_conv.1", "1x1", 64, 64, None),
+]
+
+
+def fold_bn(sd, prefix, eps=BN_EPS):
+    g, b = sd[prefix + ".weight"].float(), sd[prefix + ".bias"].float()
+    m, v = sd[prefix + ".running_mean"].float(), sd[prefix + ".running_var"].float()
+    scale = g / torch.sqrt(v + eps)
+    return scale.contiguous(), (b - m * scale).contiguous()
+
+
+class InferencePlan:
+    """Pre-packed weights + pre-allocated buffers for a fixed (batch_size, config)."""
+
+    def __init__(self, state_dict, *, batch_size=1, num_class=1, voxel_size=(0.05, 0.05, 0.1),
+                 point_cloud_range=(0, -40., -3., 70.4, 40., 1.), max_num_points=5, max_voxels=20000,
+                 sparse_shape=(40, 1600, 1408), anchors=None, anchors_bv=None, anchor_area_threshold=1,
+                 anchors_per_loc=2, grid_offsets=(0., 40.), featmap_stride=0.4, rpn_thr=0.1, score_thr=0.3,
+                 iou_thr=0.1, cap_k=2048, cap_d=512, device=None, level_cap_factor=2):
+        dev = torch.device(device if device is not None else "cuda:0")
+        self.dev, self.B, self.ncls, self.A = dev, int(batch_size), int(num_class), int(anchors_per_loc)
+        self.voxel_size = np.asarray(voxel_size, np.float32)
+        self.pc_range = np.asarray(point_cloud_range, np.float32)
+        self.T, self.max_voxels = int(max_num_points), int(max_voxels)
+        self.shape0 = tuple(int(s) for s in sparse_shape)
+        self.rpn_thr, self.score_thr, self.iou_thr = float(rpn_thr), float(score_thr), float(iou_thr)
+        self.grid_offsets, self.spatial_scale = grid_offsets, 1.0 / featmap_stride
+        self.area_thr = anchor_area_threshold
+        self.capK, self.capD = int(cap_k), int(cap_d)
+        sd = {k: v.detach().to(dev) for k, v in state_dict.items()}
+
+        # ---- level geometry / capacities ----------------------------------------------------------
+        self.shapes = [self.shape0]
+        for _ in range(3):
+            self.shapes.append(K.conv_out_shape(self.shapes[-1]))
+        cap0 = self.B * self.max_voxels
+        self.caps = [cap0] + [cap0 * level_cap_factor] * 3
+        D3, self.H, self.W = self.shapes[3]
+        self.D3 = D3
+
+        # ---- sparse weights -----------------------------------------------------------------------
+        self.sp = []
+        for wname, bnname, kind, cin, cout, key in VXNET:
+            w = sd["neck.backbone.%s.weight" % wname].float()
+            k = 1 if kind == "1x1" else 27
+            wp = K.spconv_pack_weight(w.reshape(k, cin, cout).contiguous())
+            scale, shift = fold_bn(sd, "neck.backbone.%s" % bnname)
+            self.sp.append((kind, cin, cout, key, wp, scale, shift))
+
+        # ---- dense weights ------------------------------------------------------------------------
+        self.bev = []
+        for i in range(8):
+            w = sd["neck.fcn.conv%d.weight" % i].float()
+            if i == 0:      # densify writes d-major channels (d*C + c); reference order is c*D + d (cmn.py:113-114)
+                cout, cin = w.shape[:2]
+                c = cin // D3
+                w = w.view(cout, c, D3, 3, 3).permute(0, 2, 1, 3, 4).reshape(cout, cin, 3, 3)
+            scale, shift = fold_bn(sd, "neck.fcn.bn%d" % i)
+            self.bev.append((K.conv2d_pack_weight(w.contiguous()), w.shape[0], w.shape[2], scale, shift))
+        hw = torch.cat([sd["rpn_head.conv_box.weight"], sd["rpn_head.conv_cls.weight"],
+                        sd["rpn_head.conv_dir_cls.weight"]], 0).float().contiguous()
+        hb = torch.cat([sd["rpn_head.conv_box.bias"], sd["rpn_head.conv_cls.bias"],
+                        sd["rpn_head.conv_dir_cls.bias"]], 0).float().contiguous()
+        self.n_box = sd["rpn_head.conv_box.weight"].shape[0]
+        self.n_cls = sd["rpn_head.conv_cls.weight"].shape[0]
+        self.n_dir = sd["rpn_head.conv_dir_cls.weight"].shape[0]
+        self.head_c = hw.shape[0]
+        self.head_w, self.head_b = K.conv2d_pack_weight(hw), hb
+        w0 = sd["extra_head.convs.0.weight"].float().contiguous()
+        self.ps_parts = w0.shape[0]
+        self.ps_w0 = K.conv2d_pack_weight(w0)
+        self.ps_s0, self.ps_b0 = fold_bn(sd, "extra_head.convs.1")
+        self.ps_w1 = K.conv2d_pack_weight(sd["extra_head.convs.3.weight"].float().contiguous())
+
+        # ---- anchors --------------------------------------------------------------------------------
+        self.Atot = self.ncls * self.H * self.W * self.A
+        if anchors is not None:
+            an = np.asarray(anchors, np.float32).reshape(-1, 7)
+            assert an.shape[0] == self.Atot, (an.shape, self.Atot)
+            self.anchors = torch.from_numpy(np.ascontiguousarray(an)).to(dev)
+            bv = anchors_bv if anchors_bv is not None else A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]])
+            self.anchors_bv = torch.from_numpy(np.ascontiguousarray(bv, np.float32)).to(dev)
+        else:
+            self.anchors = self.anchors_bv = None
+
+        # ---- buffers --------------------------------------------------------------------------------
+        B, H, W = self.B, self.H, self.W
+        i32, f32 = torch.int32, torch.float32
+        z = lambda *s, dt=f32: torch.zeros(*s, dtype=dt, device=dev)       # noqa: E731
+        self.status = z(1, dt=i32)
+        self.row_off = z(B + 1, dt=i32)
+        self.vnum = z(B, dt=i32)
+        self.n = [self.row_off[B:B + 1]] + [z(1, dt=i32) for _ in range(3)]       # device row counts per level
+        self.idx = [z(c, 4, dt=i32) for c in self.caps]
+        self.tables = [K.HashTable(c, dev) for c in self.caps]
+        self.nbr = {key: z(self.caps[lvl], 27, dt=i32)
+                    for key, lvl in (("subm0", 0), ("down0", 1), ("subm1", 1), ("down1", 2), ("subm2", 2),
+                                     ("down2", 3), ("subm3", 3))}
+        self.feat = [z(max(self.caps), 64), z(max(self.caps), 64)]
+        self.mean = z(self.caps[0], 4)
+        self.dense = z(B, 64 * D3, H, W)
+        self.act = [z(B, 256, H, W) for _ in range(3)]
+        self.head_out = z(B, self.head_c, H, W)
+        self.ps_t = [z(B, self.ps_parts, H, W), z(B, self.ps_parts, H, W)]
+        self.mask = z(B, self.Atot, dt=torch.uint8)
+        self.df = dict(guided=z(B, self.capK, 7), labels=z(B, self.capK, dt=i32), scores=z(B, self.capK),
+                       counts=z(B, dt=i32))
+        self.logits = z(B, self.capK)
+        self.det = dict(boxes=z(B, self.capD, 7), scores=z(B, self.capD), labels=z(B, self.capD, dt=i32),
+                        counts=z(B, dt=i32))
+        self.middle = {}
+
+    # ------------------------------------------------------------------------------------------------
+    def voxelize(self, clouds):
+        """clouds: list of B device tensors [Ni, ndim] f32.  Fills idx[0] (b,z,y,x), mean, row_off."""
+        assert len(clouds) == self.B
+        self.row_off.zero_()
+        for b, pts in enumerate(clouds):
+            K.voxelize(pts, self.voxel_size, self.pc_range, self.T, self.max_voxels, batch_idx=b, coors_cols=4,
+                       want_voxels=False, want_mean=True, nfeat=4,
+                       out=dict(coors=self.idx[0], mean=self.mean, voxel_num=self.vnum[b:b + 1],
+                                num_points=self._numpts()),
+                       row_offset=self.row_off[b:b + 2], status=self.status, cap=self.caps[0])
+
+    def _numpts(self):
+        if not hasattr(self, "_np"):
+            self._np = torch.zeros(self.caps[0], dtype=torch.int32, device=self.dev)
+        return self._np
+
+    def load_voxels(self, voxel_feats, coors4):
+        """Reference-style inputs (single_stage.py:110-117): mean features [M,4] and coords [M,4] (b,z,y,x)."""
+        m = voxel_feats.shape[0]
+        assert m <= self.caps[0]
+        self.mean[:m].copy_(voxel_feats)
+        self.idx[0][:m].copy_(coors4.int())
+        self.row_off.zero_()
+        bc = torch.bincount(coors4[:, 0].long(), minlength=self.B).cumsum(0).int()
+        self.row_off[1:].copy_(bc)
+
+    def backbone(self, keep_middle=False):
+        B = self.B
+        x = self.mean
+        lvl = 0
+        self.tables[0].build(self.idx[0], self.n[0], self.shapes[0], B, self.status)
+        built = set()
+        cur = 0
+        for li, (kind, cin, cout, key, wp, scale, shift) in enumerate(self.sp):
+            y = self.feat[cur]
+            if kind == "subm":
+                if key not in built:
+                    K.rulebook_subm(self.idx[lvl], self.n[lvl], self.caps[lvl], self.shapes[lvl], B, self.tables[lvl],
+                                    self.nbr[key])
+                    built.add(key)
+                K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y)
+            elif kind == "down":
+                K.rulebook_conv(self.idx[lvl], self.n[lvl], self.caps[lvl], self.shapes[lvl], B, self.tables[lvl],
+                                self.caps[lvl + 1], self.idx[lvl + 1], self.n[lvl + 1], self.nbr[key], self.status)
+                lvl += 1
+                K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y)
+                self.tables[lvl].build(self.idx[lvl], self.n[lvl], self.shapes[lvl], B, self.status)
+            else:
+                K.spconv_fwd(x, None, self.n[lvl], self.caps[lvl], wp, 1, cin, cout, scale, shift, True, y)
+            if keep_middle:
+                self.middle[li] = (y.clone(), lvl, cout)
+            x = y
+            cur ^= 1
+        self.sp_out = x
+        K.densify(x, self.idx[3], self.n[3], self.caps[3], self.shapes[3], B, 1, self.dense)
+
+    def bev_and_heads(self):
+        x = self.dense
+        for i, (wp, cout, ks, scale, shift) in enumerate(self.bev):
+            y = self.act[i % 2] if i < 7 else self.act[2]
+            K.conv2d_fwd(x, wp, cout, ks, scale, shift, True, y)
+            x = y
+            if i == 6:
+                self.conv6 = y
+        self.x = x
+        K.conv2d_fwd(x, self.head_w, self.head_c, 1, None, self.head_b, False, self.head_out)
+        K.conv2d_fwd(self.conv6, self.ps_w0, self.ps_parts, 3, self.ps_s0, self.ps_b0, True, self.ps_t[0])
+        K.conv2d_fwd(self.ps_t[0], self.ps_w1, self.ps_parts, 1, None, None, False, self.ps_t[1])
+
+    def anchor_masks(self, masks=None):
+        if masks is not None:
+            self.mask.copy_(masks.view(self.B, -1).to(torch.uint8))
+            return
+        H0, W0 = self.shape0[1], self.shape0[2]
+        for b in range(self.B):
+            K.anchor_mask(self.idx[0], self.row_off[b:b + 1], self.row_off[b + 1:b + 2], H0, W0, self.anchors_bv,
+                          self.voxel_size, self.pc_range, self.area_thr, self.mask[b])
+
+    def post(self):
+        HW = self.H * self.W
+        ho = self.head_out
+        base = ho.view(-1)
+        box = base
+        cls = base[self.n_box * HW:]
+        dirp = base[(self.n_box + self.n_cls) * HW:]
+        K.decode_filter(box, cls, dirp, self.head_c * HW, self.B, self.ncls, self.A, self.H, self.W, self.anchors,
+                        self.mask, self.rpn_thr, self.capK, self.df, self.status)
+        K.pswarp_sample(self.ps_t[1], self.df["guided"], self.df["counts"], self.capK, self.grid_offsets,
+                        self.spatial_scale, self.logits)
+        K.rescore_nms(self.df["guided"], self.logits, self.df["labels"], self.df["counts"], self.score_thr,
+                      self.iou_thr, self.capD, self.det, self.status)
+
+    # ------------------------------------------------------------------------------------------------
+    def run_from_points(self, clouds, anchors_mask=None):
+        """One frame batch, raw device point clouds in -> device detection buffers out (no host sync)."""
+        self.voxelize(clouds)
+        self.backbone()
+        self.bev_and_heads()
+        self.anchor_masks(anchors_mask)
+        self.post()
+        return self.det
+
+    def run_from_voxels(self, voxel_feats, coors4, anchors_mask=None):
+        self.load_voxels(voxel_feats, coors4)
+        self.backbone()
+        self.bev_and_heads()
+        self.anchor_masks(anchors_mask)
+        self.post()
+        return self.det
+
+    def results(self):
+        """The only host sync of a frame: D2H of the (small) detection buffers, like
+        ssd_rotate_head.py:529-531.  Returns per-sample (boxes[k,7], scores[k], labels[k]) numpy or None."""
+        counts = self.det["counts"].cpu().numpy()
+        st = int(self.status.item())
+        if st:
+            raise RuntimeError("sassd pipeline status flags 0x%x (capacity overflow / hash full)" % st)
+        out = []
+        for b in range(self.B):
+            k = int(counts[b])
+            if k == 0:
+                out.append((None, None, None))
+                continue
+            out.append((self.det["boxes"][b, :k].cpu().numpy(), self.det["scores"][b, :k].cpu().numpy(),
+                        self.det["labels"][b, :k].cpu().numpy().astype(np.int64)))
+        return out

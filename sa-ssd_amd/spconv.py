@@ -1,0 +1,158 @@
+"""Mirror of the spconv v1.0 surface the reference uses (mmdet/models/necks/cmn.py:1,109-112,138-173,208-212;
+mmdet/core/bbox/transforms.py:218-223): SparseConvTensor(.features/.indices/.dense()), SubMConv3d, SparseConv3d,
+SparseSequential -- same constructor arguments, same weight layout [kz,ky,kx,Cin,Cout] (checkpoint compatible),
+same `indice_key` rulebook sharing.  All arithmetic runs in libsassd (hash/bitmap rulebook + MFMA gather conv).
+
+This module-by-module facade is the drop-in/compatibility path (one host read of the output row count per strided
+conv, because the reference API exposes exact-size tensors); the fused, sync-free production path is
+sassd.pipeline.InferencePlan, which calls the same kernels with folded BatchNorm.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import kernels as K
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {}          # indice_key -> (out_indices, nbr, out_shape, hash table)
+        self._table = None
+
+    @property
+    def spatial_size(self):
+        return int(np.prod(self.spatial_shape))
+
+    def _n_ptr(self):
+        return torch.tensor([self.indices.shape[0]], dtype=torch.int32, device=self.indices.device)
+
+    def table(self):
+        if self._table is None:
+            idx = self.indices.int().contiguous()
+            cap = max(idx.shape[0], 1)
+            self._table = K.HashTable(cap, idx.device).build(idx, self._n_ptr(), self.spatial_shape, self.batch_size)
+        return self._table
+
+    def dense(self, channels_first=True):
+        """[B, C, D, H, W] like spconv (scatter_nd + permute)."""
+        d, h, w = self.spatial_shape
+        c = self.features.shape[1]
+        n = self.indices.shape[0]
+        out = K.densify(self.features.contiguous(), self.indices.int().contiguous(), self._n_ptr(), max(n, 1),
+                        (d, h, w), self.batch_size, 0)
+        out = out.view(self.batch_size, c, d, h, w)
+        return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (list, tuple)) else (v, v, v)
+
+
+class SparseConvolution(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False, subm=False,
+                 indice_key=None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _triple(kernel_size), _triple(stride), _triple(padding)
+        self.subm, self.indice_key = subm, indice_key
+        self.conv1x1 = int(np.prod(self.kernel_size)) == 1
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+        self._packed = None
+        self._packed_version = None
+
+    def reset_parameters(self):
+        n = self.in_channels * int(np.prod(self.kernel_size))
+        stdv = 1.0 / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def packed_weight(self):
+        v = self.weight._version
+        if self._packed is None or self._packed_version != v or self._packed.device != self.weight.device:
+            k = int(np.prod(self.kernel_size))
+            w = self.weight.detach().reshape(k, self.in_channels, self.out_channels).contiguous().float()
+            self._packed = K.spconv_pack_weight(w)
+            self._packed_version = v
+        return self._packed
+
+    def forward(self, inp):
+        assert isinstance(inp, SparseConvTensor)
+        feats = inp.features.contiguous().float()
+        idx = inp.indices.int().contiguous()
+        n = idx.shape[0]
+        dev = feats.device
+        cin, cout = self.in_channels, self.out_channels
+        bias = self.bias.detach() if self.bias is not None else None
+        if self.conv1x1:
+            # spconv shortcut: features @ weight.view(Cin, Cout), indices unchanged
+            y = K.spconv_fwd(feats, None, inp._n_ptr(), max(n, 1), self.packed_weight(), 1, cin, cout, None, bias)
+            out = SparseConvTensor(y[:n], inp.indices, inp.spatial_shape, inp.batch_size)
+            out.indice_dict, out._table = inp.indice_dict, inp._table
+            return out
+        if self.kernel_size != (3, 3, 3):
+            raise NotImplementedError("only k=3 and k=1 sparse convs exist on the SA-SSD path")
+        book = inp.indice_dict.get(self.indice_key) if self.indice_key is not None else None
+        if self.subm:
+            if book is None:
+                nbr = K.rulebook_subm(idx, inp._n_ptr(), max(n, 1), inp.spatial_shape, inp.batch_size, inp.table())
+                book = (idx, nbr, inp.spatial_shape, inp._table)
+                if self.indice_key is not None:
+                    inp.indice_dict[self.indice_key] = book
+            out_idx, nbr, oshape, otable = book
+            n_out = n
+        else:
+            if self.stride != (2, 2, 2) or self.padding != (1, 1, 1):
+                raise NotImplementedError("strided sparse conv is k=3,s=2,p=1 on the SA-SSD path (cmn.py:170)")
+            if book is None:
+                cap_out = max(8 * n, 1)
+                oi, on, nbr = K.rulebook_conv(idx, inp._n_ptr(), max(n, 1), inp.spatial_shape, inp.batch_size,
+                                              inp.table(), cap_out)
+                n_out = int(on.item())            # compatibility path: exact-size tensors need the count
+                book = (oi[:n_out].contiguous(), nbr[:max(n_out, 1)].contiguous(),
+                        list(K.conv_out_shape(inp.spatial_shape)), None)
+                if self.indice_key is not None:
+                    inp.indice_dict[self.indice_key] = book
+            out_idx, nbr, oshape, otable = book
+            n_out = out_idx.shape[0]
+        n_ptr = torch.tensor([n_out], dtype=torch.int32, device=dev)
+        y = K.spconv_fwd(feats, nbr, n_ptr, max(n_out, 1), self.packed_weight(), 27, cin, cout, None, bias)
+        out = SparseConvTensor(y[:n_out], out_idx, oshape, inp.batch_size)
+        out.indice_dict = inp.indice_dict
+        out._table = otable if not self.subm else inp._table
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias, True, indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias, False, indice_key)
+
+
+class SparseSequential(nn.Sequential):
+    """Sparse modules consume/produce SparseConvTensor; plain nn.Modules are applied to `.features`."""
+
+    def forward(self, inp):
+        for m in self:
+            if isinstance(m, SparseConvolution):
+                inp = m(inp)
+            elif isinstance(inp, SparseConvTensor):
+                if inp.indices.shape[0] != 0:
+                    inp.features = m(inp.features)
+            else:
+                inp = m(inp)
+        return inp

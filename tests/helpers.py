@@ -73,3 +73,98 @@ def rand_bev_boxes(rng, k, spread=12.0):
     x = rng.uniform(0, spread, k); y = rng.uniform(0, spread, k)
     w = rng.uniform(1.2, 2.2, k); l = rng.uniform(3, 5, k); a = rng.uniform(-3.3, 3.3, k)
     return np.stack([x - w / 2, y - l / 2, x + w / 2, y + l / 2, a], 1).astype(np.float32)
+
+
+def randomize_detector(model, seed=0, cls_bias=-2.0):
+    """Seeded weights + randomised BN running stats (so BN folding is exercised) + a negative cls bias so that
+    ~10^2 anchors pass the 0.1 guided-anchor threshold."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2:
+                fan_in = p[0].numel() if p.dim() == 4 else int(np.prod(p.shape[:-1]))
+                if p.dim() == 5:
+                    fan_in = int(np.prod(p.shape[:4])) // 3          # sparse kernels are mostly empty
+                p.copy_(torch.randn(p.shape, generator=g) * (2.0 / max(fan_in, 1)) ** 0.5)
+            elif name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            else:
+                p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.75)
+        for name, b in model.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif name.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+        model.rpn_head.conv_cls.bias.add_(cls_bias)
+        model.rpn_head.conv_box.weight.mul_(0.05)          # keep decoded boxes close to their anchors
+        model.rpn_head.conv_box.bias.mul_(0.5)
+    return model
+
+
+def oracle_params(sd):
+    """detector state_dict -> the parameter dicts oracle.nets expects."""
+    from sassd.pipeline import VXNET
+    bn = lambda p: dict(weight=sd[p + ".weight"], bias=sd[p + ".bias"], running_mean=sd[p + ".running_mean"],   # noqa: E731
+                        running_var=sd[p + ".running_var"])
+    vx = {}
+    for (wname, bnname, kind, cin, cout, key), (oname, *_r) in zip(VXNET, onets.VXNET_LAYERS):
+        k = 1 if kind == "1x1" else 27
+        vx[oname] = dict(weight=sd["neck.backbone.%s.weight" % wname].reshape(k, cin, cout),
+                         bn=bn("neck.backbone.%s" % bnname))
+    bev = {"conv%d" % i: dict(weight=sd["neck.fcn.conv%d.weight" % i], bn=bn("neck.fcn.bn%d" % i)) for i in range(8)}
+    head = {n: dict(weight=sd["rpn_head.%s.weight" % n], bias=sd["rpn_head.%s.bias" % n])
+            for n in ("conv_box", "conv_cls", "conv_dir_cls")}
+    ps = {"conv0": dict(weight=sd["extra_head.convs.0.weight"], bn=bn("extra_head.convs.1")),
+          "conv1": dict(weight=sd["extra_head.convs.3.weight"])}
+    return vx, bev, head, ps
+
+
+def oracle_forward(sd, clouds, anchors, anchors_bv, cfg, num_class=1, keep=None):
+    """Whole path on the CPU oracle. clouds: list of numpy [N,4]. Returns dict of intermediate + final results."""
+    vx, bev, head, ps = oracle_params(sd)
+    feats, coors, coors3 = [], [], []
+    for b, pts in enumerate(clouds):
+        v, c, n = clib.points_to_voxel(pts, cfg["voxel_size"], cfg["pc_range"], cfg["max_points"], True,
+                                       cfg["max_voxels"])
+        feats.append(clib.voxel_mean(v, n))
+        coors3.append(c)
+        coors.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+    feats, coors = np.concatenate(feats), np.concatenate(coors)
+    B = len(clouds)
+    x3, idx3, shape3, middle, books, acts = onets.vxnet_forward(feats, coors, cfg["sparse_shape"], B, vx, True)
+    dense = onets.densify(x3, idx3, shape3, B)
+    x, conv6 = onets.bevnet_forward(dense, bev)
+    box, cls, dirp = onets.ssd_head_forward(x, head, num_class)
+    masks = np.stack([onets.anchors_mask(c, anchors_bv, cfg["voxel_size"], cfg["pc_range"], cfg["grid_xyz"], 1)
+                      for c in coors3])
+    an = torch.from_numpy(anchors).view(1, -1, 7).expand(B, -1, -1)
+    guided = onets.guided_anchors(box, cls, dirp, an, torch.from_numpy(masks), num_class, 0.1)
+    logits, psfeat = onets.pswarp_forward(conv6, ps, [g[0] for g in guided])
+    dets = [onets.rescore(g[0], lg, g[1], cfg.get("score_thr", 0.3), 0.1) for g, lg in zip(guided, logits)]
+    return dict(feats=feats, coors=coors, x3=x3, idx3=idx3, acts=acts, dense=dense, x=x, conv6=conv6, box=box, cls=cls,
+                dirp=dirp, masks=masks, guided=guided, logits=logits, psfeat=psfeat, dets=dets, books=books)
+
+
+from oracle import clib  # noqa: E402
+
+
+def calibrate_cls_head(model, cloud, anchors_bv, cfg, target_mean=-3.9, target_std=0.45):
+    """Rescale rpn_head.conv_cls (weights and bias) with the CPU oracle so that masked-anchor logits have the given
+    mean/std on `cloud`: ~10^2 anchors then pass sigmoid > 0.1 instead of tens of thousands."""
+    sd = model.state_dict()
+    vx, bev, head, ps = oracle_params(sd)
+    v, c, n = clib.points_to_voxel(cloud, cfg["voxel_size"], cfg["pc_range"], cfg["max_points"], True, cfg["max_voxels"])
+    coors = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+    x3, idx3, shape3, *_ = onets.vxnet_forward(clib.voxel_mean(v, n), coors, cfg["sparse_shape"], 1, vx)
+    x, _ = onets.bevnet_forward(onets.densify(x3, idx3, shape3, 1), bev)
+    ncls = model.rpn_head._num_class
+    _, cls, _ = onets.ssd_head_forward(x, head, ncls)
+    m = onets.anchors_mask(c, anchors_bv, cfg["voxel_size"], cfg["pc_range"], cfg["grid_xyz"], 1)
+    lg = cls.reshape(-1, ncls)[torch.from_numpy(m)]
+    mean, std = lg.mean().item(), lg.std().item()
+    s = target_std / max(std, 1e-6)
+    with torch.no_grad():
+        b_old = model.rpn_head.conv_cls.bias.clone()
+        model.rpn_head.conv_cls.weight.mul_(s)
+        model.rpn_head.conv_cls.bias.copy_((b_old - mean) * s + target_mean)
+    return model

@@ -48,7 +48,8 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
                                  float *__restrict__ wp)
 {
     const int taps = ks * ks;
-    const size_t total = (size_t)Cin * taps * CoutPad;
+    const int CinPad = (Cin + kKC - 1) / kKC * kKC;
+    const size_t total = (size_t)CinPad * taps * CoutPad;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int co = i % CoutPad;
@@ -56,7 +57,7 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
     const int tap = (i / ((size_t)CoutPad * kKC)) % taps;
     const int chunk = i / ((size_t)CoutPad * kKC * taps);
     const int ci = chunk * kKC + kc;
-    wp[i] = (co < Cout) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+    wp[i] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
 }
 
 template <int CT, int TAPS>
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     const float *xb = P.x + (size_t)b * P.Cin * P.HW;
-    const int nchunk = P.Cin / kKC;
+    const int nchunk = (P.Cin + kKC - 1) / kKC;
     const int aoff = (lane >> 5) * BMC + ct * 32 + (lane & 31);
 
     for (int ch = 0; ch < nchunk; ++ch) {
@@ -121,8 +122,8 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
             for (int r = wave; r < nrows_tot; r += 4) {
                 const int kc = r / nprows, pr = r - kc * nprows;
                 const int yy = y_first - 1 + pr;
-                const bool rowok = (yy >= 0) && (yy < P.H);
-                const float *srow = xb + ((size_t)(ch * kKC + kc) * P.H + (rowok ? yy : 0)) * P.W;
+                const bool rowok = (yy >= 0) && (yy < P.H) && (ch * kKC + kc < P.Cin);
+                const float *srow = xb + ((size_t)(rowok ? ch * kKC + kc : 0) * P.H + (rowok ? yy : 0)) * P.W;
                 float *drow = P_s + kc * chs + pr * PW;
                 for (int px = lane; px < PW; px += 64) {
                     const int xx = px - 1;
@@ -204,14 +205,14 @@ inline int cout_pad(int Cout) { return (Cout > 64) ? cdiv(Cout, 128) * 128 : cdi
 
 extern "C" size_t sassd_conv2d_packed_floats(int Cin, int Cout, int ksize)
 {
-    return (size_t)Cin * ksize * ksize * cout_pad(Cout);
+    return (size_t)cdiv(Cin, kKC) * kKC * ksize * ksize * cout_pad(Cout);
 }
 
 extern "C" int sassd_conv2d_pack_weight(const float *w, int Cout, int Cin, int ksize, float *packed, void *stream_)
 {
-    if (!w || !packed || (ksize != 1 && ksize != 3) || Cin % kKC) return SASSD_EINVAL;
+    if (!w || !packed || (ksize != 1 && ksize != 3) || Cin < 1) return SASSD_EINVAL;
     const int cp = cout_pad(Cout);
-    const size_t total = (size_t)Cin * ksize * ksize * cp;
+    const size_t total = (size_t)cdiv(Cin, kKC) * kKC * ksize * ksize * cp;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, w,
                        Cout, Cin, ksize, cp, packed);
     return sassd_launch_status();
@@ -221,7 +222,7 @@ extern "C" int sassd_conv2d_fwd(const float *x, const float *w_packed, const flo
                                 int relu, float *y, int batch, int Cin, int Cout, int H, int W, int ksize,
                                 void *stream_)
 {
-    if (!x || !w_packed || !y || batch < 1 || Cin % kKC || (ksize != 1 && ksize != 3)) return SASSD_EINVAL;
+    if (!x || !w_packed || !y || batch < 1 || Cin < 1 || (ksize != 1 && ksize != 3)) return SASSD_EINVAL;
     if (H < 1 || W < 2) return SASSD_EINVAL;
     ConvParams P;
     P.x = x; P.wp = w_packed; P.scale = scale; P.shift = shift; P.y = y;

@@ -168,7 +168,7 @@ def test_densify(dev):
 
 @pytest.mark.parametrize("cin,cout,ks,h,w,b", [(16, 256, 3, 20, 176, 1), (320, 256, 3, 11, 176, 2), (256, 256, 1, 9, 176, 1),
                                                (256, 28, 3, 13, 176, 1), (256, 20, 1, 7, 50, 2), (8, 128, 3, 200, 176, 1),
-                                               (24, 72, 1, 5, 31, 1)])
+                                               (24, 72, 1, 5, 31, 1), (28, 28, 1, 9, 176, 1), (5, 40, 3, 6, 17, 1)])
 def test_conv2d(dev, cin, cout, ks, h, w, b):
     g = torch.Generator().manual_seed(cin + cout + ks)
     x = torch.randn(b, cin, h, w, generator=g)

@@ -135,3 +135,4 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.sassd_version()
     assert lib.sassd_voxelize_workspace_bytes(21500, 5) > 0
     assert lib.sassd_conv2d_packed_floats(256, 28, 3) == 256 * 9 * 32
+    assert lib.sassd_conv2d_packed_floats(28, 28, 1) == 32 * 32

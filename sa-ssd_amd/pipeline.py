@@ -147,11 +147,22 @@ class InferencePlan:
         self.det = dict(boxes=z(B, self.capD, 7), scores=z(B, self.capD), labels=z(B, self.capD, dt=i32),
                         counts=z(B, dt=i32))
         self.middle = {}
+        self.prof = None           # set to {} to collect (name, start_event, end_event) tuples per frame
+
+    def _ev(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()                 # current stream == the stream every sassd kernel is launched on
+        return e
+
+    def _seg(self, name, e0):
+        if self.prof is not None:
+            self.prof.setdefault(name, []).append((e0, self._ev()))
 
     # ------------------------------------------------------------------------------------------------
     def voxelize(self, clouds):
         """clouds: list of B device tensors [Ni, ndim] f32.  Fills idx[0] (b,z,y,x), mean, row_off."""
         assert len(clouds) == self.B
+        e0 = self._ev() if self.prof is not None else None
         self.row_off.zero_()
         for b, pts in enumerate(clouds):
             K.voxelize(pts, self.voxel_size, self.pc_range, self.T, self.max_voxels, batch_idx=b, coors_cols=4,
@@ -159,6 +170,7 @@ class InferencePlan:
                        out=dict(coors=self.idx[0], mean=self.mean, voxel_num=self.vnum[b:b + 1],
                                 num_points=self._numpts()),
                        row_offset=self.row_off[b:b + 2], status=self.status, cap=self.caps[0])
+        self._seg("voxelize", e0)
 
     def _numpts(self):
         if not hasattr(self, "_np"):
@@ -177,6 +189,7 @@ class InferencePlan:
 
     def backbone(self, keep_middle=False):
         B = self.B
+        e0 = self._ev() if self.prof is not None else None
         x = self.mean
         lvl = 0
         self.tables[0].build(self.idx[0], self.n[0], self.shapes[0], B, self.status)
@@ -203,13 +216,18 @@ class InferencePlan:
             x = y
             cur ^= 1
         self.sp_out = x
+        self._seg("sparse", e0)
+        e1 = self._ev() if self.prof is not None else None
         K.densify(x, self.idx[3], self.n[3], self.caps[3], self.shapes[3], B, 1, self.dense)
+        self._seg("densify", e1)
 
     def bev_and_heads(self):
         x = self.dense
         for i, (wp, cout, ks, scale, shift) in enumerate(self.bev):
             y = self.act[i % 2] if i < 7 else self.act[2]
+            e0 = self._ev() if self.prof is not None else None
             K.conv2d_fwd(x, wp, cout, ks, scale, shift, True, y)
+            self._seg("bev_conv%d" % i, e0)
             x = y
             if i == 6:
                 self.conv6 = y
@@ -228,6 +246,7 @@ class InferencePlan:
                           self.voxel_size, self.pc_range, self.area_thr, self.mask[b])
 
     def post(self):
+        e0 = self._ev() if self.prof is not None else None
         HW = self.H * self.W
         ho = self.head_out
         base = ho.view(-1)
@@ -240,6 +259,34 @@ class InferencePlan:
                         self.spatial_scale, self.logits)
         K.rescore_nms(self.df["guided"], self.logits, self.df["labels"], self.df["counts"], self.score_thr,
                       self.iou_thr, self.capD, self.det, self.status)
+        self._seg("post", e0)
+
+    def sparse_work(self):
+        """Algorithmic work of the sparse path for the CURRENT frame (SURVEY.md 8d formulas): per layer
+        B_gs = 4P(Cin+Cout) + 8P + 4K*Cin*Cout + 4*Nout*Cout, B_min, flops = 2*P*Cin*Cout; rulebook bytes."""
+        n = [int(t.item()) for t in self.n]
+        pairs = {}
+        lvl_of = dict(subm0=0, down0=1, subm1=1, down1=2, subm2=2, down2=3, subm3=3)
+        for key, t in self.nbr.items():
+            pairs[key] = int((t[:n[lvl_of[key]]] >= 0).sum().item())
+        bgs = bmin = flops = rb = 0
+        lvl = 0
+        seen = set()
+        for kind, cin, cout, key, *_ in self.sp:
+            if kind == "down":
+                nin, lvl = n[lvl], lvl + 1
+            else:
+                nin = n[lvl]
+            nout = n[lvl]
+            p = pairs[key] if key else nout
+            k = 27 if key else 1
+            bgs += 4 * p * (cin + cout) + 8 * p + 4 * k * cin * cout + 4 * nout * cout
+            bmin += 4 * nin * cin + 4 * nout * cout + 4 * k * cin * cout + 8 * p
+            flops += 2 * p * cin * cout
+            if key and key not in seen:
+                seen.add(key)
+                rb += (16 * nin + 8 * p) if kind == "subm" else (16 * nin + 16 * nout + 8 * p)
+        return dict(n=n, pairs=pairs, bytes_gs=bgs, bytes_min=bmin, flops=flops, rulebook_bytes=rb)
 
     # ------------------------------------------------------------------------------------------------
     def run_from_points(self, clouds, anchors_mask=None):

@@ -8,28 +8,39 @@
 //   MFMA "A" = weights (M = cout), "B" = pixels (N = 32 consecutive linear pixels -> coalesced 128-B stores),
 //   v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 cycles, peak 157.3 TF.
 // Tiling (wave = 64 lanes, 4 waves / workgroup, 1 workgroup / CU):
-//   workgroup tile = 128 couts x 288 linear pixels  (4 x 9 MFMA tiles; 35200 px * 256 couts -> 246 workgroups,
-//   i.e. ONE round on 256 CUs at 96 % tile utilisation);  wave w owns cout tile w and all 9 pixel segments
-//   (9 x 16 accumulator VGPRs).  Small-Cout layers (28 / 20 channels) use 32 couts x 256 px, 2 segments / wave.
-//   K loop: 8 input channels per step.  The input PATCH (8 ch x <=5 rows x (W+2), zero halo) is staged ONCE in LDS
-//   and serves all 9 taps through shifted LDS reads -- 9x less L2->LDS traffic than per-tap im2col staging and no
-//   border masks in the inner loop.  LDS images are k-major ([k][cout] / [k][pixel]) so both MFMA operand reads
-//   are 32 consecutive dwords per half-wave: conflict free, no swizzle.
+//   wide layers (Cout multiple of 128): workgroup tile = 128 couts x 288 linear pixels (4 x 9 MFMA tiles;
+//     35200 px * 256 couts -> 246 workgroups = ONE round on 256 CUs at 96 % tile utilisation); wave w owns cout
+//     tile w and all 9 pixel segments (9 x 16 accumulator registers).
+//   narrow layers (Cout <= 64, e.g. 28 / 20): workgroup tile = 32 couts x 160 px; the 4 waves split the K
+//     (input channel) dimension and reduce through LDS at the end.
+//   K loop: KC input channels per step (8 for 3x3, 16 for 1x1).  The input PATCH (KC ch x <=5 rows x (W+8), zero
+//   halo) is staged ONCE in LDS and serves all 9 taps through shifted LDS reads -- 9x less L2->LDS traffic than
+//   per-tap im2col staging, no border masks in the inner loop.  LDS images are k-major ([k][cout] / [k][pixel]) so
+//   both MFMA operand reads are 32 consecutive dwords per half-wave: conflict free without a swizzle.
+//   Pipelining: LDS is double buffered; the global loads of chunk i+1 (16-B per lane, precomputed offsets) are
+//   issued BEFORE the 324 MFMAs of chunk i and written to the other LDS buffer after them (issue-early /
+//   write-late), one barrier per chunk.
 // Roofline: MFMA (fp32) bound; FLOPs = 2*Cout*Cin*k*k*H*W.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kKC = 8;          // input channels per K step
-
-template <int CT>
+template <int CT, int TAPS, int VEC>
 struct ConvCfg {
-    static constexpr int NSEG = (CT == 4) ? 9 : 8;    // 32-pixel segments per workgroup
-    static constexpr int SPW = (CT == 4) ? 9 : 2;     // segments per wave
-    static constexpr int BMC = CT * 32;               // couts per workgroup
+    static constexpr bool KSPLIT = (CT == 1);
+    static constexpr int NSEG = (CT == 4) ? 9 : 5;     // 32-pixel segments per workgroup (all owned by every wave)
+    static constexpr int KC = (TAPS == 9) ? 8 : 16;    // input channels per K step
+    static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    static constexpr int BMC = CT * 32;                // couts per workgroup
     static constexpr int PIX = NSEG * 32;
+    static constexpr int WV4 = TAPS * KC * BMC / 4;    // weight float4 per chunk
+    static constexpr int NLW = (WV4 + 255) / 256;      // weight float4 per thread
+    static constexpr int MAXLP = (VEC == 4) ? 10 : 40; // patch loads per thread (upper bound)
+    static constexpr int WS = TAPS * KC * BMC;         // floats
 };
 
 struct ConvParams {
@@ -39,35 +50,36 @@ struct ConvParams {
     int ntp;        // pixel tiles per image
     int ncg;        // cout groups
     int NPR;        // patch rows allocated in LDS
-    int PW;         // patch width = W + 2
+    int PW;         // patch row stride (floats): 4 left pad (col 3 = halo) + W + right halo/pad, multiple of 4
     int relu;
 };
 
-// w [Cout][Cin][k][k] -> wp [Cin/8][TAPS][8][CoutPad]
-__global__ void conv_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int ks, int CoutPad,
+// w [Cout][Cin][k][k] -> wp [Cin padded to KC][TAPS][CoutPad] grouped as [chunk of KC][tap][kc][CoutPad]
+__global__ void conv_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int ks, int CoutPad, int KC,
                                  float *__restrict__ wp)
 {
     const int taps = ks * ks;
-    const int CinPad = (Cin + kKC - 1) / kKC * kKC;
+    const int CinPad = (Cin + KC - 1) / KC * KC;
     const size_t total = (size_t)CinPad * taps * CoutPad;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int co = i % CoutPad;
-    const int kc = (i / CoutPad) % kKC;
-    const int tap = (i / ((size_t)CoutPad * kKC)) % taps;
-    const int chunk = i / ((size_t)CoutPad * kKC * taps);
-    const int ci = chunk * kKC + kc;
+    const int kc = (i / CoutPad) % KC;
+    const int tap = (i / ((size_t)CoutPad * KC)) % taps;
+    const int chunk = i / ((size_t)CoutPad * KC * taps);
+    const int ci = chunk * KC + kc;
     wp[i] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
 }
 
-template <int CT, int TAPS>
+template <int CT, int TAPS, int VEC>
 __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
 {
-    using C = ConvCfg<CT>;
-    constexpr int SPW = C::SPW, BMC = C::BMC, PIX = C::PIX;
+    using C = ConvCfg<CT, TAPS, VEC>;
+    constexpr int NSEG = C::NSEG, BMC = C::BMC, PIX = C::PIX, KC = C::KC, HALO = C::HALO, NLW = C::NLW,
+                  MAXLP = C::MAXLP, WS = C::WS;
+    constexpr bool KSPLIT = C::KSPLIT;
+    typedef typename std::conditional<VEC == 4, float4, float>::type pvec_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *W_s = smem;                               // [TAPS*8][BMC]
-    float *P_s = smem + TAPS * kKC * BMC;            // [8][NPR][PW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int g = blockIdx.x;
@@ -78,143 +90,230 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
     const int p0 = pt * PIX;
     const int plast = min(p0 + PIX, P.HW) - 1;
     const int y_first = p0 / P.W;
-    const int nprows = plast / P.W - y_first + 3;     // rows y_first-1 .. y_last+1
+    const int nprows = plast / P.W - y_first + 1 + 2 * HALO;
     const int PW = P.PW;
-    const int chs = P.NPR * PW;                       // channel stride inside P_s
+    const int chs = P.NPR * PW;                       // channel stride inside the patch image
+    const int PS = KC * chs;
+    const int bufs = WS + PS;                         // floats per LDS buffer
 
-    const int ct = (CT == 4) ? wave : 0;
-    const int seg0 = (CT == 4) ? 0 : wave * SPW;
+    // ---- zero both staging buffers once: halos / out-of-image rows stay zero forever ---------------
+    for (int i = tid; i < 2 * bufs; i += 256) smem[i] = 0.f;
 
-    int laddr[SPW];
+    // ---- per-thread load descriptors (constant across K chunks) ------------------------------------
+    const int WV = P.W / VEC;
+    int goff[MAXLP], loff[MAXLP];
 #pragma unroll
-    for (int j = 0; j < SPW; ++j) {
-        int p = p0 + (seg0 + j) * 32 + (lane & 31);
-        p = min(p, P.HW - 1);
-        const int yy = p / P.W, xx = p - yy * P.W;
-        laddr[j] = (yy - y_first + 1) * PW + xx + 1 + (lane >> 5) * chs;   // lanes 32..63 read channel kc+1
+    for (int i = 0; i < MAXLP; ++i) {
+        const int f = tid + 256 * i;
+        goff[i] = -1;
+        loff[i] = 0;
+        if (f < KC * nprows * WV) {
+            const int r = f / WV, cv = f - r * WV;
+            const int kc = r / nprows, pr = r - kc * nprows;
+            const int yy = y_first - HALO + pr;
+            if (yy >= 0 && yy < P.H) {
+                goff[i] = (kc * P.H + yy) * P.W + cv * VEC;
+                loff[i] = kc * chs + pr * PW + 4 + cv * VEC;
+            }
+        }
+    }
+    int woff_g[NLW], woff_l[NLW];
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) {
+        const int f = tid + 256 * i;
+        constexpr int V = BMC / 4;
+        const int row = f / V, c4 = f - row * V;
+        woff_g[i] = (f < C::WV4) ? row * P.CoutPad + cg * BMC + c4 * 4 : -1;
+        woff_l[i] = row * BMC + c4 * 4;
     }
 
-    f32x16 acc[SPW];
+    int laddr[NSEG];
 #pragma unroll
-    for (int j = 0; j < SPW; ++j)
+    for (int j = 0; j < NSEG; ++j) {
+        int p = p0 + j * 32 + (lane & 31);
+        p = min(p, P.HW - 1);
+        const int yy = p / P.W, xx = p - yy * P.W;
+        laddr[j] = (yy - y_first + HALO) * PW + 4 + xx + (lane >> 5) * chs;   // lanes 32..63 read channel kc+1
+    }
+
+    f32x16 acc[NSEG];
+#pragma unroll
+    for (int j = 0; j < NSEG; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     const float *xb = P.x + (size_t)b * P.Cin * P.HW;
-    const int nchunk = (P.Cin + kKC - 1) / kKC;
+    const int nchunk = (P.Cin + KC - 1) / KC;
+    const int ct = KSPLIT ? 0 : wave;
     const int aoff = (lane >> 5) * BMC + ct * 32 + (lane & 31);
+    const bool ragged = (P.Cin % KC) != 0;
+
+    float4 wreg[NLW];
+    pvec_t preg[MAXLP];
+
+    auto issue = [&](int ch) {
+        const float *wsrc = P.wp + (size_t)ch * TAPS * KC * P.CoutPad;
+#pragma unroll
+        for (int i = 0; i < NLW; ++i)
+            if (woff_g[i] >= 0) wreg[i] = *(const float4 *)(wsrc + woff_g[i]);
+        const float *xc = xb + (size_t)ch * KC * P.HW;
+        if (!ragged || ch + 1 < nchunk) {
+#pragma unroll
+            for (int i = 0; i < MAXLP; ++i)
+                if (goff[i] >= 0) preg[i] = *(const pvec_t *)(xc + goff[i]);
+        } else {
+            // last, partial chunk: channels >= Cin are clamped to Cin-1 (their packed weights are zero)
+#pragma unroll
+            for (int i = 0; i < MAXLP; ++i)
+                if (goff[i] >= 0) {
+                    const int kc = goff[i] / P.HW;
+                    const int over = max(ch * KC + kc - (P.Cin - 1), 0);
+                    preg[i] = *(const pvec_t *)(xc + goff[i] - (size_t)over * P.HW);
+                }
+        }
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int i = 0; i < NLW; ++i)
+            if (woff_g[i] >= 0) *(float4 *)(buf + woff_l[i]) = wreg[i];
+        float *pbuf = buf + WS;
+#pragma unroll
+        for (int i = 0; i < MAXLP; ++i)
+            if (goff[i] >= 0) *(pvec_t *)(pbuf + loff[i]) = preg[i];
+    };
+
+    __syncthreads();                 // zero fill done
+    issue(0);
+    commit(smem);
+    __syncthreads();
 
     for (int ch = 0; ch < nchunk; ++ch) {
-        __syncthreads();
-        // ---- stage weights: TAPS*8 rows x BMC couts ------------------------------------------------
-        {
-            const float *src = P.wp + (size_t)ch * TAPS * kKC * P.CoutPad + cg * BMC;
-            constexpr int V = BMC / 4;
-            for (int i = tid; i < TAPS * kKC * V; i += 256) {
-                const int row = i / V, c4 = i - row * V;
-                const float4 v = *(const float4 *)(src + (size_t)row * P.CoutPad + c4 * 4);
-                *(float4 *)(W_s + row * BMC + c4 * 4) = v;
-            }
-        }
-        // ---- stage the input patch with zero halo: rows handled round-robin by the 4 waves ---------
-        {
-            const int nrows_tot = kKC * nprows;
-            for (int r = wave; r < nrows_tot; r += 4) {
-                const int kc = r / nprows, pr = r - kc * nprows;
-                const int yy = y_first - 1 + pr;
-                const bool rowok = (yy >= 0) && (yy < P.H) && (ch * kKC + kc < P.Cin);
-                const float *srow = xb + ((size_t)(rowok ? ch * kKC + kc : 0) * P.H + (rowok ? yy : 0)) * P.W;
-                float *drow = P_s + kc * chs + pr * PW;
-                for (int px = lane; px < PW; px += 64) {
-                    const int xx = px - 1;
-                    float v = 0.f;
-                    if (rowok && xx >= 0 && xx < P.W) v = srow[xx];
-                    drow[px] = v;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- MFMA: 9 taps x 4 k-steps x SPW segments ----------------------------------------------
+        const float *W_s = smem + (ch & 1) * bufs;
+        const float *P_s = W_s + WS;
+        const bool more = ch + 1 < nchunk;
+        if (more) issue(ch + 1);
+        // ---- MFMA: TAPS x (KC/2) k-steps x NSEG segments -------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int toff = (TAPS == 9) ? ((tap / 3 - 1) * PW + (tap % 3 - 1)) : 0;
+            if constexpr (!KSPLIT) {
 #pragma unroll
-            for (int s = 0; s < kKC / 2; ++s) {
-                const float a = W_s[(tap * kKC + 2 * s) * BMC + aoff];
-                const float *pb = P_s + 2 * s * chs + toff;
+                for (int s = 0; s < KC / 2; ++s) {
+                    const float a = W_s[(tap * KC + 2 * s) * BMC + aoff];
+                    const float *pb = P_s + 2 * s * chs + toff;
 #pragma unroll
-                for (int j = 0; j < SPW; ++j) {
-                    const float bv = pb[laddr[j]];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+                    for (int j = 0; j < NSEG; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[laddr[j]], acc[j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < KC / 8; ++t) {
+                    const int s = wave + 4 * t;                  // this wave's k-steps
+                    const float a = W_s[(tap * KC + 2 * s) * BMC + aoff];
+                    const float *pb = P_s + 2 * s * chs + toff;
+#pragma unroll
+                    for (int j = 0; j < NSEG; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[laddr[j]], acc[j], 0, 0, 0);
                 }
             }
         }
+        if (more) commit(smem + ((ch + 1) & 1) * bufs);
+        __syncthreads();
     }
 
     // ---- epilogue: D[row = cout][col = pixel] ----------------------------------------------------------
-    float sc[16], sh[16];
-    int co[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        co[r] = cg * BMC + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const bool ok = co[r] < P.Cout;
-        sc[r] = (ok && P.scale) ? P.scale[co[r]] : 1.f;
-        sh[r] = (ok && P.shift) ? P.shift[co[r]] : 0.f;
-    }
     float *yb = P.y + (size_t)b * P.Cout * P.HW;
+    if constexpr (!KSPLIT) {
+        float sc[16], sh[16];
+        int co[16];
 #pragma unroll
-    for (int j = 0; j < SPW; ++j) {
-        const int p = p0 + (seg0 + j) * 32 + (lane & 31);
-        if (p < P.HW) {
+        for (int r = 0; r < 16; ++r) {
+            co[r] = cg * BMC + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const bool ok = co[r] < P.Cout;
+            sc[r] = (ok && P.scale) ? P.scale[co[r]] : 1.f;
+            sh[r] = (ok && P.shift) ? P.shift[co[r]] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j) {
+            const int p = p0 + j * 32 + (lane & 31);
+            if (p < P.HW) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (co[r] < P.Cout) {
+                        float v = acc[j][r] * sc[r] + sh[r];
+                        if (P.relu) v = fmaxf(v, 0.f);
+                        yb[(size_t)co[r] * P.HW + p] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        // cross-wave K reduction: red[wave][seg][reg][lane] (the loop's final barrier already passed)
+        float *red = smem;
+#pragma unroll
+        for (int j = 0; j < NSEG; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * NSEG + j) * 16 + r) * 64 + lane] = acc[j][r];
+        __syncthreads();
+        for (int j = wave; j < NSEG; j += 4) {
+            const int p = p0 + j * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (co[r] < P.Cout) {
-                    float v = acc[j][r] * sc[r] + sh[r];
+                const int co = cg * BMC + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = red[((0 * NSEG + j) * 16 + r) * 64 + lane] + red[((1 * NSEG + j) * 16 + r) * 64 + lane] +
+                          red[((2 * NSEG + j) * 16 + r) * 64 + lane] + red[((3 * NSEG + j) * 16 + r) * 64 + lane];
+                if (p < P.HW && co < P.Cout) {
+                    v = v * (P.scale ? P.scale[co] : 1.f) + (P.shift ? P.shift[co] : 0.f);
                     if (P.relu) v = fmaxf(v, 0.f);
-                    yb[(size_t)co[r] * P.HW + p] = v;
+                    yb[(size_t)co * P.HW + p] = v;
                 }
             }
         }
     }
 }
 
-template <int CT, int TAPS>
+template <int CT, int TAPS, int VEC>
 int launch_conv(ConvParams P, hipStream_t stream)
 {
-    using C = ConvCfg<CT>;
+    using C = ConvCfg<CT, TAPS, VEC>;
     P.ntp = cdiv(P.HW, C::PIX);
     P.ncg = P.CoutPad / C::BMC;
-    P.PW = P.W + 2;
-    P.NPR = (C::PIX - 1 + P.W - 1) / P.W + 1 + 2;
-    const size_t lds = ((size_t)TAPS * kKC * C::BMC + (size_t)kKC * P.NPR * P.PW) * sizeof(float);
+    P.PW = (P.W + 8 + 3) / 4 * 4;
+    P.NPR = (C::PIX - 1 + P.W - 1) / P.W + 1 + 2 * C::HALO;
+    const size_t stage = 2 * ((size_t)C::WS + (size_t)C::KC * P.NPR * P.PW) * sizeof(float);
+    const size_t red = C::KSPLIT ? (size_t)4 * C::NSEG * 16 * 64 * sizeof(float) : 0;
+    const size_t lds = stage > red ? stage : red;
     if (lds > 160 * 1024) return SASSD_EINVAL;
+    if ((size_t)C::KC * P.NPR * (P.W / VEC) > (size_t)256 * C::MAXLP) return SASSD_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)conv2d_kernel<CT, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv2d_kernel<CT, TAPS, VEC>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int grid = P.B * P.ntp * P.ncg;
-    hipLaunchKernelGGL((conv2d_kernel<CT, TAPS>), dim3(grid), dim3(256), lds, stream, P);
+    hipLaunchKernelGGL((conv2d_kernel<CT, TAPS, VEC>), dim3(grid), dim3(256), lds, stream, P);
     return sassd_launch_status();
 }
 
 inline int cout_pad(int Cout) { return (Cout > 64) ? cdiv(Cout, 128) * 128 : cdiv(Cout, 32) * 32; }
+inline int kc_of(int ksize) { return ksize == 3 ? 8 : 16; }
 
 }  // namespace
 
 extern "C" size_t sassd_conv2d_packed_floats(int Cin, int Cout, int ksize)
 {
-    return (size_t)cdiv(Cin, kKC) * kKC * ksize * ksize * cout_pad(Cout);
+    const int KC = kc_of(ksize);
+    return (size_t)cdiv(Cin, KC) * KC * ksize * ksize * cout_pad(Cout);
 }
 
 extern "C" int sassd_conv2d_pack_weight(const float *w, int Cout, int Cin, int ksize, float *packed, void *stream_)
 {
     if (!w || !packed || (ksize != 1 && ksize != 3) || Cin < 1) return SASSD_EINVAL;
     const int cp = cout_pad(Cout);
-    const size_t total = (size_t)cdiv(Cin, kKC) * kKC * ksize * ksize * cp;
+    const size_t total = sassd_conv2d_packed_floats(Cin, Cout, ksize);
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, w,
-                       Cout, Cin, ksize, cp, packed);
+                       Cout, Cin, ksize, cp, kc_of(ksize), packed);
     return sassd_launch_status();
 }
 
@@ -229,6 +328,15 @@ extern "C" int sassd_conv2d_fwd(const float *x, const float *w_packed, const flo
     P.B = batch; P.Cin = Cin; P.Cout = Cout; P.CoutPad = cout_pad(Cout); P.H = H; P.W = W; P.HW = H * W;
     P.relu = relu;
     hipStream_t stream = (hipStream_t)stream_;
-    if (P.CoutPad % 128 == 0) return ksize == 3 ? launch_conv<4, 9>(P, stream) : launch_conv<4, 1>(P, stream);
-    return ksize == 3 ? launch_conv<1, 9>(P, stream) : launch_conv<1, 1>(P, stream);
+    const bool wide = P.CoutPad % 128 == 0;
+    // 16-byte row loads need W % 4 == 0 and a 16-byte aligned base
+    const bool vec = (W % 4 == 0) && (((uintptr_t)x & 15) == 0);
+#define SASSD_CONV_GO(CT, TAPS) \
+    return vec ? launch_conv<CT, TAPS, 4>(P, stream) : launch_conv<CT, TAPS, 1>(P, stream)
+    if (wide) {
+        if (ksize == 3) { SASSD_CONV_GO(4, 9); } else { SASSD_CONV_GO(4, 1); }
+    } else {
+        if (ksize == 3) { SASSD_CONV_GO(1, 9); } else { SASSD_CONV_GO(1, 1); }
+    }
+#undef SASSD_CONV_GO
 }

@@ -193,7 +193,12 @@ __device__ __forceinline__ unsigned long long nms_word(const float *__restrict__
     if (col < n && col > row) {
         const iou3d::Box a = iou3d::load_box(boxes + (size_t)row * 5);
         const iou3d::Box b = iou3d::load_box(boxes + (size_t)col * 5);
-        hit = iou3d::iou_bev(a, b) > thr;
+        // boxes whose circumscribed circles are disjoint have overlap exactly 0 (no intersection points, no
+        // contained corners) -> iou 0 > thr is false for any thr >= 0: skip the polygon clipping
+        const float dx = (a.x1 + a.x2) * 0.5f - (b.x1 + b.x2) * 0.5f, dy = (a.y1 + a.y2) * 0.5f - (b.y1 + b.y2) * 0.5f;
+        const float wa = a.x2 - a.x1, la = a.y2 - a.y1, wb = b.x2 - b.x1, lb = b.y2 - b.y1;
+        const float rr = 0.5f * (sqrtf(wa * wa + la * la) + sqrtf(wb * wb + lb * lb)) + 1e-3f;
+        if (thr < 0.f || dx * dx + dy * dy <= rr * rr) hit = iou3d::iou_bev(a, b) > thr;
     }
     return __ballot(hit);
 }
@@ -270,22 +275,18 @@ struct RnParams {
 
 constexpr int kRnLdsScores = 4096;
 
-__global__ void __launch_bounds__(1024) rescore_nms_kernel(RnParams P)
+// stage A (one workgroup per sample): sigmoid + threshold (ordered compaction), stable rank sort, sorted BEV boxes
+__global__ void __launch_bounds__(1024) rescore_prep_kernel(RnParams P, int *__restrict__ mcount)
 {
     __shared__ int wsum[17];
     __shared__ float s_score[kRnLdsScores];
-    __shared__ int s_m, s_nk;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int K = min(P.counts[b], P.capK);
     int *cand = P.cand + (size_t)b * P.capK;
     float *cscore = P.cscore + (size_t)b * P.capK;
     int *order = P.order + (size_t)b * P.capK;
     float *sb = P.sboxes + (size_t)b * P.capK * 5;
-    unsigned long long *mask = P.mask + (size_t)b * P.capK * P.ncb_cap;
-    int *keep = P.keep + (size_t)b * P.capK;
     const float *guided = P.guided + (size_t)b * P.capK * 7;
-
-    // 1. sigmoid + threshold, ordered compaction
     int running = 0;
     for (int i0 = 0; i0 < K; i0 += 1024) {
         const int i = i0 + tid;
@@ -298,10 +299,10 @@ __global__ void __launch_bounds__(1024) rescore_nms_kernel(RnParams P)
         running += tot;
     }
     const int M = running;
+    if (tid == 0) mcount[b] = M;
     __syncthreads();
-    if (M == 0) { if (tid == 0) P.out_counts[b] = 0; return; }
+    if (M == 0) return;
     const bool lds_scores = M <= kRnLdsScores;
-    // 2. stable descending rank sort
     for (int i = tid; i < M; i += 1024) {
         const float si = cscore[i];
         int rank = 0;
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(1024) rescore_nms_kernel(RnParams P)
         order[rank] = i;
     }
     __syncthreads();
-    // 3. BEV boxes (x - w/2, y - l/2, x + w/2, y + l/2, r) in sorted order  (iou3d_utils.py:47-60)
+    // BEV boxes (x - w/2, y - l/2, x + w/2, y + l/2, r) in sorted order  (iou3d_utils.py:47-60)
     for (int r = tid; r < M; r += 1024) {
         const float *g = guided + (size_t)cand[order[r]] * 7;
         const float hx = g[3] / 2, hy = g[4] / 2;
@@ -320,17 +321,39 @@ __global__ void __launch_bounds__(1024) rescore_nms_kernel(RnParams P)
         sb[r * 5 + 2] = g[0] + hx; sb[r * 5 + 3] = g[1] + hy;
         sb[r * 5 + 4] = g[6];
     }
-    __syncthreads();
-    // 4. suppression bitmask: wave per (row, column block >= row/64)
+}
+
+// stage B (many workgroups, grid-stride over (row, column block) items of the upper triangle)
+__global__ void __launch_bounds__(256) rescore_mask_kernel(RnParams P, const int *__restrict__ mcount)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int M = mcount[b];
     const int ncb = (M + 63) >> 6;
-    for (int item = wave; item < M * ncb; item += 16) {
+    const float *sb = P.sboxes + (size_t)b * P.capK * 5;
+    unsigned long long *mask = P.mask + (size_t)b * P.capK * P.ncb_cap;
+    const int nwaves = gridDim.x * 4;
+    for (int item = blockIdx.x * 4 + (threadIdx.x >> 6); item < M * ncb; item += nwaves) {
         const int row = item / ncb, cb = item - row * ncb;
         if (cb < (row >> 6)) continue;
         const unsigned long long w = nms_word(sb, M, row, cb, P.iou_thr, lane);
         if (lane == 0) mask[(size_t)row * ncb + cb] = w;
     }
-    __syncthreads();
-    // 5. greedy reduce by wave 0
+}
+
+// stage C (one workgroup per sample): greedy reduce by wave 0, then gather
+__global__ void __launch_bounds__(256) rescore_final_kernel(RnParams P, const int *__restrict__ mcount)
+{
+    __shared__ int s_nk;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = mcount[b];
+    if (M == 0) { if (tid == 0) P.out_counts[b] = 0; return; }
+    const int ncb = (M + 63) >> 6;
+    const int *cand = P.cand + (size_t)b * P.capK;
+    const float *cscore = P.cscore + (size_t)b * P.capK;
+    const int *order = P.order + (size_t)b * P.capK;
+    const unsigned long long *mask = P.mask + (size_t)b * P.capK * P.ncb_cap;
+    int *keep = P.keep + (size_t)b * P.capK;
+    const float *guided = P.guided + (size_t)b * P.capK * 7;
     if (wave == 0) {
         const int nk = nms_greedy<1>(mask, M, ncb, lane, nullptr, keep, P.capK);
         if (lane == 0) s_nk = nk;
@@ -338,8 +361,7 @@ __global__ void __launch_bounds__(1024) rescore_nms_kernel(RnParams P)
     __syncthreads();
     int nk = s_nk;
     if (nk > P.capD) { if (tid == 0 && P.status) atomicOr(P.status, SASSD_ST_BOX_OVERFLOW); nk = P.capD; }
-    // 6. gather
-    for (int t = tid; t < nk; t += 1024) {
+    for (int t = tid; t < nk; t += 256) {
         const int c = order[keep[t]];
         const int src = cand[c];
         float *ob = P.out_boxes + ((size_t)b * P.capD + t) * 7;
@@ -349,7 +371,6 @@ __global__ void __launch_bounds__(1024) rescore_nms_kernel(RnParams P)
         P.out_labels[(size_t)b * P.capD + t] = P.labels[(size_t)b * P.capK + src];
     }
     if (tid == 0) P.out_counts[b] = nk;
-    (void)s_m;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -366,7 +387,7 @@ __global__ void __launch_bounds__(256) pair_kernel(const float *__restrict__ a, 
     out[t] = IOU ? iou3d::iou_bev(A, Bx) : iou3d::box_overlap(A, Bx);
 }
 
-struct RnLayout { size_t cand, cscore, order, sboxes, mask, keep, total; int ncb_cap; };
+struct RnLayout { size_t cand, cscore, order, sboxes, mask, keep, mcount, total; int ncb_cap; };
 RnLayout rn_layout(int B, int capK)
 {
     RnLayout L;
@@ -378,6 +399,7 @@ RnLayout rn_layout(int B, int capK)
     L.sboxes = o; o += align_up((size_t)B * capK * 5 * 4, 256);
     L.mask = o;   o += align_up((size_t)B * capK * L.ncb_cap * 8, 256);
     L.keep = o;   o += align_up((size_t)B * capK * 4, 256);
+    L.mcount = o; o += align_up((size_t)B * 4, 256);
     L.total = o;
     return L;
 }
@@ -459,7 +481,11 @@ extern "C" int sassd_rescore_nms(const float *guided, const float *logits, const
     P.cand = (int *)(w + L.cand); P.cscore = (float *)(w + L.cscore); P.order = (int *)(w + L.order);
     P.sboxes = (float *)(w + L.sboxes); P.mask = (unsigned long long *)(w + L.mask); P.keep = (int *)(w + L.keep);
     P.ncb_cap = L.ncb_cap;
-    hipLaunchKernelGGL(rescore_nms_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream_, P);
+    int *mcount = (int *)(w + L.mcount);
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(rescore_prep_kernel, dim3(batch), dim3(1024), 0, stream, P, mcount);
+    hipLaunchKernelGGL(rescore_mask_kernel, dim3(512, batch), dim3(256), 0, stream, P, (const int *)mcount);
+    hipLaunchKernelGGL(rescore_final_kernel, dim3(batch), dim3(256), 0, stream, P, (const int *)mcount);
     return sassd_launch_status();
 }
 

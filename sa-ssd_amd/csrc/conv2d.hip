@@ -17,9 +17,11 @@
 //   halo) is staged ONCE in LDS and serves all 9 taps through shifted LDS reads -- 9x less L2->LDS traffic than
 //   per-tap im2col staging, no border masks in the inner loop.  LDS images are k-major ([k][cout] / [k][pixel]) so
 //   both MFMA operand reads are 32 consecutive dwords per half-wave: conflict free without a swizzle.
-//   Pipelining: LDS is double buffered; the global loads of chunk i+1 (16-B per lane, precomputed offsets) are
-//   issued BEFORE the 324 MFMAs of chunk i and written to the other LDS buffer after them (issue-early /
-//   write-late), one barrier per chunk.
+//   Pipelining: LDS is double buffered and filled by direct global->LDS DMA (global_load_lds_dwordx4, 1 KiB per wave
+//   instruction, no staging VGPRs, no ds_write): the DMA of chunk i+1 is issued before the 324 MFMAs of chunk i and
+//   drained (vmcnt) at the single barrier per chunk.  The LDS image is lane-linear, so the zero halo / out-of-image
+//   rows are produced by pointing those lanes' SOURCE address at a 16-byte zero page -- no masks, no memset.
+//   (Rows not 16-B aligned, W % 4 != 0, fall back to register staging.)
 // Roofline: MFMA (fp32) bound; FLOPs = 2*Cout*Cin*k*k*H*W.
 #include <type_traits>
 
@@ -28,6 +30,10 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
 template <int CT, int TAPS, int VEC>
 struct ConvCfg {
@@ -39,8 +45,10 @@ struct ConvCfg {
     static constexpr int PIX = NSEG * 32;
     static constexpr int WV4 = TAPS * KC * BMC / 4;    // weight float4 per chunk
     static constexpr int NLW = (WV4 + 255) / 256;      // weight float4 per thread
-    static constexpr int MAXLP = (VEC == 4) ? 10 : 40; // patch loads per thread (upper bound)
-    static constexpr int WS = TAPS * KC * BMC;         // floats
+    static constexpr int MAXLP = (VEC == 4) ? 1 : 40;  // register-staged patch loads per thread (VEC == 1 path)
+    static constexpr int WS = TAPS * KC * BMC;         // floats (multiple of 256)
+    static constexpr int NWJ = (WS / 256 + 3) / 4;     // weight DMA wave-loads per wave
+    static constexpr int MAXPJ = 10;                   // patch DMA wave-loads per wave (upper bound)
 };
 
 struct ConvParams {
@@ -78,7 +86,6 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
     constexpr int NSEG = C::NSEG, BMC = C::BMC, PIX = C::PIX, KC = C::KC, HALO = C::HALO, NLW = C::NLW,
                   MAXLP = C::MAXLP, WS = C::WS;
     constexpr bool KSPLIT = C::KSPLIT;
-    typedef typename std::conditional<VEC == 4, float4, float>::type pvec_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -94,38 +101,9 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
     const int PW = P.PW;
     const int chs = P.NPR * PW;                       // channel stride inside the patch image
     const int PS = KC * chs;
-    const int bufs = WS + PS;                         // floats per LDS buffer
-
-    // ---- zero both staging buffers once: halos / out-of-image rows stay zero forever ---------------
-    for (int i = tid; i < 2 * bufs; i += 256) smem[i] = 0.f;
-
-    // ---- per-thread load descriptors (constant across K chunks) ------------------------------------
-    const int WV = P.W / VEC;
-    int goff[MAXLP], loff[MAXLP];
-#pragma unroll
-    for (int i = 0; i < MAXLP; ++i) {
-        const int f = tid + 256 * i;
-        goff[i] = -1;
-        loff[i] = 0;
-        if (f < KC * nprows * WV) {
-            const int r = f / WV, cv = f - r * WV;
-            const int kc = r / nprows, pr = r - kc * nprows;
-            const int yy = y_first - HALO + pr;
-            if (yy >= 0 && yy < P.H) {
-                goff[i] = (kc * P.H + yy) * P.W + cv * VEC;
-                loff[i] = kc * chs + pr * PW + 4 + cv * VEC;
-            }
-        }
-    }
-    int woff_g[NLW], woff_l[NLW];
-#pragma unroll
-    for (int i = 0; i < NLW; ++i) {
-        const int f = tid + 256 * i;
-        constexpr int V = BMC / 4;
-        const int row = f / V, c4 = f - row * V;
-        woff_g[i] = (f < C::WV4) ? row * P.CoutPad + cg * BMC + c4 * 4 : -1;
-        woff_l[i] = row * BMC + c4 * 4;
-    }
+    const int PSpad = (PS + 255) / 256 * 256;
+    const int bufs = WS + PSpad;                      // floats per LDS buffer (1 KiB aligned)
+    constexpr bool DMA = (VEC == 4);
 
     int laddr[NSEG];
 #pragma unroll
@@ -148,29 +126,97 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
     const int aoff = (lane >> 5) * BMC + ct * 32 + (lane & 31);
     const bool ragged = (P.Cin % KC) != 0;
 
+    // ================= staging descriptors ==========================================================
+    // DMA path: wave-load j covers LDS float4 slots [64j, 64j+64); lane l owns slot 64j + l.
+    int wsrc[C::NWJ];            // global float offset of this lane's weight float4 (or -2: no such load)
+    int psrc[C::MAXPJ];          // global float offset inside the channel chunk, -1: zero page, -2: no such load
+    // register path (VEC == 1)
+    int goff[MAXLP], loff[MAXLP];
+    float preg[MAXLP];
     float4 wreg[NLW];
-    pvec_t preg[MAXLP];
+    int woff_g[NLW], woff_l[NLW];
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < C::NWJ; ++i) {
+            const int q = 64 * (wave + 4 * i) + lane;
+            constexpr int V = BMC / 4;
+            const int row = q / V, c4 = q - row * V;
+            wsrc[i] = (q * 4 < WS) ? row * P.CoutPad + cg * BMC + c4 * 4 : -2;
+        }
+#pragma unroll
+        for (int i = 0; i < C::MAXPJ; ++i) {
+            const int e = (64 * (wave + 4 * i) + lane) * 4;
+            psrc[i] = -2;
+            if (e < PS) {
+                const int kc = e / chs, rem = e - kc * chs;
+                const int pr = rem / PW, col = rem - pr * PW;
+                const int yy = y_first - HALO + pr;
+                psrc[i] = (pr < nprows && yy >= 0 && yy < P.H && col >= 4 && col < 4 + P.W)
+                              ? (kc * P.H + yy) * P.W + col - 4 : -1;
+            }
+        }
+    } else {
+        for (int i = tid; i < 2 * bufs; i += 256) smem[i] = 0.f;      // halos / invalid rows stay zero
+        const int WV = P.W;
+#pragma unroll
+        for (int i = 0; i < MAXLP; ++i) {
+            const int f = tid + 256 * i;
+            goff[i] = -1;
+            loff[i] = 0;
+            if (f < KC * nprows * WV) {
+                const int r = f / WV, cv = f - r * WV;
+                const int kc = r / nprows, pr = r - kc * nprows;
+                const int yy = y_first - HALO + pr;
+                if (yy >= 0 && yy < P.H) {
+                    goff[i] = (kc * P.H + yy) * P.W + cv;
+                    loff[i] = kc * chs + pr * PW + 4 + cv;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int f = tid + 256 * i;
+            constexpr int V = BMC / 4;
+            const int row = f / V, c4 = f - row * V;
+            woff_g[i] = (f < C::WV4) ? row * P.CoutPad + cg * BMC + c4 * 4 : -1;
+            woff_l[i] = row * BMC + c4 * 4;
+        }
+        __syncthreads();
+    }
 
+    // channel clamp for a ragged last chunk: channels >= Cin read channel Cin-1 (their packed weights are zero)
+    auto clamp_off = [&](int ch, int off) -> size_t {
+        size_t o = (size_t)ch * KC * P.HW + off;
+        if (ragged && ch + 1 == nchunk) {
+            const int kc = off / P.HW;
+            const int over = max(ch * KC + kc - (P.Cin - 1), 0);
+            o -= (size_t)over * P.HW;
+        }
+        return o;
+    };
+    auto dma = [&](int ch, float *buf) {
+        const float *wsrc_base = P.wp + (size_t)ch * TAPS * KC * P.CoutPad;
+#pragma unroll
+        for (int i = 0; i < C::NWJ; ++i)
+            if (wsrc[i] > -2)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc_base + wsrc[i]),
+                                                 (lds_ptr_t)(buf + 256 * (wave + 4 * i)), 16, 0, 0);
+        float *pbuf = buf + WS;
+#pragma unroll
+        for (int i = 0; i < C::MAXPJ; ++i)
+            if (psrc[i] > -2) {
+                const float *src = (psrc[i] >= 0) ? xb + clamp_off(ch, psrc[i]) : g_zero_page;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(pbuf + 256 * (wave + 4 * i)), 16, 0, 0);
+            }
+    };
     auto issue = [&](int ch) {
-        const float *wsrc = P.wp + (size_t)ch * TAPS * KC * P.CoutPad;
+        const float *wsrc_base = P.wp + (size_t)ch * TAPS * KC * P.CoutPad;
 #pragma unroll
         for (int i = 0; i < NLW; ++i)
-            if (woff_g[i] >= 0) wreg[i] = *(const float4 *)(wsrc + woff_g[i]);
-        const float *xc = xb + (size_t)ch * KC * P.HW;
-        if (!ragged || ch + 1 < nchunk) {
+            if (woff_g[i] >= 0) wreg[i] = *(const float4 *)(wsrc_base + woff_g[i]);
 #pragma unroll
-            for (int i = 0; i < MAXLP; ++i)
-                if (goff[i] >= 0) preg[i] = *(const pvec_t *)(xc + goff[i]);
-        } else {
-            // last, partial chunk: channels >= Cin are clamped to Cin-1 (their packed weights are zero)
-#pragma unroll
-            for (int i = 0; i < MAXLP; ++i)
-                if (goff[i] >= 0) {
-                    const int kc = goff[i] / P.HW;
-                    const int over = max(ch * KC + kc - (P.Cin - 1), 0);
-                    preg[i] = *(const pvec_t *)(xc + goff[i] - (size_t)over * P.HW);
-                }
-        }
+        for (int i = 0; i < MAXLP; ++i)
+            if (goff[i] >= 0) preg[i] = xb[clamp_off(ch, goff[i])];
     };
     auto commit = [&](float *buf) {
 #pragma unroll
@@ -179,19 +225,25 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
         float *pbuf = buf + WS;
 #pragma unroll
         for (int i = 0; i < MAXLP; ++i)
-            if (goff[i] >= 0) *(pvec_t *)(pbuf + loff[i]) = preg[i];
+            if (goff[i] >= 0) pbuf[loff[i]] = preg[i];
     };
 
-    __syncthreads();                 // zero fill done
-    issue(0);
-    commit(smem);
+    if constexpr (DMA) {
+        dma(0, smem);
+    } else {
+        issue(0);
+        commit(smem);
+    }
     __syncthreads();
 
     for (int ch = 0; ch < nchunk; ++ch) {
         const float *W_s = smem + (ch & 1) * bufs;
         const float *P_s = W_s + WS;
         const bool more = ch + 1 < nchunk;
-        if (more) issue(ch + 1);
+        if (more) {
+            if constexpr (DMA) dma(ch + 1, smem + ((ch + 1) & 1) * bufs);
+            else issue(ch + 1);
+        }
         // ---- MFMA: TAPS x (KC/2) k-steps x NSEG segments -------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -217,8 +269,10 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
                 }
             }
         }
-        if (more) commit(smem + ((ch + 1) & 1) * bufs);
-        __syncthreads();
+        if constexpr (!DMA) {
+            if (more) commit(smem + ((ch + 1) & 1) * bufs);
+        }
+        __syncthreads();                 // drains the in-flight LDS-DMA (vmcnt) before the buffers swap
     }
 
     // ---- epilogue: D[row = cout][col = pixel] ----------------------------------------------------------
@@ -280,11 +334,13 @@ int launch_conv(ConvParams P, hipStream_t stream)
     P.ncg = P.CoutPad / C::BMC;
     P.PW = (P.W + 8 + 3) / 4 * 4;
     P.NPR = (C::PIX - 1 + P.W - 1) / P.W + 1 + 2 * C::HALO;
-    const size_t stage = 2 * ((size_t)C::WS + (size_t)C::KC * P.NPR * P.PW) * sizeof(float);
+    const size_t ps = ((size_t)C::KC * P.NPR * P.PW + 255) / 256 * 256;
+    const size_t stage = 2 * ((size_t)C::WS + ps) * sizeof(float);
     const size_t red = C::KSPLIT ? (size_t)4 * C::NSEG * 16 * 64 * sizeof(float) : 0;
     const size_t lds = stage > red ? stage : red;
     if (lds > 160 * 1024) return SASSD_EINVAL;
-    if ((size_t)C::KC * P.NPR * (P.W / VEC) > (size_t)256 * C::MAXLP) return SASSD_EINVAL;
+    if (VEC == 4 ? (ps > (size_t)C::MAXPJ * 4 * 256) : ((size_t)C::KC * P.NPR * P.W > (size_t)256 * C::MAXLP))
+        return SASSD_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)conv2d_kernel<CT, TAPS, VEC>,

@@ -56,6 +56,7 @@ def build_model(seed=0):
 def cpu_baseline(model, an, bv, cal, budget_s=20.0):
     import helpers as H
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(torch.get_num_threads(), 16))      # oneDNN / index_add scale poorly past ~16 threads here
     frames, t0 = 0, time.time()
     while frames < 2 or (time.time() - t0 < budget_s and frames < 8):
         H.oracle_forward(sd, [synth.k21(100 + frames)], an, bv, cal)
@@ -76,13 +77,8 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic frames cycled through")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")          # RCCL; used only for the barrier + max-time reduction
+    from sassd import dist as D
+    rank, local_rank, world = D.init("nccl")     # RCCL over xGMI; only the barrier + max-time reduction use it
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -92,8 +88,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -110,10 +105,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, plan.prof = plan.prof, None
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.allreduce_max(dt, dev)
     ndet = int(plan.det["counts"].sum().item())
 
     # latency mode (host sync + result read-back per frame), reported as an extra

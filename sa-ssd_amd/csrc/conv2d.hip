@@ -194,20 +194,22 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
         }
         return o;
     };
+    // one weight wave-load + one (or two) patch wave-loads; part in [0, NPARTS)
+    constexpr int NPARTS = (C::NWJ > C::MAXPJ) ? C::NWJ : C::MAXPJ;
+    auto dma_part = [&](int ch, float *buf, int part) {
+        if (part < C::NWJ && wsrc[part] > -2) {
+            const float *wsrc_base = P.wp + (size_t)ch * TAPS * KC * P.CoutPad;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc_base + wsrc[part]),
+                                             (lds_ptr_t)(buf + 256 * (wave + 4 * part)), 16, 0, 0);
+        }
+        if (part < C::MAXPJ && psrc[part] > -2) {
+            const float *src = (psrc[part] >= 0) ? xb + clamp_off(ch, psrc[part]) : g_zero_page;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + WS + 256 * (wave + 4 * part)), 16, 0, 0);
+        }
+    };
     auto dma = [&](int ch, float *buf) {
-        const float *wsrc_base = P.wp + (size_t)ch * TAPS * KC * P.CoutPad;
 #pragma unroll
-        for (int i = 0; i < C::NWJ; ++i)
-            if (wsrc[i] > -2)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc_base + wsrc[i]),
-                                                 (lds_ptr_t)(buf + 256 * (wave + 4 * i)), 16, 0, 0);
-        float *pbuf = buf + WS;
-#pragma unroll
-        for (int i = 0; i < C::MAXPJ; ++i)
-            if (psrc[i] > -2) {
-                const float *src = (psrc[i] >= 0) ? xb + clamp_off(ch, psrc[i]) : g_zero_page;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(pbuf + 256 * (wave + 4 * i)), 16, 0, 0);
-            }
+        for (int part = 0; part < NPARTS; ++part) dma_part(ch, buf, part);
     };
     auto issue = [&](int ch) {
         const float *wsrc_base = P.wp + (size_t)ch * TAPS * KC * P.CoutPad;
@@ -240,14 +242,23 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
         const float *W_s = smem + (ch & 1) * bufs;
         const float *P_s = W_s + WS;
         const bool more = ch + 1 < nchunk;
+        float *nbuf = smem + ((ch + 1) & 1) * bufs;
         if (more) {
-            if constexpr (DMA) dma(ch + 1, smem + ((ch + 1) & 1) * bufs);
-            else issue(ch + 1);
+            if constexpr (!DMA) issue(ch + 1);
+            else if constexpr (TAPS == 1) dma(ch + 1, nbuf);
         }
         // ---- MFMA: TAPS x (KC/2) k-steps x NSEG segments -------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int toff = (TAPS == 9) ? ((tap / 3 - 1) * PW + (tap % 3 - 1)) : 0;
+            if constexpr (DMA && TAPS == 9) {
+                // spread the next chunk's DMA issue over the taps so its address math hides under the MFMAs
+                // (all parts are issued during taps 0..5, leaving >= 108 MFMAs for the last one to land)
+                if (more && tap < 6) {
+#pragma unroll
+                    for (int part = tap; part < NPARTS; part += 6) dma_part(ch + 1, nbuf, part);
+                }
+            }
             if constexpr (!KSPLIT) {
 #pragma unroll
                 for (int s = 0; s < KC / 2; ++s) {

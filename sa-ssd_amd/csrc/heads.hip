@@ -231,6 +231,52 @@ __device__ __forceinline__ int nms_greedy(const unsigned long long *mask, int n,
     return nk;
 }
 
+// Greedy reduce, 64 rows at a time, by ONE wave (n <= 4096 boxes: lane l owns the removal word of column block l).
+//   * the 64x64 diagonal block is resolved on the scalar unit: lane i holds row i's diagonal word, the running
+//     removal word lives in SGPRs and is updated through v_readlane -- no memory access in the serial chain;
+//   * the kept rows' remaining words are then OR-ed into the later column blocks with independent, pipelined
+//     loads (one 8-byte word per lane per kept row).
+// Identical result to the serial host loop of iou3d.cpp:100-116.
+__device__ __forceinline__ int nms_greedy_chunked(const unsigned long long *__restrict__ mask, int n, int ncb, int lane,
+                                                  int *__restrict__ keep, int cap_keep)
+{
+    unsigned long long remv = 0ull;                  // lane l: removal bits of boxes 64l .. 64l+63
+    int nk = 0;
+    for (int cb0 = 0; cb0 < ncb; ++cb0) {
+        const int r = cb0 * 64 + lane;
+        const unsigned long long dw = (r < n) ? mask[(size_t)r * ncb + cb0] : 0ull;
+        const unsigned dlo = (unsigned)dw, dhi = (unsigned)(dw >> 32);
+        unsigned long long rem = __shfl(remv, cb0, 64);
+        rem = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
+              (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)rem);
+        const int rows = min(64, n - cb0 * 64);
+        unsigned long long kept = 0ull;
+        for (int i = 0; i < rows; ++i) {
+            if (!((rem >> i) & 1ull)) {
+                kept |= 1ull << i;
+                rem |= ((unsigned long long)__builtin_amdgcn_readlane(dhi, i) << 32) |
+                       (unsigned long long)__builtin_amdgcn_readlane(dlo, i);
+            }
+        }
+        // record kept rows in order
+        if ((kept >> lane) & 1ull) {
+            const int pos = nk + __popcll(kept & ((1ull << lane) - 1ull));
+            if (pos < cap_keep) keep[pos] = r;
+        }
+        nk += __popcll(kept);
+        // propagate to later column blocks
+        unsigned long long acc = 0ull;
+        unsigned long long km = kept;
+        while (km) {
+            const int i = __ffsll((long long)km) - 1;
+            km &= km - 1ull;
+            if (lane > cb0 && lane < ncb) acc |= mask[(size_t)(cb0 * 64 + i) * ncb + lane];
+        }
+        remv |= acc;
+    }
+    return nk;
+}
+
 __global__ void __launch_bounds__(256) nms_mask_kernel(const float *__restrict__ boxes, int n, int ncb, float thr,
                                                        unsigned long long *__restrict__ mask)
 {
@@ -302,13 +348,21 @@ __global__ void __launch_bounds__(1024) rescore_prep_kernel(RnParams P, int *__r
     if (tid == 0) mcount[b] = M;
     __syncthreads();
     if (M == 0) return;
-    const bool lds_scores = M <= kRnLdsScores;
+    // stable descending rank sort: rank_i = #{j : s_j > s_i or (s_j == s_i and j < i)}
     for (int i = tid; i < M; i += 1024) {
         const float si = cscore[i];
         int rank = 0;
-        for (int j = 0; j < M; ++j) {
-            const float sj = lds_scores ? s_score[j] : cscore[j];
-            rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+        if (M <= kRnLdsScores) {
+#pragma unroll 8
+            for (int j = 0; j < M; ++j) {
+                const float sj = s_score[j];
+                rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+            }
+        } else {
+            for (int j = 0; j < M; ++j) {
+                const float sj = cscore[j];
+                rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+            }
         }
         order[rank] = i;
     }
@@ -355,7 +409,7 @@ __global__ void __launch_bounds__(256) rescore_final_kernel(RnParams P, const in
     int *keep = P.keep + (size_t)b * P.capK;
     const float *guided = P.guided + (size_t)b * P.capK * 7;
     if (wave == 0) {
-        const int nk = nms_greedy<1>(mask, M, ncb, lane, nullptr, keep, P.capK);
+        const int nk = nms_greedy_chunked(mask, M, ncb, lane, keep, P.capK);
         if (lane == 0) s_nk = nk;
     }
     __syncthreads();

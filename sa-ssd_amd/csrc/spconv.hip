@@ -3,17 +3,12 @@
 // Replaces spconv v1.0 `indice_conv_fp32` (27 x {gather kernel, cuBLAS sgemm, scatter-add kernel} per layer,
 // ~80 launches) + nn.BatchNorm1d + nn.ReLU (mmdet/models/necks/cmn.py:138-173,208-212) by ONE launch per layer.
 //
-// Work decomposition (wave = 64 lanes, CDNA4):
-//   workgroup = tile of 64 output rows, NT = Cout/16 waves; wave w owns output channels [16w, 16w+16).
-//   1. the tile's rulebook records nbr[64][27] are copied to LDS (one coalesced 6.9 KB read);
-//   2. per kernel offset k a wave ballots "row has a neighbour at k" and compacts (row, in_row) pairs into an
-//      LDS list -- only real pairs are multiplied (dense 27-offset evaluation would waste ~3x the FLOPs);
-//   3. pairs are processed 16 at a time: A = 16 gathered input rows (each lane loads Cin/4 contiguous floats of
-//      its row straight from HBM/L2), B = W[k][:, 16 couts] fragment (pre-packed, 16 B/lane loads);
-//      Cin/4 v_mfma_f32_16x16x4_f32 steps (exact fp32, the fp32 MFMA rate equals the fp32 VALU rate but needs one
-//      VGPR per operand);  results are scatter-ACCUMULATED into the tile's fp32 accumulator in LDS
-//      (each wave owns its 16 columns -> plain read-modify-write, deterministic summation order);
-//   4. epilogue: LDS accumulator -> scale/shift/ReLU -> coalesced float4 stores.
+// Work decomposition (wave = 64 lanes, CDNA4): see spconv_fwd_kernel below -- a register-stationary design: every
+// wave owns a 16-row x 16-channel output tile for ALL kernel offsets, accumulates in registers with
+// v_mfma_f32_16x16x4_f32 (exact fp32; the fp32 MFMA rate equals the fp32 VALU rate but needs one VGPR per operand)
+// and gathers its A operand straight from HBM/L2 in fragment order.  An earlier LDS-staged gather/scatter version
+// (per-offset compaction + LDS accumulators) was 3-4x slower at KITTI scale: at ~14k rows the layer is latency
+// bound, and per-offset barriers / LDS round trips cost more than the zero-padded MFMA work they saved.
 // Roofline: HBM/L2 bound (<= 16 FLOP/B); algorithmic bytes B_gs = 4P(Cin+Cout) + 8P + 4K*Cin*Cout + 4*Nout*Cout.
 #include "common.h"
 
@@ -21,7 +16,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTile = 64;      // output rows per workgroup
+
 constexpr int kK = 27;
 
 template <int CIN, int COUT>
@@ -62,98 +57,142 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int K, float *__
     packed[i] = w[((size_t)k * CIN + q * S::KS + kk) * COUT + nt * 16 + m];
 }
 
+int g_spconv_dbg = 0;           // reserved debug switch (tools/ablate_spconv.py); 0 in production
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+
+// Register-stationary sparse conv: one wave = 16 output rows x ALL Cout channels x all K offsets.
+//   accumulators  NT x f32x4 (x2 chains) per lane in registers for the whole layer: no LDS accumulation, no
+//                 atomics, deterministic summation order k = 0..K-1
+//   rulebook      the lane's row record nbr[row][0..26] is loaded once into 27 registers (coalesced 108-B records)
+//   A operand     rows gathered straight from HBM/L2 in MFMA fragment order (lane (m,q) reads Cin/4 contiguous
+//                 floats of row nbr[m][k]; missing neighbours contribute zeros), each row read ONCE per offset,
+//                 prefetched one offset ahead under the previous offset's MFMAs
+//   B operand     W[k] (all Cout) is shared by the 4 waves of the workgroup: direct global->LDS DMA of the
+//                 pre-packed fragment image (lane-linear, conflict-free 16-B reads), double buffered, one barrier
+//                 per offset.  This keeps the CU's vector-memory pipe (64 B/clk) -- not the MFMA pipe -- from
+//                 being the bottleneck: per offset a workgroup moves 16 KB of A + 16 KB of B instead of 128 KB.
+//   offsets with no neighbour in the wave's 16 rows skip their MFMAs (wave-uniform ballot)
 template <int CIN, int COUT>
-__global__ void __launch_bounds__((COUT / 16) * 64)
+__global__ void __launch_bounds__(256)
 spconv_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_ptr,
                   int cap, const float *__restrict__ wp, int K, const float *__restrict__ scale,
-                  const float *__restrict__ shift, int relu, float *__restrict__ y)
+                  const float *__restrict__ shift, int relu, float *__restrict__ y, int dbg)
 {
     using S = SpShape<CIN, COUT>;
-    constexpr int KS = S::KS, NT = S::NT, LDA = S::LDA;
-    __shared__ __attribute__((aligned(16))) float acc_s[kTile * LDA];
-    __shared__ int nbr_s[kTile * kK];
-    __shared__ int list_idx[kK * kTile];
-    __shared__ unsigned char list_row[kK * kTile];
-    __shared__ int cnt_s[kK];
+    constexpr int KS = S::KS, NT = S::NT;
+    constexpr bool BLDS = (KS >= 4);                // B through LDS-DMA (16-B pieces); KS == 1: plain loads
+    constexpr int J = BLDS ? KS / 4 : 1;            // float4 pieces per lane per channel tile
+    constexpr int NWL = NT * J;                     // B wave-loads per offset
+    constexpr int BBUF = NWL * 256;                 // floats per B buffer
+    __shared__ __attribute__((aligned(16))) float bs[2 * BBUF];
 
     const int n = min(*n_ptr, cap);
-    const int r0 = blockIdx.x * kTile;
-    if (r0 >= n) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rows = min(kTile, n - r0);
-
-    // ---- 1. stage rulebook records + zero the accumulator ----------------------------------------
-    if (nbr) {
-        const int32_t *src = nbr + (size_t)r0 * kK;
-        for (int i = tid; i < rows * kK; i += NT * 64) nbr_s[i] = src[i];
-    }
-    for (int i = tid; i < kTile * LDA; i += NT * 64) acc_s[i] = 0.f;
-    __syncthreads();
-
-    // ---- 2. per-offset compaction (wave w handles offsets w, w+NT, ...) --------------------------
-    for (int k = wave; k < K; k += NT) {
-        int v = -1;
-        if (lane < rows) v = nbr ? nbr_s[lane * kK + k] : (r0 + lane);
-        const unsigned long long m = __ballot(v >= 0);
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (v >= 0) { list_idx[k * kTile + rank] = v; list_row[k * kTile + rank] = (unsigned char)lane; }
-        if (lane == 0) cnt_s[k] = __popcll(m);
-    }
-    __syncthreads();
-
-    // ---- 3. gather -> MFMA -> LDS scatter-accumulate ---------------------------------------------
+    if ((int)blockIdx.x * 64 >= n) return;          // workgroup-uniform
+    const int rb = (blockIdx.x * 4 + wave) * 16;
     const int q = lane >> 4, m16 = lane & 15;
-    const float *wbase = wp + ((size_t)wave * 64 + lane) * KS;          // + k * NT*64*KS
-    for (int k = 0; k < K; ++k) {
-        const int c = cnt_s[k];
-        if (c == 0) continue;
-        float bf[KS];
-        load_vec<KS>(wbase + (size_t)k * NT * 64 * KS, bf);
-        for (int j0 = 0; j0 < c; j0 += 16) {
-            const int p = j0 + m16;
-            float af[KS];
-            if (p < c) {
-                const int idx = list_idx[k * kTile + p];
-                load_vec<KS>(x + (size_t)idx * CIN + q * KS, af);
-            } else {
+    const int row = rb + m16;
+    const bool rok = row < n;
+
+    // ---- rulebook record of this lane's row -> registers -----------------------------------------
+    int nb[kK];
+    unsigned act = 0;                               // bit k: some row of this wave has a neighbour at offset k
+    if (nbr) {
 #pragma unroll
-                for (int i = 0; i < KS; ++i) af[i] = 0.f;
-            }
-            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < kK; ++k) {
+            nb[k] = rok ? nbr[(size_t)row * kK + k] : -1;
+            act |= (__ballot(nb[k] >= 0) != 0ull) ? (1u << k) : 0u;
+        }
+    } else {
+        nb[0] = rok ? row : -1;
+        act = (__ballot(nb[0] >= 0) != 0ull) ? 1u : 0u;
 #pragma unroll
-            for (int kk = 0; kk < KS; kk += 2) {
-                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], bf[kk], d0, 0, 0, 0);
-                if (kk + 1 < KS) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk + 1], bf[kk + 1], d1, 0, 0, 0);
-            }
-            // D[row = q*4 + reg][col = m16]  -> pair j0 + q*4 + reg, channel wave*16 + m16
+        for (int k = 1; k < kK; ++k) nb[k] = -1;
+    }
+
+    float a0[KS], a1[KS];
+    f32x4 d0[NT], d1[NT];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int pr = j0 + q * 4 + reg;
-                if (pr < c) {
-                    const int rl = list_row[k * kTile + pr];
-                    acc_s[rl * LDA + wave * 16 + m16] += d0[reg] + d1[reg];
+    for (int t = 0; t < NT; ++t) { d0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; d1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    auto fetch_a = [&](int k, float (&af)[KS]) {
+        if (nb[k] >= 0) load_vec<KS>(x + (size_t)nb[k] * CIN + q * KS, af);
+        else {
+#pragma unroll
+            for (int i = 0; i < KS; ++i) af[i] = 0.f;
+        }
+    };
+    auto dma_b = [&](int k, float *buf) {
+        if constexpr (BLDS) {
+#pragma unroll
+            for (int i = 0; i < (NWL + 3) / 4; ++i) {
+                const int t = wave + 4 * i;                              // wave-load id: (nt, j)
+                if (t < NWL) {
+                    const int tnt = t / J, j = t - tnt * J;
+                    const float *src = wp + (((size_t)k * NT + tnt) * 64 + lane) * KS + 4 * j;
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + t * 256), 16, 0, 0);
                 }
             }
         }
-    }
-    __syncthreads();
+    };
+    auto mma = [&](int k, const float (&af)[KS], const float *buf) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float bf[KS];
+            if constexpr (BLDS) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const float4 v = *(const float4 *)(buf + ((t * J + j) * 64 + lane) * 4);
+                    bf[4 * j] = v.x; bf[4 * j + 1] = v.y; bf[4 * j + 2] = v.z; bf[4 * j + 3] = v.w;
+                }
+            } else {
+                load_vec<KS>(wp + (((size_t)k * NT + t) * 64 + lane) * KS, bf);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KS; kk += 2) {
+                d0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], bf[kk], d0[t], 0, 0, 0);
+                if (kk + 1 < KS) d1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk + 1], bf[kk + 1], d1[t], 0, 0, 0);
+            }
+        }
+    };
 
-    // ---- 4. epilogue -----------------------------------------------------------------------------
-    constexpr int C4 = COUT / 4;
-    for (int i = tid; i < rows * C4; i += NT * 64) {
-        const int r = i / C4, c4 = i - r * C4;
-        float4 v = *(const float4 *)&acc_s[r * LDA + c4 * 4];
-        if (scale) {
-            const float4 s = ((const float4 *)scale)[c4];
-            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+    const int KK = nbr ? kK : 1;                    // identity rulebook: a single offset
+    dma_b(0, bs);
+    if (act & 1u) fetch_a(0, a0);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kK; k += 2) {
+        if (k < KK) {
+            // even offset k: operands in (a0, bs[0]); odd offset k+1: (a1, bs[BBUF])
+            if (k + 1 < KK) { dma_b(k + 1, bs + BBUF); if ((act >> (k + 1)) & 1u) fetch_a(k + 1, a1); }
+            if ((act >> k) & 1u) mma(k, a0, bs);
+            __syncthreads();
         }
-        if (shift) {
-            const float4 s = ((const float4 *)shift)[c4];
-            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        if (k + 1 < kK && k + 1 < KK) {
+            if (k + 2 < KK) { dma_b(k + 2, bs); if ((act >> (k + 2)) & 1u) fetch_a(k + 2, a0); }
+            if ((act >> (k + 1)) & 1u) mma(k + 1, a1, bs + BBUF);
+            __syncthreads();
         }
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        ((float4 *)(y + (size_t)(r0 + r) * COUT))[c4] = v;
     }
+
+    // ---- epilogue: D[row = q*4 + reg][col = m16] ---------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = t * 16 + m16;
+        const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = rb + q * 4 + reg;
+            if (r < n) {
+                float v = (d0[t][reg] + d1[t][reg]) * sc + sh;
+                if (relu) v = fmaxf(v, 0.f);
+                y[(size_t)r * COUT + co] = v;
+            }
+        }
+    }
+    (void)dbg; (void)K;
 }
 
 template <int CIN, int COUT>
@@ -161,8 +200,8 @@ int launch_fwd(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap
                const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
 {
     using S = SpShape<CIN, COUT>;
-    hipLaunchKernelGGL((spconv_fwd_kernel<CIN, COUT>), dim3(cdiv(cap, kTile)), dim3(S::NT * 64), 0, stream, x, nbr,
-                       n_ptr, cap, wp, K, scale, shift, relu, y);
+    hipLaunchKernelGGL((spconv_fwd_kernel<CIN, COUT>), dim3(cdiv(cap, 64)), dim3(256), 0, stream, x, nbr,
+                       n_ptr, cap, wp, K, scale, shift, relu, y, g_spconv_dbg);
     return sassd_launch_status();
 }
 
@@ -200,6 +239,8 @@ __global__ void densify_kernel(const float *__restrict__ feats, const int32_t *_
 }
 
 }  // namespace
+
+extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags; }
 
 extern "C" size_t sassd_spconv_packed_floats(int K, int Cin, int Cout) { return (size_t)K * Cin * Cout; }
 

@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing for the hot path: one process per GPU, frames sharded across ranks, no data-path collective
+(inference is embarrassingly parallel over frames; the reference runs `single_test` serially,
+tools/test.py:29-32).  torch.distributed is used only for the start/stop barrier and the max-over-ranks timing
+reduction; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU (tests)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def allreduce_max(value, device="cpu"):
+    """max over ranks of a python float."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_sum(value, device="cpu"):
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def frame_shard(num_frames, rank, world):
+    """Round-robin frame indices of this rank: disjoint, complete, balanced to within one frame."""
+    return list(range(rank, num_frames, world))
+
+
+def gather_results(obj):
+    """Host-side gather of per-rank result lists to rank 0 (like collecting result dicts after single_test)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out

@@ -139,3 +139,39 @@ def test_spconv_facade_matches_fused_plan(dev):
     torch.cuda.synchronize()
     assert (x - plan.x).abs().max().item() < 2e-4 * max(1.0, plan.x.abs().max().item())
     assert (conv6 - plan.conv6).abs().max().item() < 2e-4 * max(1.0, plan.conv6.abs().max().item())
+
+
+def test_multi_class_batch(dev):
+    """configs[3] shape: multi_cfg (Car + Pedestrian + Cyclist, 211200 anchors), batch > 1."""
+    model, c = _model("configs/multi_cfg.py", seed=4)
+    names = c.data.val.class_names
+    assert len(names) == 3 and model.rpn_head.conv_cls.out_channels == 18
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    an, bv = _anchors(names)
+    assert an.shape[0] == 211200
+    clouds = [H.frame("small", 20), H.frame("small", 21)]
+    ref = H.oracle_forward(sd, clouds, an, bv, dict(CFG, score_thr=0.3), num_class=3)
+    plan = InferencePlan(sd, batch_size=2, num_class=3, anchors=an, anchors_bv=bv, device=dev, cap_k=4096, cap_d=1024)
+    plan.run_from_points([torch.from_numpy(p).to(dev) for p in clouds])
+    res = plan.results()
+    assert np.array_equal(plan.mask.cpu().numpy().astype(bool), ref["masks"])
+    cnt = plan.df["counts"].cpu().numpy()
+    got_any = False
+    for b in range(2):
+        gb, gl, gs = ref["guided"][b]
+        if (np.abs(gs.numpy() - 0.1) < 1e-5).any():
+            continue
+        assert cnt[b] == len(gb)
+        k = cnt[b]
+        assert np.abs(plan.df["guided"][b, :k].cpu().numpy() - gb.numpy()).max() < 1e-4
+        assert np.array_equal(plan.df["labels"][b, :k].cpu().numpy(), gl.numpy())
+        d = ref["dets"][b]
+        if d is None:
+            assert res[b][0] is None
+            continue
+        if (np.abs(torch.sigmoid(ref["logits"][b]).numpy() - 0.3) < 1e-5).any():
+            continue
+        _match_sets(res[b][0], res[b][1], d[0], d[1])
+        assert np.array_equal(res[b][2], d[2])
+        got_any = True
+    assert got_any

@@ -51,6 +51,11 @@ struct ConvCfg {
     static constexpr int MAXPJ = 10;                   // patch DMA wave-loads per wave (upper bound)
 };
 
+#ifndef SASSD_DMA_TAPS
+#define SASSD_DMA_TAPS 3
+#endif
+constexpr int kDmaTaps = SASSD_DMA_TAPS;   // taps over which the next chunk's DMA issue is spread
+
 struct ConvParams {
     const float *x, *wp, *scale, *shift;
     float *y;
@@ -60,6 +65,7 @@ struct ConvParams {
     int NPR;        // patch rows allocated in LDS
     int PW;         // patch row stride (floats): 4 left pad (col 3 = halo) + W + right halo/pad, multiple of 4
     int relu;
+    int dbg;        // ablation switches (tools/run_conv.py): 1 = no DMA after the first chunk, 2 = no barrier
 };
 
 // w [Cout][Cin][k][k] -> wp [Cin padded to KC][TAPS][CoutPad] grouped as [chunk of KC][tap][kc][CoutPad]
@@ -248,42 +254,54 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
             else if constexpr (TAPS == 1) dma(ch + 1, nbuf);
         }
         // ---- MFMA: TAPS x (KC/2) k-steps x NSEG segments -------------------------------------------
+        // Operand registers are double buffered at tap granularity: the LDS reads of tap t+1 (NSTEP weight +
+        // NSTEP*NSEG pixel operands) are issued as one batch in front of tap t's MFMAs and have the whole MFMA
+        // block (NSTEP*NSEG x 64 cycles) to land; sched_barrier keeps hipcc from sinking them into the block,
+        // where it would emit an s_waitcnt lgkmcnt(0) -- a full LDS round trip -- in front of every MFMA.
+        constexpr int NSTEP = KSPLIT ? KC / 8 : KC / 2;
+        float a_cur[NSTEP], a_nxt[NSTEP], b_cur[NSTEP][NSEG], b_nxt[NSTEP][NSEG];
+        auto read_ops = [&](int tap, float (&av)[NSTEP], float (&bv)[NSTEP][NSEG]) {
+            const int toff = (TAPS == 9) ? ((tap / 3 - 1) * PW + (tap % 3 - 1)) : 0;
+#pragma unroll
+            for (int t = 0; t < NSTEP; ++t) {
+                const int s = KSPLIT ? wave + 4 * t : t;
+                av[t] = W_s[(tap * KC + 2 * s) * BMC + aoff];
+                const float *pb = P_s + 2 * s * chs + toff;
+#pragma unroll
+                for (int j = 0; j < NSEG; ++j) bv[t][j] = pb[laddr[j]];
+            }
+        };
+        read_ops(0, a_cur, b_cur);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = (TAPS == 9) ? ((tap / 3 - 1) * PW + (tap % 3 - 1)) : 0;
             if constexpr (DMA && TAPS == 9) {
-                // spread the next chunk's DMA issue over the taps so its address math hides under the MFMAs
-                // (all parts are issued during taps 0..5, leaving >= 108 MFMAs for the last one to land)
-                if (more && tap < 6) {
+                // spread the next chunk's DMA issue over the first taps so its address math hides under the MFMAs
+                if (more && tap < kDmaTaps && !(P.dbg & 1)) {
 #pragma unroll
-                    for (int part = tap; part < NPARTS; part += 6) dma_part(ch + 1, nbuf, part);
+                    for (int part = tap; part < NPARTS; part += kDmaTaps) dma_part(ch + 1, nbuf, part);
                 }
             }
-            if constexpr (!KSPLIT) {
+            if (tap + 1 < TAPS) read_ops(tap + 1, a_nxt, b_nxt);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < KC / 2; ++s) {
-                    const float a = W_s[(tap * KC + 2 * s) * BMC + aoff];
-                    const float *pb = P_s + 2 * s * chs + toff;
+            for (int t = 0; t < NSTEP; ++t)
 #pragma unroll
-                    for (int j = 0; j < NSEG; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[laddr[j]], acc[j], 0, 0, 0);
-                }
-            } else {
+                for (int j = 0; j < NSEG; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur[t][j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < TAPS) {
 #pragma unroll
-                for (int t = 0; t < KC / 8; ++t) {
-                    const int s = wave + 4 * t;                  // this wave's k-steps
-                    const float a = W_s[(tap * KC + 2 * s) * BMC + aoff];
-                    const float *pb = P_s + 2 * s * chs + toff;
+                for (int t = 0; t < NSTEP; ++t) {
+                    a_cur[t] = a_nxt[t];
 #pragma unroll
-                    for (int j = 0; j < NSEG; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[laddr[j]], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NSEG; ++j) b_cur[t][j] = b_nxt[t][j];
                 }
             }
         }
         if constexpr (!DMA) {
             if (more) commit(smem + ((ch + 1) & 1) * bufs);
         }
-        __syncthreads();                 // drains the in-flight LDS-DMA (vmcnt) before the buffers swap
+        if (!(P.dbg & 2)) __syncthreads();   // drains the in-flight LDS-DMA (vmcnt) before the buffers swap
     }
 
     // ---- epilogue: D[row = cout][col = pixel] ----------------------------------------------------------
@@ -363,10 +381,14 @@ int launch_conv(ConvParams P, hipStream_t stream)
     return sassd_launch_status();
 }
 
+int g_conv_dbg = 0;
+
 inline int cout_pad(int Cout) { return (Cout > 64) ? cdiv(Cout, 128) * 128 : cdiv(Cout, 32) * 32; }
 inline int kc_of(int ksize) { return ksize == 3 ? 8 : 16; }
 
 }  // namespace
+
+extern "C" void sassd_debug_set_conv(int flags) { g_conv_dbg = flags; }
 
 extern "C" size_t sassd_conv2d_packed_floats(int Cin, int Cout, int ksize)
 {
@@ -394,6 +416,7 @@ extern "C" int sassd_conv2d_fwd(const float *x, const float *w_packed, const flo
     P.x = x; P.wp = w_packed; P.scale = scale; P.shift = shift; P.y = y;
     P.B = batch; P.Cin = Cin; P.Cout = Cout; P.CoutPad = cout_pad(Cout); P.H = H; P.W = W; P.HW = H * W;
     P.relu = relu;
+    P.dbg = g_conv_dbg;
     hipStream_t stream = (hipStream_t)stream_;
     const bool wide = P.CoutPad % 128 == 0;
     // 16-byte row loads need W % 4 == 0 and a 16-byte aligned base

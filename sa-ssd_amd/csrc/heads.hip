@@ -247,15 +247,15 @@ __device__ __forceinline__ int nms_greedy_chunked(const unsigned long long *__re
         const unsigned long long dw = (r < n) ? mask[(size_t)r * ncb + cb0] : 0ull;
         const unsigned dlo = (unsigned)dw, dhi = (unsigned)(dw >> 32);
         unsigned long long rem = __shfl(remv, cb0, 64);
-        rem = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
-              (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)rem);
+        rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rem >> 32)) << 32) |
+              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem);
         const int rows = min(64, n - cb0 * 64);
         unsigned long long kept = 0ull;
         for (int i = 0; i < rows; ++i) {
             if (!((rem >> i) & 1ull)) {
                 kept |= 1ull << i;
-                rem |= ((unsigned long long)__builtin_amdgcn_readlane(dhi, i) << 32) |
-                       (unsigned long long)__builtin_amdgcn_readlane(dlo, i);
+                rem |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                       (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, i);
             }
         }
         // record kept rows in order

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
     const int bufs = WS + PSpad;                      // floats per LDS buffer (1 KiB aligned)
     constexpr bool DMA = (VEC == 4);
 
+    const float *xb = P.x + (size_t)b * P.Cin * P.HW;
     int laddr[NSEG];
 #pragma unroll
     for (int j = 0; j < NSEG; ++j) {
@@ -126,7 +127,6 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    const float *xb = P.x + (size_t)b * P.Cin * P.HW;
     const int nchunk = (P.Cin + KC - 1) / KC;
     const int ct = KSPLIT ? 0 : wave;
     const int aoff = (lane >> 5) * BMC + ct * 32 + (lane & 31);
@@ -134,31 +134,47 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
 
     // ================= staging descriptors ==========================================================
     // DMA path: wave-load j covers LDS float4 slots [64j, 64j+64); lane l owns slot 64j + l.
-    int wsrc[C::NWJ];            // global float offset of this lane's weight float4 (or -2: no such load)
-    int psrc[C::MAXPJ];          // global float offset inside the channel chunk, -1: zero page, -2: no such load
+    // Branch-free issue: every lane of every wave-load is always active.  Each lane keeps a 64-bit source pointer per
+    // wave-load that is advanced by a per-lane increment each chunk (0 for lanes fed from the zero page); wave-loads
+    // that do not exist for this wave (tail) read the zero page into a 1 KiB dummy LDS slot.
+    const float *wptr[C::NWJ];
+    const float *pptr[C::MAXPJ];
+    unsigned pdata = 0;          // bit i: this lane's patch piece i is real data (pointer advances per chunk)
+    int wdst[C::NWJ], pdst[C::MAXPJ];      // wave-uniform LDS float offsets inside a buffer (or the dummy slot)
+    int winc[C::NWJ];
     // register path (VEC == 1)
     int goff[MAXLP], loff[MAXLP];
     float preg[MAXLP];
     float4 wreg[NLW];
     int woff_g[NLW], woff_l[NLW];
+    const int dummy = 2 * bufs;                     // float offset of the dummy LDS slot
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     if constexpr (DMA) {
 #pragma unroll
         for (int i = 0; i < C::NWJ; ++i) {
-            const int q = 64 * (wave + 4 * i) + lane;
+            const int t = wave_s + 4 * i;
+            const int q = 64 * t + lane;
             constexpr int V = BMC / 4;
             const int row = q / V, c4 = q - row * V;
-            wsrc[i] = (q * 4 < WS) ? row * P.CoutPad + cg * BMC + c4 * 4 : -2;
+            const bool ok = t * 256 < WS;
+            wptr[i] = ok ? P.wp + (size_t)row * P.CoutPad + cg * BMC + c4 * 4 : g_zero_page;
+            wdst[i] = ok ? t * 256 : -1;
+            winc[i] = ok ? TAPS * KC * P.CoutPad : 0;
         }
 #pragma unroll
         for (int i = 0; i < C::MAXPJ; ++i) {
-            const int e = (64 * (wave + 4 * i) + lane) * 4;
-            psrc[i] = -2;
+            const int t = wave_s + 4 * i;
+            const int e = (64 * t + lane) * 4;
+            pptr[i] = g_zero_page;
+            pdst[i] = (t * 256 < PSpad) ? WS + t * 256 : -1;
             if (e < PS) {
                 const int kc = e / chs, rem = e - kc * chs;
                 const int pr = rem / PW, col = rem - pr * PW;
                 const int yy = y_first - HALO + pr;
-                psrc[i] = (pr < nprows && yy >= 0 && yy < P.H && col >= 4 && col < 4 + P.W)
-                              ? (kc * P.H + yy) * P.W + col - 4 : -1;
+                if (pr < nprows && yy >= 0 && yy < P.H && col >= 4 && col < 4 + P.W) {
+                    pptr[i] = xb + (size_t)(kc * P.H + yy) * P.W + col - 4;
+                    pdata |= 1u << i;
+                }
             }
         }
     } else {
@@ -200,17 +216,28 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
         }
         return o;
     };
-    // one weight wave-load + one (or two) patch wave-loads; part in [0, NPARTS)
+    // one weight wave-load + one patch wave-load; part in [0, NPARTS).  Chunks are issued strictly in order
+    // (0, 1, 2, ...), each part exactly once per chunk, so "advance then load" keeps the pointers in step.
     constexpr int NPARTS = (C::NWJ > C::MAXPJ) ? C::NWJ : C::MAXPJ;
+    const int pinc = KC * P.HW;
     auto dma_part = [&](int ch, float *buf, int part) {
-        if (part < C::NWJ && wsrc[part] > -2) {
-            const float *wsrc_base = P.wp + (size_t)ch * TAPS * KC * P.CoutPad;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc_base + wsrc[part]),
-                                             (lds_ptr_t)(buf + 256 * (wave + 4 * part)), 16, 0, 0);
+        if (part < C::NWJ) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)wptr[part],
+                                             (lds_ptr_t)(wdst[part] >= 0 ? buf + wdst[part] : smem + dummy), 16, 0, 0);
+            wptr[part] += winc[part];
         }
-        if (part < C::MAXPJ && psrc[part] > -2) {
-            const float *src = (psrc[part] >= 0) ? xb + clamp_off(ch, psrc[part]) : g_zero_page;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + WS + 256 * (wave + 4 * part)), 16, 0, 0);
+        if (part < C::MAXPJ) {
+            const float *src = pptr[part];
+            if (ragged && ch + 1 == nchunk) {          // uniform, last partial chunk only: clamp channels >= Cin
+                if ((pdata >> part) & 1u) {
+                    const int e = (64 * (wave_s + 4 * part) + lane) * 4;
+                    const int over = max(ch * KC + e / chs - (P.Cin - 1), 0);
+                    src -= (size_t)over * P.HW;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(pdst[part] >= 0 ? buf + pdst[part] : smem + dummy),
+                                             16, 0, 0);
+            pptr[part] += ((pdata >> part) & 1u) ? pinc : 0;
         }
     };
     auto dma = [&](int ch, float *buf) {
@@ -281,13 +308,20 @@ __global__ void __launch_bounds__(256) conv2d_kernel(ConvParams P)
                     for (int part = tap; part < NPARTS; part += kDmaTaps) dma_part(ch + 1, nbuf, part);
                 }
             }
-            if (tap + 1 < TAPS) read_ops(tap + 1, a_nxt, b_nxt);
             __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < TAPS) read_ops(tap + 1, a_nxt, b_nxt);
 #pragma unroll
             for (int t = 0; t < NSTEP; ++t)
 #pragma unroll
                 for (int j = 0; j < NSEG; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur[t][j], acc[j], 0, 0, 0);
+            // interleave: one MFMA, then (at most) two LDS reads of the next tap, so the matrix pipe never drains
+            // while the operand batch is being issued
+#pragma unroll
+            for (int i = 0; i < NSTEP * NSEG; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // <= 2 DS reads
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (tap + 1 < TAPS) {
 #pragma unroll
@@ -366,7 +400,7 @@ int launch_conv(ConvParams P, hipStream_t stream)
     const size_t ps = ((size_t)C::KC * P.NPR * P.PW + 255) / 256 * 256;
     const size_t stage = 2 * ((size_t)C::WS + ps) * sizeof(float);
     const size_t red = C::KSPLIT ? (size_t)4 * C::NSEG * 16 * 64 * sizeof(float) : 0;
-    const size_t lds = stage > red ? stage : red;
+    const size_t lds = (stage > red ? stage : red) + 1024;      // + 1 KiB dummy DMA slot
     if (lds > 160 * 1024) return SASSD_EINVAL;
     if (VEC == 4 ? (ps > (size_t)C::MAXPJ * 4 * 256) : ((size_t)C::KC * P.NPR * P.W > (size_t)256 * C::MAXLP))
         return SASSD_EINVAL;

@@ -54,7 +54,7 @@ class InferencePlan:
                  point_cloud_range=(0, -40., -3., 70.4, 40., 1.), max_num_points=5, max_voxels=20000,
                  sparse_shape=(40, 1600, 1408), anchors=None, anchors_bv=None, anchor_area_threshold=1,
                  anchors_per_loc=2, grid_offsets=(0., 40.), featmap_stride=0.4, rpn_thr=0.1, score_thr=0.3,
-                 iou_thr=0.1, cap_k=2048, cap_d=512, device=None, level_cap_factor=2):
+                 iou_thr=0.1, cap_k=2048, cap_d=512, device=None, level_cap_factor=2, overlap=True):
         dev = torch.device(device if device is not None else "cuda:0")
         self.dev, self.B, self.ncls, self.A = dev, int(batch_size), int(num_class), int(anchors_per_loc)
         self.voxel_size = np.asarray(voxel_size, np.float32)
@@ -147,6 +147,11 @@ class InferencePlan:
         self.det = dict(boxes=z(B, self.capD, 7), scores=z(B, self.capD), labels=z(B, self.capD, dt=i32),
                         counts=z(B, dt=i32))
         self.middle = {}
+        # coordinate-only work (rulebooks, anchors_mask) runs on a side stream, overlapping the feature path
+        self.overlap = bool(overlap)
+        self.side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.rb_ev = {k: torch.cuda.Event() for k in self.nbr}
+        self.mask_ev = torch.cuda.Event()
         self.prof = None           # set to {} to collect (name, start_event, end_event) tuples per frame
 
     def _ev(self):
@@ -187,28 +192,45 @@ class InferencePlan:
         bc = torch.bincount(coors4[:, 0].long(), minlength=self.B).cumsum(0).int()
         self.row_off[1:].copy_(bc)
 
-    def backbone(self, keep_middle=False):
+    def rulebooks(self):
+        """All 7 rulebooks + 3 next-level hash tables.  They depend only on voxel COORDINATES, so they are issued on
+        a side HIP stream and overlap the feature path; `self.rb_ev[key]` fires when a rulebook is ready."""
         B = self.B
+        self.tables[0].build(self.idx[0], self.n[0], self.shapes[0], B, self.status)
+        for lvl in range(4):
+            K.rulebook_subm(self.idx[lvl], self.n[lvl], self.caps[lvl], self.shapes[lvl], B, self.tables[lvl],
+                            self.nbr["subm%d" % lvl])
+            self.rb_ev["subm%d" % lvl].record()
+            if lvl < 3:
+                K.rulebook_conv(self.idx[lvl], self.n[lvl], self.caps[lvl], self.shapes[lvl], B, self.tables[lvl],
+                                self.caps[lvl + 1], self.idx[lvl + 1], self.n[lvl + 1], self.nbr["down%d" % lvl],
+                                self.status)
+                self.rb_ev["down%d" % lvl].record()
+                self.tables[lvl + 1].build(self.idx[lvl + 1], self.n[lvl + 1], self.shapes[lvl + 1], B, self.status)
+
+    def backbone(self, keep_middle=False, anchors_mask=None):
+        main = torch.cuda.current_stream(self.dev)
         e0 = self._ev() if self.prof is not None else None
+        if self.overlap:
+            self.side.wait_stream(main)                 # voxel coordinates are ready
+            with torch.cuda.stream(self.side):
+                self.rulebooks()
+                self.anchor_masks(anchors_mask)         # also coordinate-only work
+                self.mask_ev.record()
+        else:
+            self.rulebooks()
         x = self.mean
         lvl = 0
-        self.tables[0].build(self.idx[0], self.n[0], self.shapes[0], B, self.status)
-        built = set()
         cur = 0
         for li, (kind, cin, cout, key, wp, scale, shift) in enumerate(self.sp):
             y = self.feat[cur]
+            if key is not None and self.overlap:
+                main.wait_event(self.rb_ev[key])
             if kind == "subm":
-                if key not in built:
-                    K.rulebook_subm(self.idx[lvl], self.n[lvl], self.caps[lvl], self.shapes[lvl], B, self.tables[lvl],
-                                    self.nbr[key])
-                    built.add(key)
                 K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y)
             elif kind == "down":
-                K.rulebook_conv(self.idx[lvl], self.n[lvl], self.caps[lvl], self.shapes[lvl], B, self.tables[lvl],
-                                self.caps[lvl + 1], self.idx[lvl + 1], self.n[lvl + 1], self.nbr[key], self.status)
                 lvl += 1
                 K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y)
-                self.tables[lvl].build(self.idx[lvl], self.n[lvl], self.shapes[lvl], B, self.status)
             else:
                 K.spconv_fwd(x, None, self.n[lvl], self.caps[lvl], wp, 1, cin, cout, scale, shift, True, y)
             if keep_middle:
@@ -218,7 +240,7 @@ class InferencePlan:
         self.sp_out = x
         self._seg("sparse", e0)
         e1 = self._ev() if self.prof is not None else None
-        K.densify(x, self.idx[3], self.n[3], self.caps[3], self.shapes[3], B, 1, self.dense)
+        K.densify(x, self.idx[3], self.n[3], self.caps[3], self.shapes[3], B := self.B, 1, self.dense)
         self._seg("densify", e1)
 
     def bev_and_heads(self):
@@ -289,22 +311,25 @@ class InferencePlan:
         return dict(n=n, pairs=pairs, bytes_gs=bgs, bytes_min=bmin, flops=flops, rulebook_bytes=rb)
 
     # ------------------------------------------------------------------------------------------------
-    def run_from_points(self, clouds, anchors_mask=None):
-        """One frame batch, raw device point clouds in -> device detection buffers out (no host sync)."""
-        self.voxelize(clouds)
-        self.backbone()
+    def _tail(self, anchors_mask):
         self.bev_and_heads()
-        self.anchor_masks(anchors_mask)
+        if self.overlap:
+            torch.cuda.current_stream(self.dev).wait_event(self.mask_ev)
+        else:
+            self.anchor_masks(anchors_mask)
         self.post()
         return self.det
 
+    def run_from_points(self, clouds, anchors_mask=None):
+        """One frame batch, raw device point clouds in -> device detection buffers out (no host sync)."""
+        self.voxelize(clouds)
+        self.backbone(anchors_mask=anchors_mask)
+        return self._tail(anchors_mask)
+
     def run_from_voxels(self, voxel_feats, coors4, anchors_mask=None):
         self.load_voxels(voxel_feats, coors4)
-        self.backbone()
-        self.bev_and_heads()
-        self.anchor_masks(anchors_mask)
-        self.post()
-        return self.det
+        self.backbone(anchors_mask=anchors_mask)
+        return self._tail(anchors_mask)
 
     def results(self):
         """The only host sync of a frame: D2H of the (small) detection buffers, like

@@ -62,54 +62,61 @@ int g_spconv_dbg = 0;           // reserved debug switch (tools/ablate_spconv.py
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
-// Register-stationary sparse conv: one wave = 16 output rows x ALL Cout channels x all K offsets.
-//   accumulators  NT x f32x4 (x2 chains) per lane in registers for the whole layer: no LDS accumulation, no
-//                 atomics, deterministic summation order k = 0..K-1
-//   rulebook      the lane's row record nbr[row][0..26] is loaded once into 27 registers (coalesced 108-B records)
+// Register-stationary sparse conv.  One wave = 16 output rows x ALL Cout channels x every S-th kernel offset;
+// the S waves of a row group split the 27 offsets (k = j*S + s) and add their partial sums through LDS at the end.
+//   accumulators  NT x f32x4 (x2 chains) per lane in registers: no LDS accumulation, no atomics, deterministic
+//                 summation order (within a wave k ascending, then wave 0 + wave 1 + wave 2)
+//   rulebook      the lane's row record entries nbr[row][j*S + s] are loaded once into registers
 //   A operand     rows gathered straight from HBM/L2 in MFMA fragment order (lane (m,q) reads Cin/4 contiguous
 //                 floats of row nbr[m][k]; missing neighbours contribute zeros), each row read ONCE per offset,
-//                 prefetched one offset ahead under the previous offset's MFMAs
-//   B operand     W[k] (all Cout) is shared by the 4 waves of the workgroup: direct global->LDS DMA of the
-//                 pre-packed fragment image (lane-linear, conflict-free 16-B reads), double buffered, one barrier
-//                 per offset.  This keeps the CU's vector-memory pipe (64 B/clk) -- not the MFMA pipe -- from
-//                 being the bottleneck: per offset a workgroup moves 16 KB of A + 16 KB of B instead of 128 KB.
+//                 prefetched one iteration ahead under the previous iteration's MFMAs
+//   B operand     W[k] (all Cout) of the S offsets of an iteration is shared by the workgroup's 4 row groups:
+//                 direct global->LDS DMA of the pre-packed fragment image (lane-linear, conflict-free 16-B reads),
+//                 double buffered, one barrier per iteration.
+//   why S = 3     at ~14 k rows a layer is bound by the serial chain "gather latency x 27 offsets" of a wave, not by
+//                 the MFMA or memory pipes; splitting the offsets over 3 waves cuts the chain to 9 iterations and
+//                 puts 2.4 waves on every SIMD.
 //   offsets with no neighbour in the wave's 16 rows skip their MFMAs (wave-uniform ballot)
+constexpr int kSplit = 3;                     // waves per row group
+constexpr int kIter = (kK + kSplit - 1) / kSplit;
+
 template <int CIN, int COUT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(4 * kSplit * 64)
 spconv_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_ptr,
                   int cap, const float *__restrict__ wp, int K, const float *__restrict__ scale,
                   const float *__restrict__ shift, int relu, float *__restrict__ y, int dbg)
 {
-    using S = SpShape<CIN, COUT>;
-    constexpr int KS = S::KS, NT = S::NT;
+    constexpr int S = kSplit, NW = 4 * S;
+    constexpr int KS = CIN / 4, NT = COUT / 16;
     constexpr bool BLDS = (KS >= 4);                // B through LDS-DMA (16-B pieces); KS == 1: plain loads
     constexpr int J = BLDS ? KS / 4 : 1;            // float4 pieces per lane per channel tile
     constexpr int NWL = NT * J;                     // B wave-loads per offset
-    constexpr int BBUF = NWL * 256;                 // floats per B buffer
-    __shared__ __attribute__((aligned(16))) float bs[2 * BBUF];
+    constexpr int BOFF = NWL * 256;                 // floats per offset image
+    constexpr int BBUF = S * BOFF;                  // floats per iteration buffer
+    constexpr int RED = 4 * (S - 1) * 64 * NT * 4;  // floats for the final partial-sum exchange
+    constexpr int LDSF = (2 * BBUF > RED) ? 2 * BBUF : RED;
+    __shared__ __attribute__((aligned(16))) float bs[LDSF];
 
     const int n = min(*n_ptr, cap);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x * 64 >= n) return;          // workgroup-uniform
-    const int rb = (blockIdx.x * 4 + wave) * 16;
+    const int rg = wave / S, sp = wave - rg * S;
+    const int rb = (blockIdx.x * 4 + rg) * 16;
     const int q = lane >> 4, m16 = lane & 15;
     const int row = rb + m16;
     const bool rok = row < n;
+    const int KK = nbr ? kK : 1;                    // identity rulebook: a single offset
 
-    // ---- rulebook record of this lane's row -> registers -----------------------------------------
-    int nb[kK];
-    unsigned act = 0;                               // bit k: some row of this wave has a neighbour at offset k
-    if (nbr) {
+    // ---- this wave's rulebook entries -> registers -------------------------------------------------
+    int nb[kIter];
+    unsigned act = 0;                               // bit j: some row of this wave has a neighbour at offset j*S+sp
 #pragma unroll
-        for (int k = 0; k < kK; ++k) {
-            nb[k] = rok ? nbr[(size_t)row * kK + k] : -1;
-            act |= (__ballot(nb[k] >= 0) != 0ull) ? (1u << k) : 0u;
-        }
-    } else {
-        nb[0] = rok ? row : -1;
-        act = (__ballot(nb[0] >= 0) != 0ull) ? 1u : 0u;
-#pragma unroll
-        for (int k = 1; k < kK; ++k) nb[k] = -1;
+    for (int j = 0; j < kIter; ++j) {
+        const int k = j * S + sp;
+        nb[j] = -1;
+        if (k < KK && rok) nb[j] = nbr ? nbr[(size_t)row * kK + k] : row;
+        act |= (__ballot(nb[j] >= 0) != 0ull) ? (1u << j) : 0u;
     }
 
     float a0[KS], a1[KS];
@@ -117,35 +124,40 @@ spconv_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, 
 #pragma unroll
     for (int t = 0; t < NT; ++t) { d0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; d1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    auto fetch_a = [&](int k, float (&af)[KS]) {
-        if (nb[k] >= 0) load_vec<KS>(x + (size_t)nb[k] * CIN + q * KS, af);
+    auto fetch_a = [&](int j, float (&af)[KS]) {
+        if (nb[j] >= 0) load_vec<KS>(x + (size_t)nb[j] * CIN + q * KS, af);
         else {
 #pragma unroll
             for (int i = 0; i < KS; ++i) af[i] = 0.f;
         }
     };
-    auto dma_b = [&](int k, float *buf) {
+    auto dma_b = [&](int j, float *buf) {           // the S offset images of iteration j
         if constexpr (BLDS) {
 #pragma unroll
-            for (int i = 0; i < (NWL + 3) / 4; ++i) {
-                const int t = wave + 4 * i;                              // wave-load id: (nt, j)
-                if (t < NWL) {
-                    const int tnt = t / J, j = t - tnt * J;
-                    const float *src = wp + (((size_t)k * NT + tnt) * 64 + lane) * KS + 4 * j;
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + t * 256), 16, 0, 0);
+            for (int i = 0; i < (S * NWL + NW - 1) / NW; ++i) {
+                const int t = wave + NW * i;                             // wave-load id: (offset slot, nt, piece)
+                if (t < S * NWL) {
+                    const int so = t / NWL, r = t - so * NWL;
+                    const int tnt = r / J, jj = r - tnt * J;
+                    const int k = j * S + so;
+                    if (k < KK) {
+                        const float *src = wp + (((size_t)k * NT + tnt) * 64 + lane) * KS + 4 * jj;
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + t * 256), 16, 0, 0);
+                    }
                 }
             }
         }
     };
-    auto mma = [&](int k, const float (&af)[KS], const float *buf) {
+    auto mma = [&](int j, const float (&af)[KS], const float *buf) {
+        const int k = j * S + sp;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float bf[KS];
             if constexpr (BLDS) {
 #pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const float4 v = *(const float4 *)(buf + ((t * J + j) * 64 + lane) * 4);
-                    bf[4 * j] = v.x; bf[4 * j + 1] = v.y; bf[4 * j + 2] = v.z; bf[4 * j + 3] = v.w;
+                for (int jj = 0; jj < J; ++jj) {
+                    const float4 v = *(const float4 *)(buf + sp * BOFF + ((t * J + jj) * 64 + lane) * 4);
+                    bf[4 * jj] = v.x; bf[4 * jj + 1] = v.y; bf[4 * jj + 2] = v.z; bf[4 * jj + 3] = v.w;
                 }
             } else {
                 load_vec<KS>(wp + (((size_t)k * NT + t) * 64 + lane) * KS, bf);
@@ -158,37 +170,54 @@ spconv_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, 
         }
     };
 
-    const int KK = nbr ? kK : 1;                    // identity rulebook: a single offset
+    const int niter = (KK + S - 1) / S;
     dma_b(0, bs);
     if (act & 1u) fetch_a(0, a0);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kK; k += 2) {
-        if (k < KK) {
-            // even offset k: operands in (a0, bs[0]); odd offset k+1: (a1, bs[BBUF])
-            if (k + 1 < KK) { dma_b(k + 1, bs + BBUF); if ((act >> (k + 1)) & 1u) fetch_a(k + 1, a1); }
-            if ((act >> k) & 1u) mma(k, a0, bs);
+    for (int j = 0; j < kIter; j += 2) {
+        if (j < niter) {
+            // even iteration j: operands in (a0, bs[0]); odd iteration j+1: (a1, bs[BBUF])
+            if (j + 1 < niter) { dma_b(j + 1, bs + BBUF); if ((act >> (j + 1)) & 1u) fetch_a(j + 1, a1); }
+            if ((act >> j) & 1u) mma(j, a0, bs);
             __syncthreads();
         }
-        if (k + 1 < kK && k + 1 < KK) {
-            if (k + 2 < KK) { dma_b(k + 2, bs); if ((act >> (k + 2)) & 1u) fetch_a(k + 2, a0); }
-            if ((act >> (k + 1)) & 1u) mma(k + 1, a1, bs + BBUF);
+        if (j + 1 < kIter && j + 1 < niter) {
+            if (j + 2 < niter) { dma_b(j + 2, bs); if ((act >> (j + 2)) & 1u) fetch_a(j + 2, a0); }
+            if ((act >> (j + 1)) & 1u) mma(j + 1, a1, bs + BBUF);
             __syncthreads();
         }
     }
 
-    // ---- epilogue: D[row = q*4 + reg][col = m16] ---------------------------------------------------
+    // ---- combine the S partial sums of a row group (fixed order), then the epilogue ------------------
+    if (sp > 0) {
+        float *dst = bs + (((rg * (S - 1) + (sp - 1)) * 64 + lane) * NT) * 4;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = t * 16 + m16;
-        const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 v = d0[t] + d1[t];
+            *(float4 *)(dst + t * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    if (sp == 0) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = rb + q * 4 + reg;
-            if (r < n) {
-                float v = (d0[t][reg] + d1[t][reg]) * sc + sh;
-                if (relu) v = fmaxf(v, 0.f);
-                y[(size_t)r * COUT + co] = v;
+        for (int t = 0; t < NT; ++t) {
+            f32x4 v = d0[t] + d1[t];
+#pragma unroll
+            for (int o = 0; o < S - 1; ++o) {
+                const float4 p = *(const float4 *)(bs + (((rg * (S - 1) + o) * 64 + lane) * NT + t) * 4);
+                v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+            }
+            const int co = t * 16 + m16;
+            const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = rb + q * 4 + reg;         // D[row = q*4 + reg][col = m16]
+                if (r < n) {
+                    float o2 = v[reg] * sc + sh;
+                    if (relu) o2 = fmaxf(o2, 0.f);
+                    y[(size_t)r * COUT + co] = o2;
+                }
             }
         }
     }
@@ -200,7 +229,7 @@ int launch_fwd(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap
                const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
 {
     using S = SpShape<CIN, COUT>;
-    hipLaunchKernelGGL((spconv_fwd_kernel<CIN, COUT>), dim3(cdiv(cap, 64)), dim3(256), 0, stream, x, nbr,
+    hipLaunchKernelGGL((spconv_fwd_kernel<CIN, COUT>), dim3(cdiv(cap, 64)), dim3(4 * kSplit * 64), 0, stream, x, nbr,
                        n_ptr, cap, wp, K, scale, shift, relu, y, g_spconv_dbg);
     return sassd_launch_status();
 }

@@ -49,7 +49,7 @@ def build_model(seed=0):
     bv = A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]]).astype(np.float32)
     cal = dict(voxel_size=synth.KITTI_VOXEL, pc_range=synth.KITTI_RANGE, max_points=5, max_voxels=20000,
                sparse_shape=(40, 1600, 1408), grid_xyz=(1408, 1600, 40))
-    H.calibrate_cls_head(model, synth.lidar64(11)[:3000], bv, cal)
+    H.calibrate_cls_head(model, synth.lidar64(11)[:3000], bv, cal, target_count=100)   # ~4-5e2 guided anchors on K21
     return model, an, bv, cal
 
 

@@ -54,7 +54,7 @@ class InferencePlan:
                  point_cloud_range=(0, -40., -3., 70.4, 40., 1.), max_num_points=5, max_voxels=20000,
                  sparse_shape=(40, 1600, 1408), anchors=None, anchors_bv=None, anchor_area_threshold=1,
                  anchors_per_loc=2, grid_offsets=(0., 40.), featmap_stride=0.4, rpn_thr=0.1, score_thr=0.3,
-                 iou_thr=0.1, cap_k=2048, cap_d=512, device=None, level_cap_factor=2, overlap=True):
+                 iou_thr=0.1, cap_k=4096, cap_d=512, device=None, level_cap_factor=2, overlap=True):
         dev = torch.device(device if device is not None else "cuda:0")
         self.dev, self.B, self.ncls, self.A = dev, int(batch_size), int(num_class), int(anchors_per_loc)
         self.voxel_size = np.asarray(voxel_size, np.float32)

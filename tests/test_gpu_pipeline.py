@@ -175,3 +175,45 @@ def test_multi_class_batch(dev):
         assert np.array_equal(res[b][2], d[2])
         got_any = True
     assert got_any
+
+
+WAYMO = dict(voxel_size=synth.WAYMO_VOXEL, pc_range=synth.WAYMO_RANGE, max_points=5, max_voxels=150000,
+             sparse_shape=(40, 1504, 1504), grid_xyz=(1504, 1504, 40))
+
+
+def test_waymo_scale_frame(dev):
+    """configs[4] shape on one GPU, inference side: 180k points, 0.1 x 0.1 x 0.15 m voxels (grid 40x1504x1504,
+    ~79k active voxels, BEV 188x188).  Stresses the hash tables / bitmaps at 5x the KITTI row counts."""
+    c = Config.fromfile("configs/car_cfg.py")
+    mcfg = dict(c.model)
+    mcfg["neck"] = dict(mcfg["neck"], output_shape=[40, 1504, 1504])
+    mcfg["extra_head"] = dict(mcfg["extra_head"], grid_offsets=(75.2, 75.2), featmap_stride=0.8)
+    model = H.randomize_detector(build_detector(mcfg, c.train_cfg, c.test_cfg).eval(), 7)
+    an = A.AnchorGeneratorStride(sizes=[1.6, 3.9, 1.56], anchor_strides=[.8, .8, 1.], anchor_offsets=[-74.8, -74.8, -1.0],
+                                 rotations=[0, 1.57])([1, 188, 188]).reshape(-1, 7)
+    bv = A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]]).astype(np.float32)
+    pts = synth.waymo_synth(0)[:180000]
+    H.calibrate_cls_head(model, pts, bv, WAYMO, target_count=600)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref = H.oracle_forward(sd, [pts], an, bv, dict(WAYMO, score_thr=0.3))
+    plan = InferencePlan(sd, batch_size=1, anchors=an, anchors_bv=bv, device=dev, voxel_size=WAYMO["voxel_size"],
+                         point_cloud_range=WAYMO["pc_range"], max_voxels=150000, sparse_shape=WAYMO["sparse_shape"],
+                         grid_offsets=(75.2, 75.2), featmap_stride=0.8, cap_k=8192, cap_d=2048)
+    plan.run_from_points([torch.from_numpy(pts).to(dev)])
+    torch.cuda.synchronize()
+    assert int(plan.status.item()) == 0
+    n0, n3 = int(plan.n[0].item()), int(plan.n[3].item())
+    assert n0 == 79302 == len(ref["coors"])
+    assert np.array_equal(plan.idx[0][:n0].cpu().numpy(), ref["coors"])
+    assert np.array_equal(plan.mean[:n0].cpu().numpy(), ref["feats"])
+    assert n3 == len(ref["idx3"]) and np.array_equal(plan.idx[3][:n3].cpu().numpy(), ref["idx3"])
+    e = (plan.sp_out[:n3].cpu() - ref["x3"]).abs().max().item()
+    assert e < 1e-4 * max(1.0, ref["x3"].abs().max().item()), e
+    e = (plan.x.cpu() - ref["x"]).abs().max().item()
+    assert e < 2e-4 * max(1.0, ref["x"].abs().max().item()), e
+    assert np.array_equal(plan.mask.cpu().numpy().astype(bool), ref["masks"])
+    gb, gl, gs = ref["guided"][0]
+    if not (np.abs(gs.numpy() - 0.1) < 1e-5).any():
+        k = int(plan.df["counts"][0].item())
+        assert k == len(gb)
+        assert np.abs(plan.df["guided"][0, :k].cpu().numpy() - gb.numpy()).max() < 1e-4

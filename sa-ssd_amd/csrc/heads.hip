@@ -164,7 +164,11 @@ __global__ void __launch_bounds__(256) pswarp_kernel(WarpParams P)
         const float u = (x + P.offx) * P.scale, v = (y + P.offy) * P.scale;
         // normalise exactly like bilinear_interpolate_torch_gridsample, then grid_sample(align_corners=True)
         const float gx = u / (float)(P.W - 1) * 2.f - 1.f, gy = v / (float)(P.H - 1) * 2.f - 1.f;
-        const float fx = (gx + 1.f) / 2.f * (float)(P.W - 1), fy = (gy + 1.f) / 2.f * (float)(P.H - 1);
+        float fx = (gx + 1.f) / 2.f * (float)(P.W - 1), fy = (gy + 1.f) / 2.f * (float)(P.H - 1);
+        // keep the float -> int conversion and the +1 in range (int overflow is UB and hipcc exploits it in the
+        // bounds tests); samples outside [-1, size] contribute zero either way (zero padding), NaN -> outside
+        fx = fminf(fmaxf(fx, -2.f), (float)P.W + 1.f);
+        fy = fminf(fmaxf(fy, -2.f), (float)P.H + 1.f);
         const float x0f = floorf(fx), y0f = floorf(fy);
         const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
         const float wx1 = fx - x0f, wx0 = (x0f + 1.f) - fx, wy1 = fy - y0f, wy0 = (y0f + 1.f) - fy;

@@ -202,3 +202,18 @@ def test_iou_matrices_and_nms(dev):
             # only IoU values within 1e-5 of the threshold may legitimately differ
             iou_m = clib.boxes_iou_bev(boxes, boxes)
             assert np.any(np.abs(iou_m - 0.1) < 1e-5), (n, got, keep_ref)
+
+
+def test_pswarp_extreme_boxes_do_not_fault(dev):
+    """Random-weight heads decode boxes with lengths up to 1e18 m: samples far outside the map must read as zero
+    padding (grid_sample semantics), not fault (regression: signed-overflow UB in the bounds test)."""
+    feat = torch.randn(1, 28, 200, 176, device=dev)
+    for big in (1e2, 1e10, 1e18, 3e38, float("inf"), float("nan")):
+        g = torch.zeros(1, 64, 7, device=dev)
+        g[0, :, 0] = torch.linspace(-10, 80, 64); g[0, :, 1] = torch.linspace(-50, 50, 64)
+        g[0, :, 3] = 1.6; g[0, :, 4] = big; g[0, :, 5] = 1.5; g[0, :, 6] = torch.linspace(-3, 50, 64)
+        cnt = torch.tensor([64], dtype=torch.int32, device=dev)
+        lg = K.pswarp_sample(feat, g, cnt, 64, (0., 40.), 2.5)
+        torch.cuda.synchronize()
+        if big > 1e6:
+            assert torch.isfinite(lg[0, :64]).all() or big != big

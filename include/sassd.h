@@ -178,6 +178,27 @@ size_t sassd_nms_workspace_bytes(int n);
 int sassd_nms_gpu(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep,
                   void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (a16, a17) training-side point operators of the auxiliary network.
+ * pointnet2_cuda (mmdet/ops/pointnet2/src/interpolate.cpp:13,25,40; kernels interpolate_gpu.cu:9-146):
+ *   three_nn            unknown [N,4] (b,x,y,z), known [M,4] -> dist2 [N,3] f32 (squared), idx [N,3] i32: the three
+ *                       nearest known points of the same batch index, first index wins ties
+ *   three_interpolate   points [M,C], idx, weight [N,3] -> out [N,C]
+ *   three_interpolate_grad  grad_out [N,C] -> ACCUMULATES into grad_points [M,C] (caller zeroes it; float atomics,
+ *                       like the reference interpolate_gpu.cu:143-145)
+ * points_op_cpu (mmdet/ops/points_op/src/points_op.cpp:107-144):
+ *   pts_in_boxes3d      pts [N,3], boxes3d [M,7] -> pts_flag [M,N] i32 (fully written), reg_target [N,3] f32
+ *                       (only rows of points inside a box are written: caller zeroes, as points_op/__init__.py:8-9)
+ * ---------------------------------------------------------------------------------------------- */
+int sassd_three_nn(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
+                   void *stream);
+int sassd_three_interpolate(int c, int m, int n, const float *points, const int32_t *idx, const float *weight,
+                            float *out, void *stream);
+int sassd_three_interpolate_grad(int c, int n, int m, const float *grad_out, const int32_t *idx,
+                                 const float *weight, float *grad_points, void *stream);
+int sassd_pts_in_boxes3d(const float *pts, int n, const float *boxes3d, int m, int32_t *pts_flag,
+                         float *reg_target, void *stream);
+
 /* Hardware self-test helper used by tests: D = A(32x2k) * B(2k x32) through v_mfma_f32_32x32x2_f32 and
  * D = A(16x4k) * B(4k x16) through v_mfma_f32_16x16x4_f32 with the lane maps the kernels assume. */
 int sassd_mfma_probe(const float *a32, const float *b32, float *d32, const float *a16, const float *b16,

@@ -100,3 +100,39 @@ def nms_rotated(boxes_sorted, thr, return_mask=False):
     mask = np.zeros((max(n, 1), max(cb, 1)), np.uint64)
     k = lib().orc_nms_rotated(_p(b), n, C.c_float(thr), _p(keep), _p(mask))
     return (keep[:k], mask[:n, :cb]) if return_mask else keep[:k]
+
+
+def three_nn(unknown, known):
+    u = np.ascontiguousarray(unknown, np.float32)
+    k = np.ascontiguousarray(known, np.float32)
+    d = np.empty((len(u), 3), np.float32)
+    i = np.empty((len(u), 3), np.int32)
+    lib().orc_three_nn(len(u), len(k), _p(u), _p(k), _p(d), _p(i))
+    return d, i
+
+
+def three_interpolate(points, idx, weight):
+    pts = np.ascontiguousarray(points, np.float32)
+    idx = np.ascontiguousarray(idx, np.int32)
+    w = np.ascontiguousarray(weight, np.float32)
+    out = np.empty((len(idx), pts.shape[1]), np.float32)
+    lib().orc_three_interpolate(pts.shape[1], len(pts), len(idx), _p(pts), _p(idx), _p(w), _p(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    g = np.ascontiguousarray(grad_out, np.float32)
+    idx = np.ascontiguousarray(idx, np.int32)
+    w = np.ascontiguousarray(weight, np.float32)
+    gp = np.zeros((m, g.shape[1]), np.float32)
+    lib().orc_three_interpolate_grad(g.shape[1], len(g), m, _p(g), _p(idx), _p(w), _p(gp))
+    return gp
+
+
+def pts_in_boxes3d(pts, boxes):
+    p = np.ascontiguousarray(pts, np.float32)
+    b = np.ascontiguousarray(boxes, np.float32)
+    flag = np.zeros((len(b), len(p)), np.int32)
+    reg = np.zeros((len(p), 3), np.float32)
+    lib().orc_pts_in_boxes3d(_p(p), len(p), _p(b), len(b), _p(flag), _p(reg))
+    return flag, reg

@@ -229,3 +229,77 @@ int orc_nms_rotated(const float *boxes, int n, float thr, int64_t *keep, uint64_
     if (!mask_out) free(mask);
     return nk;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Training-side point operators.
+ * three_nn / three_interpolate (+grad): mmdet/ops/pointnet2/src/interpolate_gpu.cu:9-56, :80-102, :124-146.
+ * pts_in_boxes3d: mmdet/ops/points_op/src/points_op.cpp:92-144 (literal argument order of the call site).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_three_nn(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx)
+{
+    for (int p = 0; p < n; ++p) {
+        const float ub = unknown[p * 4], ux = unknown[p * 4 + 1], uy = unknown[p * 4 + 2], uz = unknown[p * 4 + 3];
+        double b1 = 1e40, b2 = 1e40, b3 = 1e40;
+        int i1 = 0, i2 = 0, i3 = 0;
+        for (int k = 0; k < m; ++k) {
+            if (known[k * 4] != ub) continue;
+            const float x = known[k * 4 + 1], y = known[k * 4 + 2], z = known[k * 4 + 3];
+            const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+            if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+            else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+            else if (d < b3) { b3 = d; i3 = k; }
+        }
+        dist2[p * 3] = (float)b1; dist2[p * 3 + 1] = (float)b2; dist2[p * 3 + 2] = (float)b3;
+        idx[p * 3] = i1; idx[p * 3 + 1] = i2; idx[p * 3 + 2] = i3;
+    }
+}
+
+void orc_three_interpolate(int c, int m, int n, const float *points, const int32_t *idx, const float *weight,
+                           float *out)
+{
+    (void)m;
+    for (int p = 0; p < n; ++p)
+        for (int ch = 0; ch < c; ++ch)
+            out[(size_t)p * c + ch] = weight[p * 3] * points[(size_t)idx[p * 3] * c + ch] +
+                                      weight[p * 3 + 1] * points[(size_t)idx[p * 3 + 1] * c + ch] +
+                                      weight[p * 3 + 2] * points[(size_t)idx[p * 3 + 2] * c + ch];
+}
+
+void orc_three_interpolate_grad(int c, int n, int m, const float *grad_out, const int32_t *idx, const float *weight,
+                                float *grad_points /* zeroed by the caller */)
+{
+    (void)m;
+    for (int p = 0; p < n; ++p)
+        for (int ch = 0; ch < c; ++ch)
+            for (int j = 0; j < 3; ++j)
+                grad_points[(size_t)idx[p * 3 + j] * c + ch] += grad_out[(size_t)p * c + ch] * weight[p * 3 + j];
+}
+
+static int orc_pt_in_box3d(float x, float y, float z, float cx, float cy, float bottom_z, float w, float l, float h,
+                           float angle)
+{
+    float max_dis = 10.0, x_rot, y_rot, cosa, sina, cz;
+    cz = bottom_z + h / 2.0;
+    if ((fabsf(x - cx) > max_dis) || (fabsf(z - cz) > h / 2.0) || (fabsf(y - cy) > max_dis)) return 0;
+    cosa = cosf(angle); sina = sinf(angle);
+    x_rot = (x - cx) * cosa + (y - cy) * (-sina);
+    y_rot = (x - cx) * sina + (y - cy) * cosa;
+    return (x_rot >= -w / 2.0) & (x_rot <= w / 2.0) & (y_rot >= -l / 2.0) & (y_rot <= l / 2.0);
+}
+
+void orc_pts_in_boxes3d(const float *pts, int n, const float *boxes, int m, int32_t *flag /*[m,n]*/,
+                        float *reg /*[n,3], zeroed by the caller*/)
+{
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            const float *b = boxes + i * 7;
+            const int in = orc_pt_in_box3d(pts[j * 3], pts[j * 3 + 1], pts[j * 3 + 2], b[0], b[1], b[2], b[3], b[4],
+                                           b[5], b[6]);
+            flag[(size_t)i * n + j] = in;
+            if (in == 1) {
+                reg[j * 3] = pts[j * 3] - b[0];
+                reg[j * 3 + 1] = pts[j * 3 + 1] - b[1];
+                reg[j * 3 + 2] = pts[j * 3 + 2] - (b[2] + b[3] / 2.0);
+            }
+        }
+}

@@ -316,6 +316,47 @@ def nms_gpu(boxes_sorted, thresh):
     return keep, num
 
 
+def three_nn(unknown, known):
+    """unknown [N,4], known [M,4] (b,x,y,z) -> (dist2 [N,3] squared distances, idx [N,3] int32)."""
+    _chk_cuda(unknown, known)
+    n, m = unknown.shape[0], known.shape[0]
+    d = torch.empty(n, 3, dtype=torch.float32, device=unknown.device)
+    i = torch.empty(n, 3, dtype=torch.int32, device=unknown.device)
+    _C.check(_C.lib().sassd_three_nn(n, m, _C.ptr(unknown), _C.ptr(known), _C.ptr(d), _C.ptr(i), _C.stream()),
+             "sassd_three_nn")
+    return d, i
+
+
+def three_interpolate(points, idx, weight):
+    _chk_cuda(points, idx, weight)
+    m, c = points.shape
+    n = idx.shape[0]
+    out = torch.empty(n, c, dtype=torch.float32, device=points.device)
+    _C.check(_C.lib().sassd_three_interpolate(c, m, n, _C.ptr(points), _C.ptr(idx), _C.ptr(weight), _C.ptr(out),
+                                              _C.stream()), "sassd_three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    _chk_cuda(grad_out, idx, weight)
+    n, c = grad_out.shape
+    gp = torch.zeros(m, c, dtype=torch.float32, device=grad_out.device)
+    _C.check(_C.lib().sassd_three_interpolate_grad(c, n, m, _C.ptr(grad_out), _C.ptr(idx), _C.ptr(weight), _C.ptr(gp),
+                                                   _C.stream()), "sassd_three_interpolate_grad")
+    return gp
+
+
+def pts_in_boxes3d(pts, boxes3d):
+    """pts [N,3], boxes3d [M,7] -> (pts_in_flag [M,N] int32, reg_target [N,3]) on the device."""
+    _chk_cuda(pts, boxes3d)
+    n, m = pts.shape[0], boxes3d.shape[0]
+    flag = torch.zeros(m, n, dtype=torch.int32, device=pts.device)
+    reg = torch.zeros(n, 3, dtype=torch.float32, device=pts.device)
+    _C.check(_C.lib().sassd_pts_in_boxes3d(_C.ptr(pts), n, _C.ptr(boxes3d), m, _C.ptr(flag), _C.ptr(reg),
+                                           _C.stream()), "sassd_pts_in_boxes3d")
+    return flag, reg
+
+
 def mfma_probe(a32, b32, a16, b16, ksteps):
     dev = a32.device
     d32 = torch.zeros(32, 32, dtype=torch.float32, device=dev)

@@ -35,3 +35,13 @@ def points_to_voxel(points, voxel_size, coors_range, max_points=35, reverse_inde
                                want_mean=False)
     m = int(r["voxel_num"].item())
     return (r["voxels"][:m].cpu().numpy(), r["coors"][:m].cpu().numpy(), r["num_points"][:m].cpu().numpy())
+
+
+def pts_in_boxes3d(pts, boxes3d):
+    """mmdet/ops/points_op/__init__.py:5-11 (points_op.cpp:107-144) on the device: pts (N,3), boxes3d (M,7) ->
+    (pts_in_flag [M,N] int32, reg_target [N,3]).  Inputs may be CPU or device tensors; outputs live where `pts` does."""
+    dev = pts.device
+    p = pts.contiguous().float().to(_device())
+    b = boxes3d.contiguous().float().to(_device())
+    flag, reg = K.pts_in_boxes3d(p, b)
+    return flag.to(dev), reg.to(dev)

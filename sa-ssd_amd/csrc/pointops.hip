@@ -15,6 +15,7 @@ __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float
                                                        const float *__restrict__ known, float *__restrict__ dist2,
                                                        int *__restrict__ idx)
 {
+#pragma clang fp contract(off)      // same IEEE fp32 operation sequence as the CPU oracle (squared distances bit-exact)
     __shared__ float4 tile[kNnTile];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f);

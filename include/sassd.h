@@ -106,6 +106,24 @@ int sassd_spconv_fwd(const float *x, const int32_t *nbr, const int32_t *n_out_pt
                      const float *w_packed, int K, int Cin, int Cout, const float *scale,
                      const float *shift, int relu, float *y, void *stream);
 
+/* (a15) Sparse convolution backward (training; replaces spconv `indice_conv_backward_fp32`).
+ *   sassd_rulebook_transpose   nbrT[i,k] = o  for every rulebook entry nbr[o,k] = i  (-1 elsewhere); nbrT [cap_in,27]
+ *   sassd_spconv_pack_weight_t forward weight w [K,Cin,Cout] -> packed image of W[k]^T for the data gradient
+ *   sassd_spconv_bwd_data      dx[i,:] = sum_k dy[nbrT[i,k],:] @ W[k]^T       (dx [cap_in,Cin], dy [cap_out,Cout])
+ *                              (nbrT NULL + K = 1: the 1x1x1 layer)
+ *   sassd_spconv_bwd_weight    dw[k] (+)= sum_{o: nbr[o,k]>=0} x[nbr[o,k],:]^T (x) dy[o,:]   (dw [K,Cin,Cout];
+ *                              deterministic two-stage reduction through the caller's workspace)
+ * Gradients w.r.t. the fused scale/shift/ReLU epilogue are the caller's (elementwise). */
+int sassd_rulebook_transpose(const int32_t *nbr, const int32_t *n_out_ptr, int cap_out, int32_t *nbrT,
+                             int cap_in, void *stream);
+int sassd_spconv_pack_weight_t(const float *w, int K, int Cin, int Cout, float *packed, void *stream);
+int sassd_spconv_bwd_data(const float *dy, const int32_t *nbrT, const int32_t *n_in_ptr, int cap_in,
+                          const float *wT_packed, int K, int Cin, int Cout, float *dx, void *stream);
+size_t sassd_spconv_bwd_weight_workspace_bytes(int cap_out, int K, int Cin, int Cout);
+int sassd_spconv_bwd_weight(const float *x, const float *dy, const int32_t *nbr, const int32_t *n_out_ptr,
+                            int cap_out, int K, int Cin, int Cout, float *dw, int accumulate,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 /* (a8) SparseConvTensor.dense() + view (cmn.py:112-114): out [B, C*D, H, W] f32, zero filled here.
  * channel_order 0: channel = c*D + d (reference); 1: channel = d*C + c (internal, conv0 weights permuted). */
 int sassd_densify(const float *feats, const int32_t *indices, const int32_t *n_ptr, int cap, int C,

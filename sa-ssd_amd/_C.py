@@ -48,6 +48,11 @@ _SIGS = {
     "sassd_spconv_packed_floats": (_SZ, [_I, _I, _I]),
     "sassd_spconv_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
     "sassd_spconv_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "sassd_rulebook_transpose": (_I, [_P, _P, _I, _P, _I, _P]),
+    "sassd_spconv_pack_weight_t": (_I, [_P, _I, _I, _I, _P, _P]),
+    "sassd_spconv_bwd_data": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
+    "sassd_spconv_bwd_weight_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "sassd_spconv_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _SZ, _P]),
     "sassd_densify": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sassd_conv2d_packed_floats": (_SZ, [_I, _I, _I]),
     "sassd_conv2d_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),

@@ -42,8 +42,10 @@ __device__ __forceinline__ void load_vec(const float *__restrict__ p, float (&v)
 }
 
 // w [K][CIN][COUT] -> packed [K][NT][64 lanes][KS]:  lane (q = l>>4, m = l&15) holds W[k][q*KS + kk][nt*16 + m]
+// transposed = 1: `w` is the FORWARD weight [K][COUT][CIN] of a Cout->Cin layer and the packed image is W[k]^T, i.e.
+// the weights of the data-gradient conv (CIN x COUT here are the gradient conv's own in/out widths).
 template <int CIN, int COUT>
-__global__ void pack_weight_kernel(const float *__restrict__ w, int K, float *__restrict__ packed)
+__global__ void pack_weight_kernel(const float *__restrict__ w, int K, float *__restrict__ packed, int transposed)
 {
     using S = SpShape<CIN, COUT>;
     const int total = K * S::NT * 64 * S::KS;
@@ -54,7 +56,8 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int K, float *__
     const int nt = (i / (S::KS * 64)) % S::NT;
     const int k = i / (S::KS * 64 * S::NT);
     const int q = lane >> 4, m = lane & 15;
-    packed[i] = w[((size_t)k * CIN + q * S::KS + kk) * COUT + nt * 16 + m];
+    const int ci = q * S::KS + kk, co = nt * 16 + m;
+    packed[i] = transposed ? w[((size_t)k * COUT + co) * CIN + ci] : w[((size_t)k * CIN + ci) * COUT + co];
 }
 
 int g_spconv_dbg = 0;           // reserved debug switch (tools/ablate_spconv.py); 0 in production
@@ -235,11 +238,12 @@ int launch_fwd(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap
 }
 
 template <int CIN, int COUT>
-int launch_pack(const float *w, int K, float *packed, hipStream_t stream)
+int launch_pack(const float *w, int K, float *packed, int transposed, hipStream_t stream)
 {
     using S = SpShape<CIN, COUT>;
     const int total = K * S::NT * 64 * S::KS;
-    hipLaunchKernelGGL((pack_weight_kernel<CIN, COUT>), dim3(cdiv(total, 256)), dim3(256), 0, stream, w, K, packed);
+    hipLaunchKernelGGL((pack_weight_kernel<CIN, COUT>), dim3(cdiv(total, 256)), dim3(256), 0, stream, w, K, packed,
+                       transposed);
     return sassd_launch_status();
 }
 
@@ -250,6 +254,8 @@ int launch_pack(const float *w, int K, float *packed, hipStream_t stream)
     if (Cin == 32 && Cout == 32) return FN<32, 32>(__VA_ARGS__);                 \
     if (Cin == 32 && Cout == 64) return FN<32, 64>(__VA_ARGS__);                 \
     if (Cin == 64 && Cout == 64) return FN<64, 64>(__VA_ARGS__);                 \
+    if (Cin == 32 && Cout == 16) return FN<32, 16>(__VA_ARGS__);   /* data-gradient shapes */ \
+    if (Cin == 64 && Cout == 32) return FN<64, 32>(__VA_ARGS__);                 \
     return SASSD_EINVAL;
 
 __global__ void densify_kernel(const float *__restrict__ feats, const int32_t *__restrict__ idx,
@@ -267,6 +273,151 @@ __global__ void densify_kernel(const float *__restrict__ feats, const int32_t *_
     out[(((size_t)p.x * C * D + ch) * H + p.z) * W + p.w] = feats[(size_t)row * C + c];
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward (training; replaces spconv `indice_conv_backward_fp32`):
+//   dX[i] = sum_{(i,o,k) in R} dY[o] . W[k]^T      -> the FORWARD kernel on the transposed gather table
+//                                                     nbrT[i][k] = o  and transposed-packed weights
+//   dW[k] = sum_{(i,o) in R_k} X[i]^T (x) dY[o]    -> spconv_wgrad_kernel below
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void nbr_transpose_kernel(const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_out_ptr, int cap_out,
+                                     int cap_in, int32_t *__restrict__ nbrT)
+{
+    const int n = min(*n_out_ptr, cap_out);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * kK) return;
+    const int o = t / kK, k = t - o * kK;
+    const int i = nbr[t];
+    if (i >= 0 && i < cap_in) nbrT[(size_t)i * kK + k] = o;      // each (i,k) has at most one o
+}
+
+constexpr int kWgRows = 256;       // output rows per weight-gradient workgroup
+
+// One wave = one 16x16 tile of dW[k] (ci tile x co tile) for all 27 offsets; the MFMA K dimension runs over rows:
+//   D[ci][co] += sum_rows X[nbr[row][k]][ci] * dY[row][co]      (4 rows per v_mfma_f32_16x16x4_f32)
+// Per-workgroup partial sums are written to `part` and reduced in fixed order by wgrad_reduce_kernel (deterministic).
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(((CIN + 15) / 16) * (COUT / 16) * 64)
+spconv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, const int32_t *__restrict__ nbr,
+                    const int32_t *__restrict__ n_ptr, int cap, float *__restrict__ part)
+{
+    constexpr int MT = (CIN + 15) / 16, NTT = COUT / 16;
+    __shared__ int nbr_s[kWgRows * kK];
+    const int n = min(*n_ptr, cap);
+    const int r0 = blockIdx.x * kWgRows;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cit = wave / NTT, cot = wave - cit * NTT;
+    const int q = lane >> 4, m16 = lane & 15;
+    f32x4 acc[kK];
+#pragma unroll
+    for (int k = 0; k < kK; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (r0 < n) {                                   // workgroup-uniform
+        const int rows = min(kWgRows, n - r0);
+        for (int i = tid; i < rows * kK; i += MT * NTT * 64) nbr_s[i] = nbr[(size_t)r0 * kK + i];
+        __syncthreads();
+        const int ci = cit * 16 + m16;
+        for (int s0 = 0; s0 < rows; s0 += 4) {
+            const int rl = s0 + q;
+            const bool rok = rl < rows;
+            const float b = rok ? dy[(size_t)(r0 + rl) * COUT + cot * 16 + m16] : 0.f;
+#pragma unroll
+            for (int k = 0; k < kK; ++k) {
+                const int in = rok ? nbr_s[rl * kK + k] : -1;
+                if (__ballot(in >= 0) == 0ull) continue;
+                const float a = (in >= 0 && ci < CIN) ? x[(size_t)in * CIN + ci] : 0.f;
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = q*4 + reg][col = m16] -> dW[k][ci = cit*16 + q*4 + reg][co = cot*16 + m16]
+    float *dst = part + (size_t)blockIdx.x * kK * CIN * COUT;
+#pragma unroll
+    for (int k = 0; k < kK; ++k)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int ci = cit * 16 + q * 4 + reg;
+            if (ci < CIN) dst[((size_t)k * CIN + ci) * COUT + cot * 16 + m16] = acc[k][reg];
+        }
+}
+
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, const int32_t *__restrict__ n_ptr, int cap,
+                                    int per, float *__restrict__ dw, int accumulate)
+{
+    const int n = min(*n_ptr, cap);
+    const int nwg = (n + kWgRows - 1) / kWgRows;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per) return;
+    float s = accumulate ? dw[i] : 0.f;
+    for (int g = 0; g < nwg; ++g) s += part[(size_t)g * per + i];
+    dw[i] = s;
+}
+
+template <int CIN, int COUT>
+int launch_wgrad(const float *x, const float *dy, const int32_t *nbr, const int32_t *n_ptr, int cap, float *part,
+                 float *dw, int accumulate, hipStream_t stream)
+{
+    constexpr int MT = (CIN + 15) / 16, NTT = COUT / 16;
+    const int nwg = cdiv(cap, kWgRows);
+    hipLaunchKernelGGL((spconv_wgrad_kernel<CIN, COUT>), dim3(nwg), dim3(MT * NTT * 64), 0, stream, x, dy, nbr, n_ptr,
+                       cap, part);
+    const int per = kK * CIN * COUT;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(per, 256)), dim3(256), 0, stream, (const float *)part, n_ptr, cap,
+                       per, dw, accumulate);
+    return sassd_launch_status();
+}
+
+}  // namespace
+
+extern "C" int sassd_rulebook_transpose(const int32_t *nbr, const int32_t *n_out_ptr, int cap_out, int32_t *nbrT,
+                                        int cap_in, void *stream_)
+{
+    if (!nbr || !n_out_ptr || !nbrT || cap_out <= 0 || cap_in <= 0) return SASSD_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    if ((rc = sassd_hip(hipMemsetAsync(nbrT, 0xFF, (size_t)cap_in * kK * sizeof(int32_t), stream)))) return rc;
+    hipLaunchKernelGGL(nbr_transpose_kernel, dim3(cdiv(cap_out * kK, 256)), dim3(256), 0, stream, nbr, n_out_ptr,
+                       cap_out, cap_in, nbrT);
+    return sassd_launch_status();
+}
+
+extern "C" int sassd_spconv_pack_weight_t(const float *w, int K, int Cin, int Cout, float *packed, void *stream_)
+{
+    // w is the forward weight [K, Cin, Cout]; the packed image drives the Cout -> Cin data-gradient conv
+    if (!w || !packed || K < 1 || K > kK) return SASSD_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    { const int t = Cin; Cin = Cout; Cout = t; }
+    SP_DISPATCH(launch_pack, w, K, packed, 1, stream)
+}
+
+extern "C" int sassd_spconv_bwd_data(const float *dy, const int32_t *nbrT, const int32_t *n_in_ptr, int cap_in,
+                                     const float *wT_packed, int K, int Cin, int Cout, float *dx, void *stream_)
+{
+    // dx [cap_in, Cin] = sum_k dy[nbrT[i,k]] @ W[k]^T : the forward kernel with (Cin', Cout') = (Cout, Cin)
+    if (!dy || !n_in_ptr || !wT_packed || !dx || cap_in <= 0) return SASSD_EINVAL;
+    if (nbrT ? (K != kK) : (K != 1)) return SASSD_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    { const int t = Cin; Cin = Cout; Cout = t; }
+    SP_DISPATCH(launch_fwd, dy, nbrT, n_in_ptr, cap_in, wT_packed, K, nullptr, nullptr, 0, dx, stream)
+}
+
+extern "C" size_t sassd_spconv_bwd_weight_workspace_bytes(int cap_out, int K, int Cin, int Cout)
+{
+    return (size_t)cdiv(cap_out > 0 ? cap_out : 1, kWgRows) * K * Cin * Cout * sizeof(float);
+}
+
+extern "C" int sassd_spconv_bwd_weight(const float *x, const float *dy, const int32_t *nbr, const int32_t *n_out_ptr,
+                                       int cap_out, int K, int Cin, int Cout, float *dw, int accumulate,
+                                       void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (!x || !dy || !nbr || !n_out_ptr || !dw || !workspace || cap_out <= 0 || K != kK) return SASSD_EINVAL;
+    if (workspace_bytes < sassd_spconv_bwd_weight_workspace_bytes(cap_out, K, Cin, Cout)) return SASSD_ENOSPC;
+    hipStream_t stream = (hipStream_t)stream_;
+    float *part = (float *)workspace;
+    SP_DISPATCH(launch_wgrad, x, dy, nbr, n_out_ptr, cap_out, part, dw, accumulate, stream)
+}
+
+namespace {
 }  // namespace
 
 extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags; }
@@ -277,7 +428,7 @@ extern "C" int sassd_spconv_pack_weight(const float *w, int K, int Cin, int Cout
 {
     if (!w || !packed || K < 1 || K > kK) return SASSD_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    SP_DISPATCH(launch_pack, w, K, packed, stream)
+    SP_DISPATCH(launch_pack, w, K, packed, 0, stream)
 }
 
 extern "C" int sassd_spconv_fwd(const float *x, const int32_t *nbr, const int32_t *n_out_ptr, int cap_out,

@@ -164,6 +164,44 @@ def spconv_fwd(x, nbr, n_out_ptr, cap_out, w_packed, k, cin, cout, scale=None, s
     return y
 
 
+def rulebook_transpose(nbr, n_out_ptr, cap_out, cap_in):
+    nbrT = torch.empty(cap_in, 27, dtype=torch.int32, device=nbr.device)
+    _C.check(_C.lib().sassd_rulebook_transpose(_C.ptr(nbr), _C.ptr(n_out_ptr), cap_out, _C.ptr(nbrT), cap_in,
+                                               _C.stream()), "sassd_rulebook_transpose")
+    return nbrT
+
+
+def spconv_pack_weight_t(w):
+    """forward weight [K, Cin, Cout] -> packed W[k]^T image for sassd_spconv_bwd_data."""
+    _chk_cuda(w)
+    k, cin, cout = w.shape
+    packed = torch.empty(k * cin * cout, dtype=torch.float32, device=w.device)
+    _C.check(_C.lib().sassd_spconv_pack_weight_t(_C.ptr(w), k, cin, cout, _C.ptr(packed), _C.stream()),
+             "sassd_spconv_pack_weight_t")
+    return packed
+
+
+def spconv_bwd_data(dy, nbrT, n_in_ptr, cap_in, wT_packed, k, cin, cout):
+    _chk_cuda(dy, nbrT, wT_packed)
+    dx = torch.empty(cap_in, cin, dtype=torch.float32, device=dy.device)
+    _C.check(_C.lib().sassd_spconv_bwd_data(_C.ptr(dy), _C.ptr(nbrT), _C.ptr(n_in_ptr), cap_in, _C.ptr(wT_packed), k,
+                                            cin, cout, _C.ptr(dx), _C.stream()), "sassd_spconv_bwd_data")
+    return dx
+
+
+def spconv_bwd_weight(x, dy, nbr, n_out_ptr, cap_out, cin, cout, dw=None, accumulate=False):
+    _chk_cuda(x, dy, nbr)
+    L = _C.lib()
+    if dw is None:
+        dw = torch.zeros(27, cin, cout, dtype=torch.float32, device=x.device)
+    wsb = L.sassd_spconv_bwd_weight_workspace_bytes(cap_out, 27, cin, cout)
+    ws = workspace("spconv_wgrad", wsb, x.device)
+    _C.check(L.sassd_spconv_bwd_weight(_C.ptr(x), _C.ptr(dy), _C.ptr(nbr), _C.ptr(n_out_ptr), cap_out, 27, cin, cout,
+                                       _C.ptr(dw), 1 if accumulate else 0, _C.ptr(ws), wsb, _C.stream()),
+             "sassd_spconv_bwd_weight")
+    return dw
+
+
 def densify(feats, indices, n_ptr, cap, shape, batch_size, channel_order=0, out=None):
     d, h, w = shape
     c = feats.shape[1]

@@ -217,3 +217,44 @@ def test_pswarp_extreme_boxes_do_not_fault(dev):
         torch.cuda.synchronize()
         if big > 1e6:
             assert torch.isfinite(lg[0, :64]).all() or big != big
+
+
+@pytest.mark.parametrize("cin,cout,strided", [(4, 16, False), (16, 16, False), (16, 32, True), (32, 32, False),
+                                              (32, 64, True), (64, 64, False), (64, 64, True)])
+def test_spconv_backward(dev, cin, cout, strided):
+    """a15: data and weight gradients of the sparse conv vs torch autograd through the oracle's gather/mm/index_add."""
+    idx = _level0(dev, "small", 3)
+    shape = (40, 1600, 1408)
+    idx, _, shape = orb.conv_rulebook(idx, shape, 1)
+    idx, _, shape = orb.conv_rulebook(idx, shape, 1)
+    if strided:
+        out_idx, nbr, _ = orb.conv_rulebook(idx, shape, 1)
+    else:
+        out_idx, nbr = orb.subm_rulebook(idx, shape)
+    nin, nout = len(idx), len(out_idx)
+    g = torch.Generator().manual_seed(cin + 7 * cout)
+    x = torch.randn(nin, cin, generator=g, requires_grad=True)
+    w = (torch.randn(27, cin, cout, generator=g) * 0.2).requires_grad_(True)
+    dy = torch.randn(nout, cout, generator=g)
+    onets.sparse_conv(x, nbr, w).backward(dy)
+    cap_o, cap_i = nout + 11, nin + 5
+    nb = torch.full((cap_o, 27), -1, dtype=torch.int32, device=dev)
+    nb[:nout] = torch.from_numpy(nbr).to(dev)
+    n_o = torch.tensor([nout], dtype=torch.int32, device=dev)
+    n_i = torch.tensor([nin], dtype=torch.int32, device=dev)
+    dyd = torch.zeros(cap_o, cout, device=dev); dyd[:nout] = dy.to(dev)
+    xd = torch.zeros(cap_i, cin, device=dev); xd[:nin] = x.detach().to(dev)
+    dw = K.spconv_bwd_weight(xd, dyd, nb, n_o, cap_o, cin, cout)
+    e = (dw.cpu() - w.grad).abs().max().item()
+    assert e < 2e-4 * max(1.0, w.grad.abs().max().item()), e
+    dw2 = K.spconv_bwd_weight(xd, dyd, nb, n_o, cap_o, cin, cout, dw=dw.clone(), accumulate=True)
+    assert torch.allclose(dw2, 2 * dw, rtol=1e-5, atol=1e-4 * max(1.0, dw.abs().max().item()))
+    if cin >= 16:                      # the first layer's input needs no gradient (and Cout'=4 is not a kernel shape)
+        nbT = K.rulebook_transpose(nb, n_o, cap_o, cap_i)
+        ref_t = np.full((nin, 27), -1, np.int32)
+        oo, kk = np.nonzero(nbr >= 0)
+        ref_t[nbr[oo, kk], kk] = oo
+        assert np.array_equal(nbT[:nin].cpu().numpy(), ref_t)
+        dx = K.spconv_bwd_data(dyd, nbT, n_i, cap_i, K.spconv_pack_weight_t(w.detach().to(dev)), 27, cin, cout)
+        e = (dx[:nin].cpu() - x.grad).abs().max().item()
+        assert e < 2e-4 * max(1.0, x.grad.abs().max().item()), e

@@ -174,6 +174,14 @@ int sassd_pswarp_sample(const float *feat, int batch, int H, int W, const float 
                         const int32_t *counts, int capK, float grid_off_x, float grid_off_y,
                         float spatial_scale, float *logits, void *stream);
 
+/* backward of sassd_pswarp_sample (training, PSWarpHead.loss): dlogits [B,capK] -> ACCUMULATES into dfeat [B,28,H,W]
+ * (caller zeroes; float atomics) and writes dguided [B,capK,7] (d/d x,y,w,l,r; z,h columns zero; may be NULL) --
+ * torch.nn.functional.grid_sample differentiates w.r.t. both input and grid (ssd_rotate_head.py:400-414). */
+int sassd_pswarp_sample_bwd(const float *feat, int batch, int H, int W, const float *guided,
+                            const int32_t *counts, int capK, float grid_off_x, float grid_off_y,
+                            float spatial_scale, const float *dlogits, float *dfeat, float *dguided,
+                            void *stream);
+
 /* (a13+a14) get_rescore_bboxes (ssd_rotate_head.py:487-533): sigmoid, > score_thr, BEV boxes
  * (iou3d_utils.py:47-60), stable descending sort, rotated NMS (iou3d_kernel.cu:250-292 + iou3d.cpp:100-116).
  *   out_boxes [B,capD,7], out_scores [B,capD], out_labels [B,capD] i32, out_counts [B] i32. */

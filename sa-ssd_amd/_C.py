@@ -62,6 +62,7 @@ _SIGS = {
     "sassd_decode_filter_workspace_bytes": (_SZ, [_I, _I]),
     "sassd_decode_filter": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "sassd_pswarp_sample": (_I, [_P, _I, _I, _I, _P, _P, _I, _F, _F, _F, _P, _P]),
+    "sassd_pswarp_sample_bwd": (_I, [_P, _I, _I, _I, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P]),
     "sassd_rescore_nms_workspace_bytes": (_SZ, [_I, _I]),
     "sassd_rescore_nms": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "sassd_boxes_overlap_bev": (_I, [_P, _I, _P, _I, _P, _P]),

@@ -1,0 +1,125 @@
+"""torch.autograd glue for the training path: every forward and every data / weight gradient below
+runs in a hand-written HIP kernel of libsassd, with ONE labelled exception -- the dense 2-D convolution's WEIGHT
+gradient still goes through `torch.nn.grad.conv2d_weight` (MIOpen) until the native MFMA wgrad kernel lands
+(DESIGN.md section 7).  There is no CPU fallback."""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+
+def _n_ptr(n, dev):
+    return torch.tensor([n], dtype=torch.int32, device=dev)
+
+
+class SparseConvFn(Function):
+    """y = sum_k x[nbr[:, k]] @ w[k]  (raw conv; BatchNorm / ReLU stay separate modules in training mode)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, nbr, n_out, packed):
+        # x [Nin, Cin]; weight [K, Cin, Cout] view of the module parameter; nbr [Nout, 27] or None (1x1x1)
+        k, cin, cout = weight.shape
+        x = x.contiguous()
+        dev = x.device
+        y = K.spconv_fwd(x, nbr, _n_ptr(n_out, dev), max(n_out, 1), packed, k, cin, cout)
+        ctx.save_for_backward(x, weight)
+        ctx.nbr, ctx.n_out = nbr, n_out
+        return y[:n_out]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        k, cin, cout = weight.shape
+        nbr, n_out = ctx.nbr, ctx.n_out
+        n_in = x.shape[0]
+        dev = x.device
+        dyc = torch.zeros(max(n_out, 1), cout, dtype=torch.float32, device=dev)
+        dyc[:n_out] = dy
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if cin < 16:
+                raise NotImplementedError("sparse data gradient needs Cin >= 16 (the 4-channel input layer has none)")
+            wt = K.spconv_pack_weight_t(weight.detach().contiguous())
+            if nbr is None:
+                dx = K.spconv_bwd_data(dyc, None, _n_ptr(n_in, dev), max(n_in, 1), wt, 1, cin, cout)[:n_in]
+            else:
+                nbr_t = K.rulebook_transpose(nbr, _n_ptr(n_out, dev), nbr.shape[0], max(n_in, 1))
+                dx = K.spconv_bwd_data(dyc, nbr_t, _n_ptr(n_in, dev), max(n_in, 1), wt, 27, cin, cout)[:n_in]
+        if ctx.needs_input_grad[1]:
+            if nbr is None:
+                dw = (x.t() @ dyc[:n_in]).view(1, cin, cout)          # plain library GEMM for the 1x1x1 layer
+            else:
+                xc = x if n_in > 0 else torch.zeros(1, cin, device=dev)
+                dw = K.spconv_bwd_weight(xc, dyc, nbr, _n_ptr(n_out, dev), nbr.shape[0], cin, cout)
+        return dx, dw, None, None, None
+
+
+class Conv2dFn(Function):
+    """NCHW fp32 conv (3x3 pad 1 / 1x1) + optional bias on the fp32-MFMA kernel; data gradient = the same kernel with
+    flipped, transposed weights."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed):
+        x = x.contiguous()
+        cout, cin, ks, _ = weight.shape
+        y = K.conv2d_fwd(x, packed, cout, ks, None, bias.detach().contiguous() if bias is not None else None, False)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        cout, cin, ks, _ = weight.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # [Cin, Cout, k, k], taps mirrored
+            dx = K.conv2d_fwd(dy, K.conv2d_pack_weight(wt), cin, ks)
+        if ctx.needs_input_grad[1]:
+            # INTERIM (labelled in DESIGN.md): dense weight gradient through the vendor library
+            dw = torch.nn.grad.conv2d_weight(x, weight.shape, dy, padding=ks // 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None
+
+
+class DensifyFn(Function):
+    """SparseConvTensor.dense(): [N,C] rows -> [B, C, D, H, W]; backward gathers the rows back."""
+
+    @staticmethod
+    def forward(ctx, feats, indices, shape, batch_size):
+        d, h, w = shape
+        n, c = feats.shape
+        out = K.densify(feats.contiguous(), indices, _n_ptr(n, feats.device), max(n, 1), shape, batch_size, 0)
+        ctx.indices = indices
+        return out.view(batch_size, c, d, h, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        i = ctx.indices.long()
+        return g[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous(), None, None, None
+
+
+class PSWarpFn(Function):
+    """Part-sensitive bilinear sampling of one sample: feat [1,28,H,W], boxes [K,7] -> logits [K]."""
+
+    @staticmethod
+    def forward(ctx, feat, boxes, grid_offsets, spatial_scale):
+        k = boxes.shape[0]
+        feat = feat.contiguous()
+        boxes = boxes.contiguous()
+        cnt = _n_ptr(k, feat.device)
+        lg = K.pswarp_sample(feat, boxes.view(1, k, 7), cnt, k, grid_offsets, spatial_scale)
+        ctx.save_for_backward(feat, boxes)
+        ctx.args = (grid_offsets, spatial_scale)
+        return lg.view(-1)
+
+    @staticmethod
+    def backward(ctx, dlog):
+        feat, boxes = ctx.saved_tensors
+        k = boxes.shape[0]
+        cnt = _n_ptr(k, feat.device)
+        dfeat, dg = K.pswarp_sample_bwd(feat, boxes.view(1, k, 7), cnt, k, ctx.args[0], ctx.args[1],
+                                        dlog.contiguous().view(1, k))
+        return dfeat, dg.view(k, 7), None, None

@@ -185,6 +185,66 @@ __global__ void __launch_bounds__(256) pswarp_kernel(WarpParams P)
     if (box < K && k == 0) P.logits[(size_t)b * P.capK + box] = val / 28.f;
 }
 
+// backward of pswarp_kernel (training): d logits -> d feat (atomicAdd into [B,28,H,W]) and d guided [B,capK,7]
+// (the reference differentiates grid_sample w.r.t. input AND grid, so the rescoring loss also steers x,y,w,l,r)
+__global__ void __launch_bounds__(256) pswarp_bwd_kernel(WarpParams P, const float *__restrict__ dlogits,
+                                                         float *__restrict__ dfeat, float *__restrict__ dguided)
+{
+    const int b = blockIdx.y;
+    const int K = min(P.counts[b], P.capK);
+    const int box = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int k = threadIdx.x & 31;
+    float gxg = 0.f, gyg = 0.f, gw = 0.f, gl = 0.f, gr = 0.f;
+    if (box < K && k < 28) {
+        const float *g = P.guided + ((size_t)b * P.capK + box) * 7;
+        const float xg = g[0], yg = g[1], wg = g[3], lg = g[4], rg = g[6];
+        const float ct = cosf(rg), st = sinf(rg);
+        const int ix = k / 7, iy = k - ix * 7;
+        const float xx = P.lin4[ix] * wg, yy = P.lin7[iy] * lg;
+        const float x = xx * ct + yy * st + xg;
+        const float y = yy * ct - xx * st + yg;
+        const float u = (x + P.offx) * P.scale, v = (y + P.offy) * P.scale;
+        const float gx = u / (float)(P.W - 1) * 2.f - 1.f, gy = v / (float)(P.H - 1) * 2.f - 1.f;
+        float fx = (gx + 1.f) / 2.f * (float)(P.W - 1), fy = (gy + 1.f) / 2.f * (float)(P.H - 1);
+        const bool inr = fx > -1.f && fx < (float)P.W && fy > -1.f && fy < (float)P.H;   // else: all taps padded
+        fx = fminf(fmaxf(fx, -2.f), (float)P.W + 1.f);
+        fy = fminf(fmaxf(fy, -2.f), (float)P.H + 1.f);
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+        const float wx1 = fx - x0f, wx0 = (x0f + 1.f) - fx, wy1 = fy - y0f, wy0 = (y0f + 1.f) - fy;
+        const float go = dlogits[(size_t)b * P.capK + box] / 28.f;
+        const size_t plane = ((size_t)b * 28 + k) * P.H * P.W;
+        const float *im = P.feat + plane;
+        float *di = dfeat + plane;
+        const bool xin0 = x0 >= 0 && x0 < P.W, xin1 = x1 >= 0 && x1 < P.W;
+        const bool yin0 = y0 >= 0 && y0 < P.H, yin1 = y1 >= 0 && y1 < P.H;
+        float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+        if (inr) {
+            if (yin0 && xin0) { v00 = im[(size_t)y0 * P.W + x0]; atomicAdd(&di[(size_t)y0 * P.W + x0], go * wx0 * wy0); }
+            if (yin0 && xin1) { v01 = im[(size_t)y0 * P.W + x1]; atomicAdd(&di[(size_t)y0 * P.W + x1], go * wx1 * wy0); }
+            if (yin1 && xin0) { v10 = im[(size_t)y1 * P.W + x0]; atomicAdd(&di[(size_t)y1 * P.W + x0], go * wx0 * wy1); }
+            if (yin1 && xin1) { v11 = im[(size_t)y1 * P.W + x1]; atomicAdd(&di[(size_t)y1 * P.W + x1], go * wx1 * wy1); }
+        }
+        // d sample / d fx, d fy ; fx = u, fy = v (the normalise / un-normalise pair is the identity)
+        const float dfx = ((v01 - v00) * wy0 + (v11 - v10) * wy1) * go;
+        const float dfy = ((v10 - v00) * wx0 + (v11 - v01) * wx1) * go;
+        const float dx = dfx * P.scale, dy = dfy * P.scale;
+        gxg = dx; gyg = dy;
+        gw = (dx * ct - dy * st) * P.lin4[ix];
+        gl = (dx * st + dy * ct) * P.lin7[iy];
+        gr = dx * (-xx * st + yy * ct) + dy * (-yy * st - xx * ct);
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {
+        gxg += __shfl_xor(gxg, o, 32); gyg += __shfl_xor(gyg, o, 32); gw += __shfl_xor(gw, o, 32);
+        gl += __shfl_xor(gl, o, 32); gr += __shfl_xor(gr, o, 32);
+    }
+    if (box < K && k == 0 && dguided) {
+        float *d = dguided + ((size_t)b * P.capK + box) * 7;
+        d[0] = gxg; d[1] = gyg; d[2] = 0.f; d[3] = gw; d[4] = gl; d[5] = 0.f; d[6] = gr;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // rotated NMS building blocks
 // ------------------------------------------------------------------------------------------------
@@ -515,6 +575,23 @@ extern "C" int sassd_pswarp_sample(const float *feat, int batch, int H, int W, c
     linspace_f32(-0.5f, 0.5f, 4, P.lin4);
     linspace_f32(-0.5f, 0.5f, 7, P.lin7);
     hipLaunchKernelGGL(pswarp_kernel, dim3(cdiv(capK, 8), batch), dim3(256), 0, (hipStream_t)stream_, P);
+    return sassd_launch_status();
+}
+
+extern "C" int sassd_pswarp_sample_bwd(const float *feat, int batch, int H, int W, const float *guided,
+                                       const int32_t *counts, int capK, float grid_off_x, float grid_off_y,
+                                       float spatial_scale, const float *dlogits, float *dfeat, float *dguided,
+                                       void *stream_)
+{
+    if (!feat || !guided || !counts || !dlogits || !dfeat || batch < 1 || capK < 1) return SASSD_EINVAL;
+    WarpParams P;
+    P.feat = feat; P.guided = guided; P.counts = counts; P.logits = nullptr;
+    P.B = batch; P.H = H; P.W = W; P.capK = capK;
+    P.offx = grid_off_x; P.offy = grid_off_y; P.scale = spatial_scale;
+    linspace_f32(-0.5f, 0.5f, 4, P.lin4);
+    linspace_f32(-0.5f, 0.5f, 7, P.lin7);
+    hipLaunchKernelGGL(pswarp_bwd_kernel, dim3(cdiv(capK, 8), batch), dim3(256), 0, (hipStream_t)stream_, P, dlogits,
+                       dfeat, dguided);
     return sassd_launch_status();
 }
 

@@ -9,8 +9,10 @@ arguments, parameter names -> reference checkpoints load with `load_state_dict`)
   build_detector       mmdet/models/builder.py:54-56
 
 `model(img, img_meta, return_loss=False, voxels=[..], coordinates=[..], num_points=[..], anchors=[..],
-anchors_mask=[..])` runs the fused HIP pipeline (sassd.pipeline.InferencePlan).  The training branch
-(forward_train: losses, target assignment, aux head) is outside this round's scope and raises.
+anchors_mask=[..])` runs the fused HIP pipeline (sassd.pipeline.InferencePlan).  `return_loss=True` runs the
+training branch (single_stage.py:75-108): module-by-module forward through the same HIP kernels recorded by
+sassd.autograd (sparse / dense conv, densify, part-sensitive warp, 3-NN interpolation all have HIP backward
+kernels), torch BatchNorm / ReLU / Linear in between, losses and target assignment from sassd.train_ops.
 """
 import sys
 
@@ -18,10 +20,14 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import iou3d_utils
 from . import kernels as K
 from . import spconv
+from . import train_ops as T
+from .autograd import Conv2dFn, PSWarpFn
 from .config import obj_from_dict
 from .pipeline import InferencePlan
+from .pointnet2_utils import nearest_neighbor_interpolate
 
 
 def change_default_args(**kwargs):
@@ -101,16 +107,22 @@ class VxNet(nn.Module):
 class _HipConv2d(nn.Conv2d):
     """nn.Conv2d parameters, HIP fp32-MFMA forward (sassd_conv2d_fwd) with an optional fused affine + ReLU."""
 
-    def hip_forward(self, x, scale=None, shift=None, relu=False):
+    def packed_weight(self):
         v = self.weight._version
         if getattr(self, "_pk", None) is None or self._pkv != v or self._pk.device != self.weight.device:
             self._pk, self._pkv = K.conv2d_pack_weight(self.weight.detach().float().contiguous()), v
+        return self._pk
+
+    def hip_forward(self, x, scale=None, shift=None, relu=False):
+        self.packed_weight()
         if shift is None and self.bias is not None:
             shift = self.bias.detach().float().contiguous()
         return K.conv2d_fwd(x.contiguous().float(), self._pk, self.out_channels, self.kernel_size[0], scale, shift,
                             relu)
 
     def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return Conv2dFn.apply(x.float(), self.weight, self.bias, self.packed_weight())
         return self.hip_forward(x)
 
 
@@ -133,10 +145,11 @@ class BEVNet(nn.Module):
         conv6 = None
         for i in range(8):
             conv, bn = getattr(self, 'conv%d' % i), getattr(self, 'bn%d' % i)
-            if self.training:
-                raise NotImplementedError("training-mode BatchNorm is outside this round's scope")
-            s, b = _bn_affine(bn)
-            x = conv.hip_forward(x, s, b, True)
+            if self.training or (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)):
+                x = torch.relu(bn(conv(x)))                 # batch statistics: BN stays a torch op in training
+            else:
+                s, b = _bn_affine(bn)
+                x = conv.hip_forward(x, s, b, True)
             if i == 6:
                 conv6 = x
         return x, conv6
@@ -152,14 +165,62 @@ class SpMiddleFHD(nn.Module):
         self.point_cls = nn.Linear(64, 1, bias=False)
         self.point_reg = nn.Linear(64, 3, bias=False)
 
+    def build_aux_target(self, nxyz, gt_boxes3d, enlarge=1.0):
+        """cmn.py:45-72 with the point-in-box test on the device (sassd_pts_in_boxes3d)."""
+        offsets, labels = [], []
+        for i, boxes3d in enumerate(gt_boxes3d):
+            pts = nxyz[nxyz[:, 0] == i, 1:].contiguous()
+            boxes3d = boxes3d.clone().float()
+            boxes3d[:, 3:6] *= enlarge
+            if boxes3d.shape[0] == 0 or pts.shape[0] == 0:
+                labels.append(torch.zeros(pts.shape[0], dtype=torch.uint8, device=pts.device))
+                offsets.append(torch.zeros(pts.shape[0], 3, device=pts.device))
+                continue
+            flag, off = K.pts_in_boxes3d(pts, boxes3d.to(pts.device).contiguous())
+            labels.append(flag.max(0)[0].to(torch.uint8))
+            offsets.append(off)
+        return torch.cat(labels), torch.cat(offsets)
+
+    def aux_loss(self, points, point_cls, point_reg, gt_bboxes):
+        """cmn.py:74-104."""
+        n = len(gt_bboxes)
+        pts_labels, center_targets = self.build_aux_target(points, gt_bboxes)
+        pos, neg = (pts_labels > 0).float(), (pts_labels == 0).float()
+        norm = torch.clamp(pos.sum(), min=1.0)
+        aux_cls = T.weighted_sigmoid_focal_loss(point_cls.view(-1), pts_labels.float(), weight=(pos + neg) / norm,
+                                                avg_factor=1.) / n
+        aux_reg = T.weighted_smoothl1(point_reg, center_targets, beta=1 / 9., weight=(pos / norm)[..., None],
+                                      avg_factor=1.) / n
+        return dict(aux_loss_cls=aux_cls, aux_loss_reg=aux_reg)
+
+    @staticmethod
+    def tensor2points(tensor, offset=(0., -40., -3.), voxel_size=(.05, .05, .1)):
+        """mmdet/core/bbox/transforms.py:218-223: voxel centres [b,x,y,z] of a sparse tensor's rows."""
+        ind = tensor.indices.float()
+        off = torch.tensor(offset, device=ind.device)
+        vs = torch.tensor(voxel_size, device=ind.device)
+        out = ind.clone()
+        out[:, 1:] = ind[:, [3, 2, 1]] * vs + off + .5 * vs
+        return tensor.features, out
+
     def forward(self, voxel_features, coors, batch_size, is_test=False):
-        if not is_test:
-            raise NotImplementedError("auxiliary-network training branch (cmn.py:121-135) not in scope yet")
         x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size)
         x, middle = self.backbone(x)
         x = x.dense()
         n, c, d, h, w = x.shape
-        return self.fcn(x.view(n, c * d, h, w))
+        x, conv6 = self.fcn(x.view(n, c * d, h, w))
+        if is_test:
+            return x, conv6
+        # auxiliary network (cmn.py:121-135): multi-scale voxel features interpolated back to the voxel means
+        points_mean = torch.zeros_like(voxel_features)
+        points_mean[:, 0] = coors[:, 0]
+        points_mean[:, 1:] = voxel_features[:, :3]
+        ps = []
+        for m, vs in zip(middle, ((.1, .1, .2), (.2, .2, .4), (.4, .4, .8))):
+            feat, nxyz = self.tensor2points(m, (0, -40., -3.), vs)
+            ps.append(nearest_neighbor_interpolate(points_mean, nxyz, feat))
+        pointwise = self.point_fc(torch.cat(ps, dim=-1))
+        return x, conv6, (points_mean, self.point_cls(pointwise), self.point_reg(pointwise))
 
 
 class SSDRotateHead(nn.Module):
@@ -185,6 +246,113 @@ class SSDRotateHead(nn.Module):
             outs.append(y.view(n, self._num_class, -1, h, w).permute(0, 1, 3, 4, 2).contiguous())
         return tuple(outs)
 
+    # ---- training (ssd_rotate_head.py:128-314) -----------------------------------------------------------------
+    @staticmethod
+    def add_sin_difference(boxes1, boxes2):
+        r1 = torch.sin(boxes1[..., -1:]) * torch.cos(boxes2[..., -1:])
+        r2 = torch.cos(boxes1[..., -1:]) * torch.sin(boxes2[..., -1:])
+        return torch.cat((boxes1[..., :-1], r1), dim=-1), torch.cat((boxes2[..., :-1], r2), dim=-1)
+
+    @staticmethod
+    def get_direction_target(anchors, reg_targets, use_one_hot=True):
+        b = reg_targets.shape[0]
+        rot_gt = reg_targets[..., -1] + anchors.view(b, -1, 7)[..., -1]
+        t = (rot_gt > 0).long()
+        return T.one_hot(t, 2, dtype=anchors.dtype) if use_one_hot else t
+
+    @staticmethod
+    def prepare_loss_weights(labels, pos_cls_weight=1.0, neg_cls_weight=1.0, dtype=torch.float32):
+        """'NormByNumPositives' (the only normalisation the reference's loss() requests)."""
+        cared, positives, negatives = labels >= 0, labels > 0, labels == 0
+        cls_w = negatives.type(dtype) * neg_cls_weight + pos_cls_weight * positives.type(dtype)
+        reg_w = positives.type(dtype)
+        norm = torch.clamp(positives.sum(1, keepdim=True).type(dtype), min=1.0)
+        return cls_w / norm, reg_w / norm, cared
+
+    def create_loss(self, box_preds, cls_preds, cls_targets, cls_weights, reg_targets, reg_weights, num_class,
+                    use_sigmoid_cls=True, encode_rad_error_by_sin=True, box_code_size=7):
+        b = int(box_preds.shape[0])
+        box_preds = box_preds.view(b, -1, box_code_size)
+        cls_preds = cls_preds.view(b, -1, num_class if use_sigmoid_cls else num_class + 1)
+        oh = T.one_hot(cls_targets, depth=num_class + 1, dtype=box_preds.dtype)
+        if use_sigmoid_cls:
+            oh = oh[..., 1:]
+        if encode_rad_error_by_sin:
+            box_preds, reg_targets = self.add_sin_difference(box_preds, reg_targets)
+        loc = T.weighted_smoothl1(box_preds, reg_targets, beta=1 / 9., weight=reg_weights[..., None], avg_factor=1.)
+        cls = T.weighted_sigmoid_focal_loss(cls_preds, oh, weight=cls_weights[..., None], avg_factor=1.)
+        return loc, cls
+
+    def loss(self, box_preds, cls_preds, dir_cls_preds, gt_bboxes, gt_labels, gt_types, anchors, anchors_mask, cfg):
+        b = box_preds.shape[0]
+        multi_labels, multi_targets, multi_anchors = [], [], []
+        sim = getattr(T, cfg.assigner.similarity_fn, None) or getattr(iou3d_utils, cfg.assigner.similarity_fn)
+        for cls_name, cls_anchor in anchors.items():
+            gt_mask = [torch.as_tensor(np.asarray(c) == cls_name, dtype=torch.bool, device=cls_anchor.device)
+                       for c in gt_types]
+            labels, targets, _ = T.multi_apply(
+                T.create_target_torch, cls_anchor, anchors_mask[cls_name], gt_bboxes, gt_labels, gt_mask,
+                similarity_fn=sim(), box_encoding_fn=T.second_box_encode,
+                matched_threshold=cfg.assigner[cls_name].pos_iou_thr,
+                unmatched_threshold=cfg.assigner[cls_name].neg_iou_thr, box_code_size=self._box_code_size)
+            multi_labels.append(torch.stack(labels))
+            multi_targets.append(torch.stack(targets))
+            multi_anchors.append(cls_anchor)
+        labels = torch.stack(multi_labels, 1).view(b, -1)
+        targets = torch.stack(multi_targets, 1).view(b, -1, self._box_code_size)
+        anchors = torch.stack(multi_anchors, 1).view(b, -1, self._box_code_size)
+        cls_weights, reg_weights, cared = self.prepare_loss_weights(labels)
+        cls_targets = labels * cared.type_as(labels)
+        loc, cls = self.create_loss(box_preds, cls_preds, cls_targets, cls_weights, targets, reg_weights,
+                                    num_class=self._num_class, use_sigmoid_cls=self._use_sigmoid_cls,
+                                    encode_rad_error_by_sin=self._encode_rad_error_by_sin,
+                                    box_code_size=self._box_code_size)
+        out = dict(rpn_loc_loss=loc / b * 2, rpn_cls_loss=cls / b)
+        if self._use_direction_classifier:
+            dir_labels = self.get_direction_target(anchors, targets, use_one_hot=False).view(-1)
+            w = (labels > 0).type_as(dir_cls_preds)
+            w = w / torch.clamp(w.sum(-1, keepdim=True), min=1.0)
+            out['rpn_dir_loss'] = T.weighted_cross_entropy(dir_cls_preds.view(-1, 2), dir_labels, weight=w.view(-1),
+                                                           avg_factor=1.) / b * .2
+        return out
+
+    def get_guided_anchors(self, box_preds, cls_preds, dir_cls_preds, anchors, anchors_mask, gt_bboxes, gt_labels,
+                           thr=.1):
+        """ssd_rotate_head.py:316-388, module-level torch path used by training (gradients flow into box_preds;
+        ground-truth boxes are prepended).  Inference uses the fused sassd_decode_filter kernel instead."""
+        b = box_preds.shape[0]
+        if isinstance(anchors, dict):
+            anchors = torch.cat(list(anchors.values()), 1)
+        if isinstance(anchors_mask, dict):
+            anchors_mask = torch.cat(list(anchors_mask.values()), 1)
+        batch_box = T.second_box_decode(box_preds.view(b, -1, self._box_code_size), anchors.view(b, -1, 7))
+        batch_mask = anchors_mask.view(b, -1).bool()
+        batch_cls = cls_preds.view(b, -1, self._num_class)
+        batch_dir = dir_cls_preds.view(b, -1, 2)
+        gt_bboxes = gt_bboxes if gt_bboxes is not None else [None] * b
+        gt_labels = gt_labels if gt_labels is not None else [None] * b
+        guided, labels_out = [], []
+        for box, cls, dirp, m, gtb, gtl in zip(batch_box, batch_cls, batch_dir, batch_mask, gt_bboxes, gt_labels):
+            box, cls, dirp = box[m], cls[m], dirp[m]
+            dir_labels = torch.max(dirp, dim=-1)[1]
+            scores = torch.sigmoid(cls) if self._use_sigmoid_cls else torch.softmax(cls, dim=-1)[..., 1:]
+            if self._num_class == 1:
+                top_scores = scores.squeeze(-1)
+                top_labels = torch.zeros(scores.shape[0], dtype=torch.int64, device=scores.device)
+            else:
+                top_scores, top_labels = torch.max(scores, dim=-1)
+            sel = top_scores > thr
+            box, top_labels, dir_labels = box[sel], top_labels[sel], dir_labels[sel]
+            if self._use_direction_classifier:
+                opp = (box[..., -1] > 0) ^ dir_labels.bool()
+                box = torch.cat([box[:, :-1], (box[:, -1] + opp.type_as(box) * np.pi)[:, None]], dim=1)
+            if gtb is not None:
+                box = torch.cat([gtb.type_as(box), box], 0)
+                top_labels = torch.cat([gtl.to(top_labels.device), top_labels], 0)
+            guided.append(box)
+            labels_out.append(top_labels)
+        return guided, labels_out
+
 
 class PSWarpHead(nn.Module):
     def __init__(self, grid_offsets, featmap_stride, in_channels, num_class=1, num_parts=49):
@@ -198,19 +366,45 @@ class PSWarpHead(nn.Module):
 
     def forward(self, x, guided_anchors, is_test=False):
         """guided_anchors: list (per sample) of [K,7] device tensors -> list of [K] logits."""
-        s, b = _bn_affine(self.convs[1])
-        f = self.convs[3].hip_forward(self.convs[0].hip_forward(x, s, b, True))
+        grad = torch.is_grad_enabled() and (x.requires_grad or self.convs[0].weight.requires_grad)
+        if self.training or grad:
+            f = self.convs(x)
+        else:
+            s, b = _bn_affine(self.convs[1])
+            f = self.convs[3].hip_forward(self.convs[0].hip_forward(x, s, b, True))
         scores = []
         for i, ga in enumerate(guided_anchors):
             k = ga.shape[0]
             if k == 0:
                 scores.append(torch.empty(0, device=x.device))
                 continue
+            if grad:
+                scores.append(PSWarpFn.apply(f[i:i + 1], ga.float(), tuple(self.grid_offsets),
+                                             1.0 / self.featmap_stride))
+                continue
             cnt = torch.tensor([k], dtype=torch.int32, device=x.device)
             lg = K.pswarp_sample(f[i:i + 1].contiguous(), ga.contiguous().view(1, k, 7), cnt, k, self.grid_offsets,
                                  1.0 / self.featmap_stride)
             scores.append(lg.view(-1))
         return scores if is_test else torch.cat(scores, 0)
+
+    def loss(self, cls_preds, gt_bboxes, gt_labels, anchors, cfg):
+        """ssd_rotate_head.py:456-490: class-agnostic rescoring targets from the rotated 3-D IoU (HIP overlap kernel)."""
+        b = len(anchors)
+        none = (None,) * b
+        sim = getattr(T, cfg.assigner.similarity_fn, None) or getattr(iou3d_utils, cfg.assigner.similarity_fn)
+        labels, _, _ = T.multi_apply(T.create_target_torch, [a.detach() for a in anchors], none, gt_bboxes, none,
+                                     none, similarity_fn=sim(), box_encoding_fn=T.second_box_encode,
+                                     matched_threshold=cfg.assigner.pos_iou_thr,
+                                     unmatched_threshold=cfg.assigner.neg_iou_thr)
+        labels = torch.cat(labels).unsqueeze(1)
+        cared, positives, negatives = labels >= 0, labels > 0, labels == 0
+        w = negatives.float() + positives.float()
+        w = w / torch.clamp(positives.sum().float(), min=1.0)
+        cls_targets = labels * cared.type_as(labels)
+        cls = T.weighted_sigmoid_focal_loss(cls_preds.view(-1, self._num_class), cls_targets.float(), weight=w,
+                                            avg_factor=1.)
+        return dict(loss_cls=cls / b)
 
 
 class SingleStageDetector(nn.Module):
@@ -270,7 +464,25 @@ class SingleStageDetector(nn.Module):
         return self._plan
 
     def forward_train(self, img, img_meta, **kwargs):
-        raise NotImplementedError("training path (losses / target assignment / aux head) is a later round")
+        """single_stage.py:75-108 -> dict of loss tensors."""
+        batch_size = len(img_meta)
+        ret = self.merge_second_batch(kwargs)
+        vx = self.backbone(ret['voxels'], ret['num_points'])
+        x, conv6, point_misc = self.neck(vx, ret['coordinates'], batch_size, is_test=False)
+        losses = dict()
+        losses.update(self.neck.aux_loss(*point_misc, gt_bboxes=ret['gt_bboxes']))
+        if not self.with_rpn:
+            raise NotImplementedError
+        rpn_outs = self.rpn_head(x)
+        losses.update(self.rpn_head.loss(*rpn_outs, ret['gt_bboxes'], ret['gt_labels'], ret['gt_types'],
+                                         ret['anchors'], ret['anchors_mask'], self.train_cfg.rpn))
+        guided, _ = self.rpn_head.get_guided_anchors(*rpn_outs, ret['anchors'], ret['anchors_mask'], ret['gt_bboxes'],
+                                                     ret['gt_labels'], thr=self.train_cfg.rpn.anchor_thr)
+        if getattr(self, 'extra_head', None) is not None:
+            score = self.extra_head(conv6, guided)
+            losses.update(self.extra_head.loss(score, ret['gt_bboxes'], ret['gt_labels'], guided,
+                                               self.train_cfg.extra))
+        return losses
 
     def forward_test(self, img, img_meta, **kwargs):
         """single_stage.py:110-131 on the fused pipeline.  Returns per-sample dicts

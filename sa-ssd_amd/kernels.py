@@ -293,6 +293,18 @@ def pswarp_sample(feat, guided, counts, cap_k, grid_offsets, spatial_scale, logi
     return logits
 
 
+def pswarp_sample_bwd(feat, guided, counts, cap_k, grid_offsets, spatial_scale, dlogits):
+    """-> (dfeat [B,28,H,W], dguided [B,capK,7])."""
+    b, parts, h, w = feat.shape
+    dfeat = torch.zeros_like(feat)
+    dg = torch.zeros(b, cap_k, 7, dtype=torch.float32, device=feat.device)
+    rc = _C.lib().sassd_pswarp_sample_bwd(_C.ptr(feat), b, h, w, _C.ptr(guided), _C.ptr(counts), cap_k,
+                                          float(grid_offsets[0]), float(grid_offsets[1]), float(spatial_scale),
+                                          _C.ptr(dlogits), _C.ptr(dfeat), _C.ptr(dg), _C.stream())
+    _C.check(rc, "sassd_pswarp_sample_bwd")
+    return dfeat, dg
+
+
 def rescore_nms(guided, logits, labels, counts, score_thr, iou_thr, cap_d, out=None, status=None):
     dev = guided.device
     L = _C.lib()

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
+from .autograd import DensifyFn, SparseConvFn
 
 
 class SparseConvTensor:
@@ -44,6 +45,9 @@ class SparseConvTensor:
         d, h, w = self.spatial_shape
         c = self.features.shape[1]
         n = self.indices.shape[0]
+        if torch.is_grad_enabled() and self.features.requires_grad:
+            out = DensifyFn.apply(self.features.float(), self.indices.int().contiguous(), (d, h, w), self.batch_size)
+            return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
         out = K.densify(self.features.contiguous(), self.indices.int().contiguous(), self._n_ptr(), max(n, 1),
                         (d, h, w), self.batch_size, 0)
         out = out.view(self.batch_size, c, d, h, w)
@@ -84,18 +88,26 @@ class SparseConvolution(nn.Module):
             self._packed_version = v
         return self._packed
 
+    def _apply(self, feats, nbr, n_out, k, grad):
+        """Raw conv (+bias) over a gather table: autograd-recording HIP path when gradients are wanted."""
+        cin, cout = self.in_channels, self.out_channels
+        if grad:
+            y = SparseConvFn.apply(feats, self.weight.view(k, cin, cout), nbr, n_out, self.packed_weight())
+            return y + self.bias if self.bias is not None else y
+        bias = self.bias.detach() if self.bias is not None else None
+        n_ptr = torch.tensor([n_out], dtype=torch.int32, device=feats.device)
+        return K.spconv_fwd(feats, nbr, n_ptr, max(n_out, 1), self.packed_weight(), k, cin, cout, None, bias)[:n_out]
+
     def forward(self, inp):
         assert isinstance(inp, SparseConvTensor)
         feats = inp.features.contiguous().float()
         idx = inp.indices.int().contiguous()
         n = idx.shape[0]
-        dev = feats.device
-        cin, cout = self.in_channels, self.out_channels
-        bias = self.bias.detach() if self.bias is not None else None
+        grad = torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad)
         if self.conv1x1:
             # spconv shortcut: features @ weight.view(Cin, Cout), indices unchanged
-            y = K.spconv_fwd(feats, None, inp._n_ptr(), max(n, 1), self.packed_weight(), 1, cin, cout, None, bias)
-            out = SparseConvTensor(y[:n], inp.indices, inp.spatial_shape, inp.batch_size)
+            y = self._apply(feats, None, n, 1, grad)
+            out = SparseConvTensor(y, inp.indices, inp.spatial_shape, inp.batch_size)
             out.indice_dict, out._table = inp.indice_dict, inp._table
             return out
         if self.kernel_size != (3, 3, 3):
@@ -123,9 +135,8 @@ class SparseConvolution(nn.Module):
                     inp.indice_dict[self.indice_key] = book
             out_idx, nbr, oshape, otable = book
             n_out = out_idx.shape[0]
-        n_ptr = torch.tensor([n_out], dtype=torch.int32, device=dev)
-        y = K.spconv_fwd(feats, nbr, n_ptr, max(n_out, 1), self.packed_weight(), 27, cin, cout, None, bias)
-        out = SparseConvTensor(y[:n_out], out_idx, oshape, inp.batch_size)
+        y = self._apply(feats, nbr, n_out, 27, grad)
+        out = SparseConvTensor(y, out_idx, oshape, inp.batch_size)
         out.indice_dict = inp.indice_dict
         out._table = otable if not self.subm else inp._table
         return out

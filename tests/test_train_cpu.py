@@ -1,0 +1,134 @@
+"""Training-side host logic (sassd.train_ops + the loss / target methods of the heads) against golden vectors produced
+by the reference's own Python (tests/golden/make_golden_train.py -> train_fns.npz).  CPU only: these are torch
+elementwise / indexing mirrors; the HIP kernels they sit on are covered by the -m gpu tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sassd  # noqa: F401
+from sassd import train_ops as T
+from sassd.config import ConfigDict
+from sassd.detector import PSWarpHead, SpMiddleFHD, SSDRotateHead
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_fns.npz"))
+
+
+def t(name):
+    return torch.from_numpy(G[name])
+
+
+def close(a, b, tol=1e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
+def test_losses():
+    close(T.weighted_sigmoid_focal_loss(t("fl_pred"), t("fl_target"), t("fl_weight"), avg_factor=1.), G["fl_avg1"])
+    close(T.weighted_sigmoid_focal_loss(t("fl_pred"), t("fl_target"), t("fl_weight")), G["fl_default"])
+    close(T.weighted_smoothl1(t("sl_pred"), t("sl_target"), t("sl_weight"), beta=1 / 9., avg_factor=1.),
+          G["sl_beta9"])
+    close(T.weighted_smoothl1(t("sl_pred"), t("sl_target"), t("sl_weight").expand(200, 7).contiguous()),
+          G["sl_default"])
+    close(T.weighted_cross_entropy(t("ce_logits"), t("ce_labels"), t("ce_weight"), avg_factor=1.), G["ce_avg1"])
+    close(T.weighted_cross_entropy(t("ce_logits"), t("ce_labels"), t("ce_weight")), G["ce_default"])
+
+
+def test_similarity_and_encode():
+    anchors, gt = t("anchors"), t("gt")
+    close(T.NearestIouSimilarity()(anchors[::37], gt), G["near_iou"], 1e-6)
+    enc = T.second_box_encode(gt[torch.arange(400) % 9], anchors[1000:1400])
+    close(enc, G["encode"], 1e-6)
+    close(T.second_box_decode(enc, anchors[1000:1400]), gt[torch.arange(400) % 9].numpy(), 1e-5)   # round trip
+
+
+@pytest.mark.parametrize("case", ["masked", "nomask", "nogt"])
+def test_create_target(case):
+    anchors, gt = t("anchors"), t("gt")
+    gmask = torch.tensor([1, 1, 0, 1, 1, 1, 0, 1, 1], dtype=torch.bool)
+    am, gm, gb = dict(masked=(t("anchor_mask"), gmask, gt), nomask=(None, None, gt),
+                      nogt=(t("anchor_mask"), None, gt[:0]))[case]
+    lab, tar, mx = T.create_target_torch(anchors, am, gb, torch.ones(len(gb), dtype=torch.int64), gm,
+                                         similarity_fn=T.NearestIouSimilarity(), box_encoding_fn=T.second_box_encode,
+                                         matched_threshold=0.6, unmatched_threshold=0.45, box_code_size=7)
+    assert np.array_equal(lab.numpy(), G["ct_%s_labels" % case])          # integer work: exact
+    close(tar, G["ct_%s_targets" % case], 1e-6)
+    close(mx, G["ct_%s_max" % case], 1e-6)
+    if case != "nogt":
+        assert (lab > 0).sum() > 0
+
+
+def _rpn_inputs():
+    anc = dict(Car=torch.stack([t("anchors"), t("a2")]))
+    msk = dict(Car=torch.stack([t("anchor_mask"), t("m2")]))
+    gtb = [t("gt"), t("gt2")]
+    gtl = [torch.ones(9, dtype=torch.int64), torch.ones(6, dtype=torch.int64)]
+    gtt = [np.array(["Car"] * 9), np.array(["Car"] * 5 + ["Van"])]
+    return anc, msk, gtb, gtl, gtt
+
+
+def test_rpn_loss_and_gradients():
+    head = SSDRotateHead(num_class=1, num_output_filters=8, num_anchor_per_loc=2, box_code_size=7)
+    anc, msk, gtb, gtl, gtt = _rpn_inputs()
+    box, cls, dr = (t(k).clone().requires_grad_() for k in ("rpn_box", "rpn_cls", "rpn_dir"))
+    cfg = ConfigDict(assigner=ConfigDict(Car=ConfigDict(pos_iou_thr=0.6, neg_iou_thr=0.45, min_pos_iou=0.45),
+                                         ignore_iof_thr=-1, similarity_fn="NearestIouSimilarity"), anchor_thr=0.1)
+    ls = head.loss(box, cls, dr, gtb, gtl, gtt, anc, msk, cfg)
+    for k in ("rpn_loc_loss", "rpn_cls_loss", "rpn_dir_loss"):
+        close(ls[k].detach(), G[k], 2e-6)
+    tot = ls["rpn_loc_loss"] + ls["rpn_cls_loss"] + ls["rpn_dir_loss"]
+    gb, gc, gd = torch.autograd.grad(tot.sum(), [box, cls, dr])
+    close(gb, G["rpn_gbox"], 1e-6)
+    close(gc, G["rpn_gcls"], 1e-6)
+    close(gd, G["rpn_gdir"], 1e-6)
+
+
+def test_guided_anchors_train_mode():
+    head = SSDRotateHead(num_class=1, num_output_filters=8, num_anchor_per_loc=2, box_code_size=7)
+    anc, msk, gtb, gtl, _ = _rpn_inputs()
+    guided, labels = head.get_guided_anchors(t("rpn_box"), t("rpn_cls"), t("rpn_dir"), anc, msk, gtb, gtl, thr=0.1)
+    for i in range(2):
+        assert guided[i].shape == G["guided%d" % i].shape
+        close(guided[i], G["guided%d" % i], 1e-6)
+        assert np.array_equal(labels[i].numpy(), G["guided_labels%d" % i])
+        close(guided[i][:len(gtb[i])], gtb[i].numpy(), 0)                  # ground truth is prepended
+
+
+def test_aux_loss_arithmetic():
+    neck = SpMiddleFHD.__new__(SpMiddleFHD)
+    neck.build_aux_target = lambda pts, gt: (t("aux_labels"), t("aux_offsets"))
+    ls = SpMiddleFHD.aux_loss(neck, None, t("aux_cls"), t("aux_reg"), [None, None])
+    close(ls["aux_loss_cls"], G["aux_loss_cls"], 2e-6)
+    close(ls["aux_loss_reg"], G["aux_loss_reg"], 2e-6)
+
+
+def test_rescoring_loss_with_reference_iou():
+    """PSWarpHead.loss arithmetic on CPU: the rotated 3-D IoU is an input here (taken from the CPU oracle); the HIP
+    overlap kernel itself is checked in the -m gpu suite."""
+    from oracle import clib
+    import sassd.iou3d_utils as iu
+
+    class OracleIou3d:
+        def __call__(self, a, b):
+            ov = torch.from_numpy(clib.boxes_overlap_bev(iu.boxes3d_to_bev_torch(a).numpy(),
+                                                         iu.boxes3d_to_bev_torch(b).numpy()))
+            oh = torch.clamp(torch.min((a[:, 2] + a[:, 5]).view(-1, 1), (b[:, 2] + b[:, 5]).view(1, -1))
+                             - torch.max(a[:, 2].view(-1, 1), b[:, 2].view(1, -1)), min=0)
+            o3 = ov * oh
+            va = (a[:, 3] * a[:, 4] * a[:, 5]).view(-1, 1)
+            vb = (b[:, 3] * b[:, 4] * b[:, 5]).view(1, -1)
+            return o3 / torch.clamp(va + vb - o3, min=1e-7)
+    close(OracleIou3d()(t("anchors")[::37].contiguous(), t("gt")), G["rot_iou3d"], 1e-5)
+    T.OracleIou3d = OracleIou3d
+    try:
+        ext = PSWarpHead(grid_offsets=(0., 40.), featmap_stride=.4, in_channels=8, num_class=1, num_parts=28)
+        gsub = [t("guided0")[:600].contiguous(), t("guided1")[:500].contiguous()]
+        score = t("ext_score").clone().requires_grad_()
+        cfg = ConfigDict(assigner=ConfigDict(pos_iou_thr=0.7, neg_iou_thr=0.7, similarity_fn="OracleIou3d"))
+        loss = ext.loss(score, [t("gt"), t("gt2")], None, gsub, cfg)["loss_cls"]
+        close(loss.detach(), G["ext_loss"], 1e-5)
+        close(torch.autograd.grad(loss.sum(), score)[0], G["ext_gscore"], 1e-5)
+    finally:
+        del T.OracleIou3d

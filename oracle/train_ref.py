@@ -1,0 +1,300 @@
+"""CPU oracle of ONE SA-SSD training step (TEST INFRASTRUCTURE ONLY -- never imported by the product).
+
+A plain torch-CPU fp32 restatement with autograd of what the reference computes in
+mmdet/models/detectors/single_stage.py:75-108 (forward_train), following
+
+  VxNet / BEVNet / aux head, train-mode BN     mmdet/models/necks/cmn.py:106-135,192-282
+  aux targets + aux loss                       cmn.py:45-104
+  tensor2points                                mmdet/core/bbox/transforms.py:218-223
+  anchor targets                               mmdet/core/bbox3d/target_ops.py:139-277
+  nearest / rotated-3D similarity              mmdet/ops/iou3d/iou3d_utils.py:9-45,79-111
+  rpn loss, guided anchors (GT prepended)      mmdet/models/single_stage_heads/ssd_rotate_head.py:128-388
+  PSWarp forward + rescoring loss              ssd_rotate_head.py:431-490
+  focal / smooth-L1 / CE                       mmdet/core/loss/losses.py:13-96
+
+It is written independently of sassd.train_ops (numpy target assignment, closed-form losses) and pinned against the
+same reference-generated golden vectors (tests/test_train_cpu.py::test_train_ref_pieces_pinned).  Sparse convolutions gather
+through the oracle rulebooks, 3-NN / point-in-box / rotated overlap come from oracle/sassd_oracle.c.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import clib
+from . import nets
+from . import rulebook as rb
+
+EPS = 1e-3
+
+
+# ---- layers (train mode: batch statistics) ------------------------------------------------------------------------
+def bn_train(x, w, b):
+    dims = [0] + list(range(2, x.dim()))
+    shp = (1, -1) + (1,) * (x.dim() - 2)
+    mu = x.mean(dims, keepdim=True)
+    var = ((x - mu) ** 2).mean(dims, keepdim=True)
+    return (x - mu) / torch.sqrt(var + EPS) * w.view(shp) + b.view(shp)
+
+
+def gather_conv(x, nbr, w):
+    """y[o] = sum_k x[nbr[o,k]] @ w[k]; -1 entries read a zero row."""
+    n = x.shape[0]
+    xp = torch.cat([x, x.new_zeros(1, x.shape[1])], 0)
+    idx = torch.as_tensor(np.where(nbr < 0, n, nbr), dtype=torch.int64)
+    y = x.new_zeros(nbr.shape[0], w.shape[2])
+    for k in range(nbr.shape[1]):
+        if (nbr[:, k] >= 0).any():
+            y = y + xp[idx[:, k]] @ w[k]
+    return y
+
+
+# ---- losses ---------------------------------------------------------------------------------------------------------
+def focal_sum(x, t, w, gamma=2.0, alpha=0.25):
+    p = torch.sigmoid(x)
+    ce = torch.clamp(x, min=0) - x * t + torch.log1p(torch.exp(-torch.abs(x)))
+    mod = ((1 - p) * t + p * (1 - t)) ** gamma
+    return (ce * mod * (alpha * t + (1 - alpha) * (1 - t)) * w).sum()
+
+
+def smooth_l1_sum(a, b, w, beta):
+    d = (a - b).abs()
+    return (torch.where(d < beta, d * d * (0.5 / beta), d - 0.5 * beta) * w).sum()
+
+
+# ---- similarity + target assignment (numpy, fp32) -------------------------------------------------------------------
+def near_boxes(b):
+    b = np.asarray(b, np.float32)
+    r = b[:, 6]
+    lim = np.abs(r - np.floor(r / np.float32(math.pi) + np.float32(0.5)) * np.float32(math.pi))
+    swap = lim > np.float32(math.pi / 4)
+    w = np.where(swap, b[:, 4], b[:, 3])
+    l = np.where(swap, b[:, 3], b[:, 4])
+    return np.stack([b[:, 0] - w / 2, b[:, 1] - l / 2, b[:, 0] + w / 2, b[:, 1] + l / 2], 1).astype(np.float32)
+
+
+def nearest_iou(a, b):
+    a, b = near_boxes(a), near_boxes(b)
+    lt = np.maximum(a[:, None, :2], b[None, :, :2])
+    br = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(br - lt, 0, None)
+    ov = wh[..., 0] * wh[..., 1]
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return ov / (aa[:, None] + ab[None] - ov)
+
+
+def rotated_iou3d(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    ov = clib.boxes_overlap_bev(nets.boxes3d_to_bev(torch.from_numpy(a)).numpy(),
+                                nets.boxes3d_to_bev(torch.from_numpy(b)).numpy())
+    top = np.minimum((a[:, 2] + a[:, 5])[:, None], (b[:, 2] + b[:, 5])[None])
+    bot = np.maximum(a[:, 2][:, None], b[:, 2][None])
+    o3 = ov * np.clip(top - bot, 0, None)
+    va = (a[:, 3] * a[:, 4] * a[:, 5])[:, None]
+    vb = (b[:, 3] * b[:, 4] * b[:, 5])[None]
+    return o3 / np.clip(va + vb - o3, np.float32(1e-7), None)
+
+
+def box_encode(g, a):
+    g, a = np.asarray(g, np.float32), np.asarray(a, np.float32)
+    diag = np.sqrt(a[:, 4] ** 2 + a[:, 3] ** 2)
+    zg, za = g[:, 2] + g[:, 5] / 2, a[:, 2] + a[:, 5] / 2
+    return np.stack([(g[:, 0] - a[:, 0]) / diag, (g[:, 1] - a[:, 1]) / diag, (zg - za) / a[:, 5],
+                     np.log(g[:, 3] / a[:, 3]), np.log(g[:, 4] / a[:, 4]), np.log(g[:, 5] / a[:, 5]),
+                     g[:, 6] - a[:, 6]], 1).astype(np.float32)
+
+
+def assign(all_anchors, mask, gt, gt_cls, pos_thr, neg_thr, sim):
+    """-> labels [A] int64 (-1 ignore / 0 negative / class), targets [A,7], per-anchor best overlap (masked rows)."""
+    all_anchors = np.asarray(all_anchors, np.float32)
+    sel = np.arange(len(all_anchors)) if mask is None else np.nonzero(np.asarray(mask))[0]
+    anc = all_anchors[sel]
+    n = len(anc)
+    lab = np.full(n, -1, np.int64)
+    tar = np.zeros((n, 7), np.float32)
+    best = np.zeros(n, np.float32)
+    if len(gt) and n:
+        ov = sim(anc, gt)
+        arg = ov.argmax(1)
+        best = ov[np.arange(n), arg]
+        gmax = ov.max(0)
+        gmax = np.where(gmax == 0, np.float32(-1), gmax)
+        forced = np.nonzero((ov == gmax[None]).any(1))[0]
+        lab[best >= pos_thr] = gt_cls[arg[best >= pos_thr]]
+        lab[best < neg_thr] = 0
+        lab[forced] = gt_cls[arg[forced]]
+        fg = np.nonzero(lab > 0)[0]
+        tar[fg] = box_encode(gt[arg[fg]], anc[fg])
+    else:
+        lab[:] = 0
+    full_l = np.full(len(all_anchors), -1, np.int64)
+    full_t = np.zeros((len(all_anchors), 7), np.float32)
+    full_l[sel], full_t[sel] = lab, tar
+    return full_l, full_t, best
+
+
+# ---- the step ---------------------------------------------------------------------------------------------------------
+VX = [("conv0.0", "conv0.1", "subm", "subm0"), ("conv0.3", "conv0.4", "subm", "subm0"),
+      ("down0.0", "down0.1", "down", None),
+      ("conv1.0", "conv1.1", "subm", "subm1"), ("conv1.3", "conv1.4", "subm", "subm1"),
+      ("down1.0", "down1.1", "down", None),
+      ("conv2.0", "conv2.1", "subm", "subm2"), ("conv2.3", "conv2.4", "subm", "subm2"),
+      ("conv2.6", "conv2.7", "subm", "subm2"),
+      ("down2.0", "down2.1", "down", None),
+      ("conv3.0", "conv3.1", "subm", "subm3"), ("conv3.3", "conv3.4", "subm", "subm3"),
+      ("conv3.6", "conv3.7", "subm", "subm3"),
+      ("extra_conv.0", "extra_conv.1", "1x1", None)]
+
+
+def decode(enc, a):
+    za = a[..., 2] + a[..., 5] / 2
+    diag = torch.sqrt(a[..., 4] ** 2 + a[..., 3] ** 2)
+    w, l, h = torch.exp(enc[..., 3]) * a[..., 3], torch.exp(enc[..., 4]) * a[..., 4], torch.exp(enc[..., 5]) * a[..., 5]
+    return torch.stack([enc[..., 0] * diag + a[..., 0], enc[..., 1] * diag + a[..., 1],
+                        enc[..., 2] * a[..., 5] + za - h / 2, w, l, h, enc[..., 6] + a[..., 6]], -1)
+
+
+def train_step(sd, feats, coors, batch_size, sparse_shape, gt_bboxes, gt_types, class_names, anchors, anchors_mask,
+               assign_cfg, anchor_thr=0.1, extra_thr=0.7, grid_offsets=(0., 40.), featmap_stride=0.4):
+    """sd: detector state_dict (CPU tensors); feats [N,4] voxel means; coors [N,4] (b,z,y,x); gt_bboxes: list of
+    [G,7]; gt_types: list of str arrays; anchors / anchors_mask: {class: [B, A, 7] / [B, A]};
+    assign_cfg: {class: (pos_thr, neg_thr)}.  Returns (losses {name: float}, grads {param name: tensor},
+    extras)."""
+    P = {k: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+         for k, v in sd.items() if torch.is_tensor(v) and v.dtype.is_floating_point}
+    B = batch_size
+    x = torch.as_tensor(feats, dtype=torch.float32)
+    idx = np.asarray(coors, np.int32)
+    shape = tuple(sparse_shape)
+    books, middle = {}, []
+    for wn, bn, kind, key in VX:
+        w = P["neck.backbone.%s.weight" % wn]
+        if kind == "subm":
+            if key not in books:
+                books[key] = rb.subm_rulebook(idx, shape)[1]
+            x = gather_conv(x, books[key], w.reshape(27, w.shape[3], w.shape[4]))
+        elif kind == "down":
+            oi, nbr, oshape = rb.conv_rulebook(idx, shape, B)
+            x = gather_conv(x, nbr, w.reshape(27, w.shape[3], w.shape[4]))
+            idx, shape = oi, oshape
+        else:
+            x = x @ w.reshape(w.shape[3], w.shape[4])
+        x = torch.relu(bn_train(x, P["neck.backbone.%s.weight" % bn], P["neck.backbone.%s.bias" % bn]))
+        if wn in ("conv1.3", "conv2.6", "conv3.6"):
+            middle.append((x, idx.copy()))
+    d, h, w_ = shape
+    dense = x.new_zeros(B, d, h, w_, x.shape[1])
+    ii = torch.as_tensor(idx, dtype=torch.int64)
+    dense = dense.index_put((ii[:, 0], ii[:, 1], ii[:, 2], ii[:, 3]), x)
+    y = dense.permute(0, 4, 1, 2, 3).reshape(B, -1, h, w_)
+    conv6 = None
+    for i in range(8):
+        wt = P["neck.fcn.conv%d.weight" % i]
+        y = F.conv2d(y, wt, None, 1, 1 if wt.shape[-1] == 3 else 0)
+        y = torch.relu(bn_train(y, P["neck.fcn.bn%d.weight" % i], P["neck.fcn.bn%d.bias" % i]))
+        if i == 6:
+            conv6 = y
+    losses = {}
+    # -- auxiliary head
+    fe = torch.as_tensor(feats, dtype=torch.float32)
+    pm = np.concatenate([np.asarray(coors, np.float32)[:, :1], np.asarray(feats, np.float32)[:, :3]], 1)
+    ps = []
+    for (mf, mi), vs in zip(middle, ((.1, .1, .2), (.2, .2, .4), (.4, .4, .8))):
+        vsz, off = np.asarray(vs, np.float32), np.asarray((0., -40., -3.), np.float32)
+        known = mi.astype(np.float32)
+        known[:, 1:] = mi[:, [3, 2, 1]].astype(np.float32) * vsz + off + np.float32(.5) * vsz
+        d2, nn = clib.three_nn(pm, known)
+        rec = 1.0 / (torch.sqrt(torch.from_numpy(d2)) + 1e-8)
+        wgt = rec / rec.sum(1, keepdim=True)
+        nn = torch.from_numpy(nn.astype(np.int64))
+        ps.append((mf[nn] * wgt[..., None]).sum(1))
+    pw = torch.cat(ps, -1) @ P["neck.point_fc.weight"].t()
+    pcls, preg = pw @ P["neck.point_cls.weight"].t(), pw @ P["neck.point_reg.weight"].t()
+    labs, offs = [], []
+    for b in range(B):
+        pts = pm[pm[:, 0] == b, 1:]
+        if len(gt_bboxes[b]) and len(pts):
+            flag, reg = clib.pts_in_boxes3d(pts, np.asarray(gt_bboxes[b], np.float32))
+            labs.append(flag.max(0).astype(np.float32))
+            offs.append(reg)
+        else:
+            labs.append(np.zeros(len(pts), np.float32))
+            offs.append(np.zeros((len(pts), 3), np.float32))
+    lab, off = torch.from_numpy(np.concatenate(labs)), torch.from_numpy(np.concatenate(offs))
+    norm = torch.clamp((lab > 0).float().sum(), min=1.0)
+    losses["aux_loss_cls"] = focal_sum(pcls.view(-1), lab, torch.ones_like(lab) / norm) / B
+    losses["aux_loss_reg"] = smooth_l1_sum(preg, off, ((lab > 0).float() / norm)[:, None], 1 / 9.) / B
+    # -- rpn head
+    nc = len(class_names)
+    outs = []
+    for n in ("conv_box", "conv_cls", "conv_dir_cls"):
+        o = F.conv2d(y, P["rpn_head.%s.weight" % n], P["rpn_head.%s.bias" % n])
+        outs.append(o.view(B, nc, -1, h, w_).permute(0, 1, 3, 4, 2))
+    box, cls, dr = outs[0].reshape(B, -1, 7), outs[1].reshape(B, -1, nc), outs[2].reshape(B, -1, 2)
+    L, Tg = [], []
+    for c in class_names:
+        lc, tc = [], []
+        for b in range(B):
+            gm = np.asarray(gt_types[b]) == c
+            l_, t_, _ = assign(anchors[c][b], anchors_mask[c][b], np.asarray(gt_bboxes[b], np.float32)[gm],
+                               np.full(int(gm.sum()), class_names.index(c) + 1, np.int64), assign_cfg[c][0],
+                               assign_cfg[c][1], nearest_iou)
+            lc.append(l_)
+            tc.append(t_)
+        L.append(np.stack(lc))
+        Tg.append(np.stack(tc))
+    labels = torch.from_numpy(np.stack(L, 1).reshape(B, -1))
+    targets = torch.from_numpy(np.stack(Tg, 1).reshape(B, -1, 7))
+    anc_all = torch.cat([torch.as_tensor(anchors[c], dtype=torch.float32) for c in class_names], 1).view(B, -1, 7)
+    msk_all = torch.cat([torch.as_tensor(anchors_mask[c]).bool() for c in class_names], 1).view(B, -1)
+    pos = (labels > 0).float()
+    pn = torch.clamp(pos.sum(1, keepdim=True), min=1.0)
+    cw, rw = (labels >= 0).float() / pn, pos / pn
+    onehot = torch.zeros(B, labels.shape[1], nc)
+    for c in range(nc):
+        onehot[..., c] = (labels == c + 1).float()
+    bp = torch.cat([box[..., :6], torch.sin(box[..., 6:]) * torch.cos(targets[..., 6:])], -1)
+    tp = torch.cat([targets[..., :6], torch.cos(box[..., 6:]) * torch.sin(targets[..., 6:])], -1)
+    losses["rpn_loc_loss"] = smooth_l1_sum(bp, tp, rw[..., None], 1 / 9.) / B * 2
+    losses["rpn_cls_loss"] = focal_sum(cls, onehot, cw[..., None]) / B
+    dlab = ((targets[..., 6] + anc_all[..., 6]) > 0).long().view(-1)
+    dwt = (pos / torch.clamp(pos.sum(-1, keepdim=True), min=1.0)).view(-1)
+    losses["rpn_dir_loss"] = (F.cross_entropy(dr.reshape(-1, 2), dlab, reduction="none") * dwt).sum() / B * .2
+    # -- guided anchors (+ ground truth) and the part-sensitive rescoring loss
+    dec = decode(box, anc_all)
+    f = F.conv2d(conv6, P["extra_head.convs.0.weight"], None, 1, 1)
+    f = torch.relu(bn_train(f, P["extra_head.convs.1.weight"], P["extra_head.convs.1.bias"]))
+    f = F.conv2d(f, P["extra_head.convs.3.weight"], None)
+    scores, elabels, guided_all = [], [], []
+    for b in range(B):
+        m = msk_all[b]
+        bx, sc, dl = dec[b][m], torch.sigmoid(cls[b][m]), dr[b][m].argmax(-1)
+        top = sc.squeeze(-1) if nc == 1 else sc.max(-1)[0]
+        s = top > anchor_thr
+        bx, dl = bx[s], dl[s]
+        flip = ((bx[:, 6] > 0) ^ dl.bool()).float()
+        bx = torch.cat([bx[:, :6], (bx[:, 6] + flip * math.pi)[:, None]], 1)
+        ga = torch.cat([torch.as_tensor(gt_bboxes[b], dtype=torch.float32), bx], 0)
+        guided_all.append(ga.detach())
+        n = ga.shape[0]
+        ct, st = torch.cos(ga[:, 6]).view(n, 1, 1), torch.sin(ga[:, 6]).view(n, 1, 1)
+        xx = torch.linspace(-.5, .5, 4).view(1, 4, 1) * ga[:, 3].view(n, 1, 1)
+        yy = torch.linspace(-.5, .5, 7).view(1, 1, 7) * ga[:, 4].view(n, 1, 1)
+        sx = (xx * ct + yy * st + ga[:, 0].view(n, 1, 1) + grid_offsets[0]) / featmap_stride
+        sy = (yy * ct - xx * st + ga[:, 1].view(n, 1, 1) + grid_offsets[1]) / featmap_stride
+        g = torch.stack([sx.reshape(n, 28).t() / (w_ - 1), sy.reshape(n, 28).t() / (h - 1)], -1).view(28, n, 1, 2)
+        o = F.grid_sample(f[b].unsqueeze(1), g * 2 - 1, align_corners=True)
+        scores.append(o.mean(0).view(-1))
+        el, _, _ = assign(ga.detach().numpy(), None, np.asarray(gt_bboxes[b], np.float32),
+                          np.ones(len(gt_bboxes[b]), np.int64), extra_thr, extra_thr, rotated_iou3d)
+        elabels.append(el)
+    el = torch.from_numpy(np.concatenate(elabels))
+    ew = (el >= 0).float() / torch.clamp((el > 0).float().sum(), min=1.0)
+    losses["loss_cls"] = focal_sum(torch.cat(scores), (el > 0).float(), ew) / B
+    total = sum(losses.values())
+    names = [k for k, v in P.items() if v.requires_grad]
+    grads = torch.autograd.grad(total, [P[k] for k in names], allow_unused=True)
+    return ({k: float(v.detach()) for k, v in losses.items()}, dict(zip(names, grads)),
+            dict(guided=guided_all, labels=labels, ext_labels=el, box=box.detach(), cls=cls.detach()))

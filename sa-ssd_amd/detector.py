@@ -25,7 +25,7 @@ from . import kernels as K
 from . import spconv
 from . import train_ops as T
 from .autograd import Conv2dFn, PSWarpFn
-from .config import obj_from_dict
+from .config import _wrap, obj_from_dict
 from .pipeline import InferencePlan
 from .pointnet2_utils import nearest_neighbor_interpolate
 
@@ -420,7 +420,7 @@ class SingleStageDetector(nn.Module):
             self.rpn_head = obj_from_dict(bbox_head, me)
         if extra_head is not None:
             self.extra_head = obj_from_dict(extra_head, me)
-        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.train_cfg, self.test_cfg = _wrap(train_cfg), _wrap(test_cfg)
         self.class_names = None
         self._plan, self._plan_key = None, None
         self._cfg = dict(num_class=bbox_head.get('num_class', 1) if bbox_head else 1,

@@ -88,7 +88,7 @@ class SparseConvolution(nn.Module):
             self._packed_version = v
         return self._packed
 
-    def _apply(self, feats, nbr, n_out, k, grad):
+    def _conv(self, feats, nbr, n_out, k, grad):
         """Raw conv (+bias) over a gather table: autograd-recording HIP path when gradients are wanted."""
         cin, cout = self.in_channels, self.out_channels
         if grad:
@@ -106,7 +106,7 @@ class SparseConvolution(nn.Module):
         grad = torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad)
         if self.conv1x1:
             # spconv shortcut: features @ weight.view(Cin, Cout), indices unchanged
-            y = self._apply(feats, None, n, 1, grad)
+            y = self._conv(feats, None, n, 1, grad)
             out = SparseConvTensor(y, inp.indices, inp.spatial_shape, inp.batch_size)
             out.indice_dict, out._table = inp.indice_dict, inp._table
             return out
@@ -135,7 +135,7 @@ class SparseConvolution(nn.Module):
                     inp.indice_dict[self.indice_key] = book
             out_idx, nbr, oshape, otable = book
             n_out = out_idx.shape[0]
-        y = self._apply(feats, nbr, n_out, 27, grad)
+        y = self._conv(feats, nbr, n_out, 27, grad)
         out = SparseConvTensor(y, out_idx, oshape, inp.batch_size)
         out.indice_dict = inp.indice_dict
         out._table = otable if not self.subm else inp._table

@@ -132,3 +132,23 @@ def test_rescoring_loss_with_reference_iou():
         close(torch.autograd.grad(loss.sum(), score)[0], G["ext_gscore"], 1e-5)
     finally:
         del T.OracleIou3d
+
+
+# ---- the CPU training oracle's own restatements, pinned on the same reference-generated vectors -------------------
+def test_train_ref_pieces_pinned():
+    from oracle import train_ref as R
+    anchors, gt = G["anchors"], G["gt"]
+    close(R.nearest_iou(anchors[::37], gt), G["near_iou"], 1e-6)
+    close(R.rotated_iou3d(anchors[::37], gt), G["rot_iou3d"], 1e-5)
+    close(R.box_encode(gt[np.arange(400) % 9], anchors[1000:1400]), G["encode"], 1e-6)
+    gmask = np.array([1, 1, 0, 1, 1, 1, 0, 1, 1], bool)
+    for case, (am, g_) in dict(masked=(G["anchor_mask"], gt[gmask]), nomask=(None, gt),
+                               nogt=(G["anchor_mask"], gt[:0])).items():
+        lab, tar, mx = R.assign(anchors, am, g_, np.ones(len(g_), np.int64), 0.6, 0.45, R.nearest_iou)
+        assert np.array_equal(lab, G["ct_%s_labels" % case]), case
+        close(tar, G["ct_%s_targets" % case], 1e-6)
+        close(mx, G["ct_%s_max" % case], 1e-6)
+    close(R.focal_sum(t("fl_pred"), t("fl_target"), t("fl_weight")).view(1), G["fl_avg1"], 2e-6)
+    close(R.smooth_l1_sum(t("sl_pred"), t("sl_target"), t("sl_weight"), 1 / 9.).view(1), G["sl_beta9"], 2e-6)
+    enc = torch.from_numpy(G["encode"])
+    close(R.decode(enc, torch.from_numpy(anchors[1000:1400])), gt[np.arange(400) % 9], 1e-5)

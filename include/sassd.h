@@ -225,6 +225,20 @@ int sassd_three_interpolate_grad(int c, int n, int m, const float *grad_out, con
 int sassd_pts_in_boxes3d(const float *pts, int n, const float *boxes3d, int m, int32_t *pts_flag,
                          float *reg_target, void *stream);
 
+/* ---- training: parameter update ------------------------------------------------------------------------------------
+ * Replaces tools/train_utils/__init__.py:57-61 (clip_grad_norm_ + optimizer.step) for optimizer type 'adam_onecycle'
+ * (tools/train_utils/optimization/__init__.py:17-30, fastai_optim.py:132-148): decoupled weight decay on every
+ * parameter, then Adam(betas=(mom, 0.99), eps, weight_decay=0) -- over one flat fp32 buffer.
+ * sassd_grad_sumsq: out[0] = sum(grad^2) (device float, zeroed by the call).
+ * sassd_adam_step:  g' = grad * grad_scale * min(1, max_norm / (sqrt(sumsq) * grad_scale + 1e-6)) when grad_sumsq is
+ *                   non-NULL and max_norm > 0 (torch clip_grad_norm_ semantics), else grad * grad_scale;
+ *                   p *= 1 - wd*lr; m,v Adam moments; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+ *                   `step` is t >= 1.  All pointers 16-byte aligned. */
+int sassd_grad_sumsq(const float *grad, long n, float *out, void *stream);
+int sassd_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n,
+                    const float *grad_sumsq, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    int step, float max_norm, float grad_scale, void *stream);
+
 /* Hardware self-test helper used by tests: D = A(32x2k) * B(2k x32) through v_mfma_f32_32x32x2_f32 and
  * D = A(16x4k) * B(4k x16) through v_mfma_f32_16x16x4_f32 with the lane maps the kernels assume. */
 int sassd_mfma_probe(const float *a32, const float *b32, float *d32, const float *a16, const float *b16,

@@ -415,3 +415,21 @@ def mfma_probe(a32, b32, a16, b16, ksteps):
                                    ksteps, _C.stream())
     _C.check(rc, "sassd_mfma_probe")
     return d32, d16
+
+
+def grad_sumsq(grad_flat, out=None):
+    """sum(grad^2) of a flat fp32 buffer -> device float [1] (no host sync)."""
+    _chk_cuda(grad_flat)
+    out = torch.empty(1, dtype=torch.float32, device=grad_flat.device) if out is None else out
+    _C.check(_C.lib().sassd_grad_sumsq(_C.ptr(grad_flat), grad_flat.numel(), _C.ptr(out), _C.stream()),
+             "sassd_grad_sumsq")
+    return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, sumsq, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.0,
+              grad_scale=1.0):
+    """In-place fused clip + decoupled weight decay + Adam update over flat fp32 buffers."""
+    _chk_cuda(param, grad, exp_avg, exp_avg_sq)
+    _C.check(_C.lib().sassd_adam_step(_C.ptr(param), _C.ptr(grad), _C.ptr(exp_avg), _C.ptr(exp_avg_sq),
+                                      param.numel(), _C.ptr(sumsq), lr, beta1, beta2, eps, weight_decay, int(step),
+                                      max_norm, grad_scale, _C.stream()), "sassd_adam_step")

@@ -1,0 +1,199 @@
+"""Training loop pieces for the hot path, MI355X-first (SURVEY 8e + tools/train.py, tools/train_utils/__init__.py):
+
+  * FlatParams      every parameter (and its gradient) is a view into ONE contiguous fp32 buffer, so the DDP exchange
+                    is a single RCCL all-reduce over the whole 21 MB model (8e: "bucket = whole model"), gradient
+                    clipping is one reduction and the update one streaming kernel.
+  * OneCycle        tools/train_utils/optimization/learning_schedules_fastai.py:9-78 (cosine lr / momentum phases).
+  * AdamOneCycle    optimizer type 'adam_onecycle' (optimization/__init__.py:17-30; fastai_optim.py:101-148:
+                    Adam(betas=(mom, 0.99)), true weight decay on every group incl. BatchNorm) + clip_grad_norm_
+                    (train_utils/__init__.py:60) fused in sassd_grad_sumsq / sassd_adam_step.
+  * GradSync        one process per GPU; parameters broadcast from rank 0 once, gradients all-reduced (sum; the 1/world
+                    mean is folded into the update kernel's grad_scale).  BatchNorm stays per-GPU like the reference.
+  * train_one_iter / checkpoint_state / save / load   train_utils/__init__.py:36-66,120-170.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+
+
+class FlatParams:
+    def __init__(self, model):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.offsets, off = [], 0
+        for n in sizes:
+            self.offsets.append(off)
+            off += (n + 3) // 4 * 4                         # keep every view 16-byte aligned
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.data[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):        # autograd may have replaced a view; re-attach
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+def annealing_cos(start, end, pct):
+    return end + (start - end) / 2 * (math.cos(math.pi * pct) + 1)
+
+
+class OneCycle:
+    """lr: lr_max/div -> lr_max over the first pct_start of the steps, then -> lr_max/div/1e4; momentum mirrors it
+    between moms[0] and moms[1]."""
+
+    def __init__(self, optimizer, total_step, lr_max, moms, div_factor, pct_start):
+        self.optimizer, self.total_step = optimizer, total_step
+        low = lr_max / div_factor
+        cut = int(pct_start * total_step)
+        self.lr_phases = [(0, cut, (low, lr_max)), (cut, total_step, (lr_max, low / 1e4))]
+        self.mom_phases = [(0, cut, tuple(moms)), (cut, total_step, tuple(moms[::-1]))]
+        optimizer.lr, optimizer.mom = low, moms[0]
+
+    def values(self, step):
+        lr, mom = self.optimizer.lr, self.optimizer.mom
+        for (s, e, (a, b)), (_, _, (ma, mb)) in zip(self.lr_phases, self.mom_phases):
+            if step >= s:
+                lr, mom = annealing_cos(a, b, (step - s) / (e - s)), annealing_cos(ma, mb, (step - s) / (e - s))
+        return lr, mom
+
+    def step(self, step):
+        self.optimizer.lr, self.optimizer.mom = self.values(step)
+
+
+class AdamOneCycle:
+    def __init__(self, model, lr, weight_decay, beta2=0.99, eps=1e-8, grad_clip=None, world_size=1):
+        self.flat = model if isinstance(model, FlatParams) else FlatParams(model)
+        self.lr, self.mom, self.wd, self.beta2, self.eps = lr, 0.9, weight_decay, beta2, eps
+        self.max_norm = float(grad_clip["max_norm"]) if grad_clip else 0.0
+        if grad_clip and grad_clip.get("norm_type", 2) != 2:
+            raise NotImplementedError("only the L2 gradient-norm clip of the reference configs")
+        self.world_size = world_size
+        self.exp_avg = torch.zeros_like(self.flat.data)
+        self.exp_avg_sq = torch.zeros_like(self.flat.data)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.flat.data.device)
+        self.steps = 0
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def step(self):
+        self.steps += 1
+        sumsq = K.grad_sumsq(self.flat.grad, self.sumsq) if self.max_norm > 0 else None
+        K.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, sumsq, self.lr, self.mom,
+                    self.beta2, self.eps, self.wd, self.steps, self.max_norm, 1.0 / self.world_size)
+
+    def state_dict(self):
+        return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), steps=self.steps, lr=self.lr,
+                    mom=self.mom)
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.steps, self.lr, self.mom = sd["steps"], sd["lr"], sd["mom"]
+
+
+def build_optimizer(model, optim_cfg, world_size=1):
+    if optim_cfg["type"] != "adam_onecycle":
+        raise NotImplementedError("the SA-SSD configs train with 'adam_onecycle'")
+    return AdamOneCycle(model, optim_cfg["lr"], optim_cfg["weight_decay"], grad_clip=optim_cfg.get("grad_clip"),
+                        world_size=world_size)
+
+
+def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, optim_cfg, lr_cfg):
+    if lr_cfg["policy"] != "onecycle":
+        raise NotImplementedError("the SA-SSD configs use the 'onecycle' policy")
+    return OneCycle(optimizer, total_iters_each_epoch * total_epochs, optim_cfg["lr"], list(lr_cfg["moms"]),
+                    lr_cfg["div_factor"], lr_cfg["pct_start"])
+
+
+class GradSync:
+    """Data-parallel exchange over the flat buffers (RCCL over xGMI with backend 'nccl', gloo in CPU tests)."""
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if self.on:
+            dist.broadcast(flat.data, src=0)
+
+    def all_reduce_grads(self):
+        if self.on:
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+
+
+def parse_losses(losses):
+    """train_utils/__init__.py:8-25 without the per-term .item() host syncs: (total loss tensor, detached terms)."""
+    terms = {k: (v.mean() if torch.is_tensor(v) else sum(x.mean() for x in v)) for k, v in losses.items()}
+    total = sum(v for k, v in terms.items() if "loss" in k)
+    return total, {k: v.detach() for k, v in terms.items()}
+
+
+def train_one_iter(model, optimizer, scheduler, sync, batch, it):
+    """One iteration of train_one_epoch (train_utils/__init__.py:39-61)."""
+    scheduler.step(it)
+    model.train()
+    optimizer.zero_grad()
+    loss, terms = parse_losses(model(**batch))
+    loss.backward()
+    sync.all_reduce_grads()
+    optimizer.step()
+    return loss.detach(), terms
+
+
+def checkpoint_state(model, optimizer, epoch, it):
+    return dict(epoch=epoch, it=it, model_state={k: v.detach().cpu() for k, v in model.state_dict().items()},
+                optimizer_state={k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()})
+
+
+def save_checkpoint(state, filename):
+    torch.save(state, filename if filename.endswith(".pth") else filename + ".pth")
+
+
+def load_checkpoint(model, optimizer, filename, map_location="cpu"):
+    ck = torch.load(filename, map_location=map_location)
+    sd = model.state_dict()
+    for k, v in ck["model_state"].items():                  # copy in place: parameters are views of the flat buffer
+        sd[k].copy_(v)
+    if optimizer is not None and ck.get("optimizer_state"):
+        optimizer.load_state_dict(ck["optimizer_state"])
+    return ck.get("epoch", 0), ck.get("it", 0)
+
+
+def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, voxel_size, pc_range,
+                 max_points=5, max_voxels=20000, area_threshold=1):
+    """What KittiLiDAR.prepare_train_img + collate produce (kitti.py:212-262,333-343), built on the device from raw
+    points already in HBM: HIP voxelizer + HIP anchor mask.  points: list of [N,4] device tensors; gt_bboxes: list of
+    [G,7] device tensors; anchors: {class: [A,7] device}; anchors_bv: {class: [A,4] device}.
+    Returns the keyword arguments of SingleStageDetector.forward(return_loss=True)."""
+    vs, cr = list(voxel_size), list(pc_range)
+    w0 = int(round((cr[3] - cr[0]) / vs[0]))
+    h0 = int(round((cr[4] - cr[1]) / vs[1]))
+    kw = dict(img=None, img_meta=[dict(sample_idx=i) for i in range(len(points))], return_loss=True, voxels=[],
+              coordinates=[], num_points=[], anchors={c: [] for c in class_names},
+              anchors_mask={c: [] for c in class_names}, gt_bboxes=list(gt_bboxes), gt_labels=[],
+              gt_types=list(gt_types))
+    for b, p in enumerate(points):
+        r = K.voxelize(p, vs, cr, max_points, max_voxels, batch_idx=0, coors_cols=4, want_mean=False)
+        m = int(r["voxel_num"].item())                     # the reference API carries exact-size tensors
+        kw["voxels"].append(r["voxels"][:m])
+        kw["coordinates"].append(r["coors"][:m, 1:])
+        kw["num_points"].append(r["num_points"][:m])
+        zero = torch.zeros(1, dtype=torch.int32, device=p.device)
+        for c in class_names:
+            mask = K.anchor_mask(r["coors"], zero, r["voxel_num"], h0, w0, anchors_bv[c], vs, cr, area_threshold)
+            kw["anchors"][c].append(anchors[c])
+            kw["anchors_mask"][c].append(mask.bool())
+        names = list(class_names)
+        lab = [names.index(t) + 1 if t in names else 0 for t in gt_types[b]]
+        kw["gt_labels"].append(torch.tensor(lab, dtype=torch.int64, device=p.device))
+    return kw

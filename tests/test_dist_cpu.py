@@ -3,6 +3,8 @@ max-over-ranks timing and the host-side result gather.  The data path itself has
 import os
 import socket
 
+import numpy as np
+
 import torch
 import torch.multiprocessing as mp
 
@@ -52,3 +54,48 @@ def test_two_rank_frame_sharding_and_timing_reduction():
         assert o[3] == 11.0           # all frames accounted for
         gathered = sorted(x for part in o[4] for x in part)
         assert [g[0] for g in gathered] == list(range(11))
+
+
+def _grad_sync_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    import sassd  # noqa: F401
+    from sassd import dist as D, train
+    D.init("gloo")
+    torch.manual_seed(100 + rank)                                  # different initial weights per rank
+    m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3, bias=False))
+    flat = train.FlatParams(m)
+    sync = train.GradSync(flat)                                    # broadcast from rank 0
+    w0 = flat.data.clone()
+    flat.zero_grad()
+    x = torch.full((4, 6), float(rank + 1)) + torch.arange(24.).view(4, 6) * 0.01
+    m(x).pow(2).sum().backward()
+    local = flat.grad.clone()
+    sync.all_reduce_grads()
+    q.put((rank, w0.numpy(), local.numpy(), flat.grad.clone().numpy()))
+    D.barrier()
+
+
+def test_gradient_all_reduce_world2():
+    """DDP exchange of the training path over gloo, world size 2: one broadcast of the flat parameter buffer, one
+    all-reduce (sum) of the flat gradient buffer (the 1/world mean is applied inside the update kernel)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_grad_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, w0, local, red = q.get(timeout=180)
+        got[r] = (w0, local, red)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0][0], got[1][0])                    # identical parameters after the broadcast
+    assert not np.array_equal(got[0][1], got[1][1])                # different shards -> different local gradients
+    assert np.allclose(got[0][2], got[0][1] + got[1][1], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(got[0][2], got[1][2])

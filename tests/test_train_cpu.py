@@ -152,3 +152,32 @@ def test_train_ref_pieces_pinned():
     close(R.smooth_l1_sum(t("sl_pred"), t("sl_target"), t("sl_weight"), 1 / 9.).view(1), G["sl_beta9"], 2e-6)
     enc = torch.from_numpy(G["encode"])
     close(R.decode(enc, torch.from_numpy(anchors[1000:1400])), gt[np.arange(400) % 9], 1e-5)
+
+
+def test_onecycle_schedule_matches_reference():
+    from sassd import train
+    O = np.load(os.path.join(os.path.dirname(__file__), "golden", "optim_ref.npz"))
+
+    class Opt:
+        lr = mom = None
+    o = Opt()
+    s = train.OneCycle(o, 20, 0.003, [0.95, 0.85], 10, 0.4)
+    for it in range(20):
+        s.step(it)
+        assert abs(o.lr - O["lr"][it]) < 1e-12 and abs(o.mom - O["mom"][it]) < 1e-12, it
+
+
+def test_flat_params_views():
+    from sassd import train
+    m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3, bias=False))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    f = train.FlatParams(m)
+    assert f.numel % 4 == 0 and all(o % 4 == 0 for o in f.offsets)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    m(torch.randn(4, 6)).sum().backward()
+    assert f.grad.abs().sum() > 0 and m[0].weight.grad.data_ptr() == f.grad.data_ptr()
+    f.data.mul_(2.0)
+    assert torch.equal(m[0].weight, before["0.weight"] * 2)
+    f.zero_grad()
+    assert float(m[2].weight.grad.abs().sum()) == 0

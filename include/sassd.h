@@ -218,6 +218,16 @@ int sassd_nms_gpu(const float *boxes, int n, float thresh, int64_t *keep, int32_
  * ---------------------------------------------------------------------------------------------- */
 int sassd_three_nn(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
                    void *stream);
+/* Exact accelerated variant: the known points are counting-sorted into a uniform BEV grid (batch, y, x) of
+ * `cell`-sized columns starting at (x0, y0) with nx * ny cells per batch element (coordinates outside are clamped
+ * into the border cells), and each query scans rings of cells until its 3rd best distance is provably final.
+ * Results are bit-identical to sassd_three_nn for ANY inputs (same ranking by (distance,row), same fp32 distance
+ * arithmetic); cost ~O((N+M) * points-per-neighbourhood) instead of O(N*M).  Batch indices must be 0..batch_size-1;
+ * nx*ny*batch_size <= 2^20. */
+size_t sassd_three_nn_binned_workspace_bytes(int m, int nx, int ny, int batch_size);
+int sassd_three_nn_binned(int n, int m, const float *unknown, const float *known, float x0, float y0, float cell,
+                          int nx, int ny, int batch_size, float *dist2, int32_t *idx, void *workspace,
+                          size_t workspace_bytes, void *stream);
 int sassd_three_interpolate(int c, int m, int n, const float *points, const int32_t *idx, const float *weight,
                             float *out, void *stream);
 int sassd_three_interpolate_grad(int c, int n, int m, const float *grad_out, const int32_t *idx,

@@ -9,7 +9,7 @@ from . import kernels as K
 
 
 def _n_ptr(n, dev):
-    return torch.tensor([n], dtype=torch.int32, device=dev)
+    return torch.full((1,), int(n), dtype=torch.int32, device=dev)        # fill kernel: no blocking H2D copy
 
 
 class SparseConvFn(Function):

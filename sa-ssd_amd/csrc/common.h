@@ -74,6 +74,29 @@ __device__ __forceinline__ int hash_find(const unsigned *keys, unsigned mask, un
     return -1;
 }
 
+// host-side view of a table buffer of sassd_hash_bytes(cap_rows) bytes: [keys u32 x h][vals i32 x h], h = pow2 >= 2*cap
+struct HashView {
+    unsigned *keys;
+    int *vals;
+    unsigned mask;
+};
+
+static inline unsigned hash_cap(int cap_rows)
+{
+    unsigned h = next_pow2((unsigned)(cap_rows > 0 ? cap_rows : 1) * 2u);
+    return h < 1024 ? 1024 : h;
+}
+
+static inline HashView hash_view(const void *table, int cap_rows)
+{
+    HashView v;
+    unsigned h = hash_cap(cap_rows);
+    v.keys = (unsigned *)table;
+    v.vals = (int *)((char *)table + (size_t)h * 4);
+    v.mask = h - 1;
+    return v;
+}
+
 // ---- block-wide exclusive scan of one int per thread (blockDim.x multiple of 64, <= 1024) ---------
 // `wsum` is shared scratch of >= 17 ints. Returns the exclusive prefix; *total = block sum.
 __device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total)

@@ -44,6 +44,130 @@ __global__ void __launch_bounds__(256) three_nn_kernel(int n, int m, const float
     }
 }
 
+// ---- exact 3-NN through a coarse BEV binning of the known points ---------------------------------------------------
+// The reference brute-forces O(N*M) (interpolate_gpu.cu:9-56).  Here the known points are counting-sorted into a
+// uniform (batch, y, x) grid of `cell`-sized columns (all z), and a query walks Chebyshev rings of cells around its
+// own cell, scoring every point in them.  Exactness: a point in a cell outside ring r differs from the query by
+// more than r*cell in x or y (cell indices are clamped into the grid, which only makes the test more conservative),
+// so once the 3rd best squared distance is <= (r*cell)^2 nothing farther can displace it; isolated points simply
+// keep widening until the whole grid is covered.  Candidates are ranked by (distance, row) -- exactly the order the
+// reference's ascending scan with strict '<' produces -- and distances use the same fp32 operation sequence, so
+// dist2 / idx are bit-identical to sassd_three_nn.
+struct NnBins {
+    int nx, ny, nb;
+    float x0, y0, cell;
+};
+
+__device__ __forceinline__ int nn_cell(const NnBins &g, float b, float x, float y, int *cx, int *cy)
+{
+    const int ib = (int)b;
+    if (!(ib >= 0 && ib < g.nb && (float)ib == b)) return -1;
+    *cx = min(max((int)floorf((x - g.x0) / g.cell), 0), g.nx - 1);
+    *cy = min(max((int)floorf((y - g.y0) / g.cell), 0), g.ny - 1);
+    return (ib * g.ny + *cy) * g.nx + *cx;
+}
+
+__global__ void nn_count_kernel(int m, const float *__restrict__ known, NnBins g, int *__restrict__ count)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const float4 q = ((const float4 *)known)[k];
+    int cx, cy;
+    const int c = nn_cell(g, q.x, q.y, q.z, &cx, &cy);
+    if (c >= 0) atomicAdd(&count[c], 1);
+}
+
+// single block: start[c] = exclusive prefix of count; cursor[c] = start[c]
+__global__ void __launch_bounds__(1024) nn_scan_kernel(int ncell, const int *__restrict__ count,
+                                                       int *__restrict__ start, int *__restrict__ cursor)
+{
+    __shared__ int wsum[17];
+    const int per = (ncell + 1023) / 1024;
+    const int lo = min((int)threadIdx.x * per, ncell), hi = min(lo + per, ncell);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += count[i];
+    int total;
+    int base = block_exclusive_scan(s, wsum, &total);
+    for (int i = lo; i < hi; ++i) {
+        start[i] = base;
+        cursor[i] = base;
+        base += count[i];
+    }
+    if (threadIdx.x == 0) start[ncell] = total;
+}
+
+__global__ void nn_fill_kernel(int m, const float *__restrict__ known, NnBins g, int *__restrict__ cursor,
+                               float4 *__restrict__ sorted, int *__restrict__ sorted_row)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const float4 q = ((const float4 *)known)[k];
+    int cx, cy;
+    const int c = nn_cell(g, q.x, q.y, q.z, &cx, &cy);
+    if (c < 0) return;
+    const int pos = atomicAdd(&cursor[c], 1);
+    sorted[pos] = q;
+    sorted_row[pos] = k;
+}
+
+struct Top3 {
+    double b1, b2, b3;
+    int i1, i2, i3;
+    __device__ __forceinline__ void init() { b1 = b2 = b3 = 1e40; i1 = i2 = i3 = 0; }
+    __device__ __forceinline__ static bool less(double d, int i, double bd, int bi)
+    {
+        return d < bd || (d == bd && i < bi);
+    }
+    __device__ __forceinline__ void push(float d, int i)
+    {
+        if (less(d, i, b1, i1)) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = i; }
+        else if (less(d, i, b2, i2)) { b3 = b2; i3 = i2; b2 = d; i2 = i; }
+        else if (less(d, i, b3, i3)) { b3 = d; i3 = i; }
+    }
+};
+
+__global__ void __launch_bounds__(256) three_nn_binned_kernel(int n, const float *__restrict__ unknown, NnBins g,
+                                                              const int *__restrict__ start,
+                                                              const float4 *__restrict__ sorted,
+                                                              const int *__restrict__ sorted_row,
+                                                              float *__restrict__ dist2, int *__restrict__ idx)
+{
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float4 u = ((const float4 *)unknown)[p];
+    Top3 t;
+    t.init();
+    int cx, cy;
+    const int c0 = nn_cell(g, u.x, u.y, u.z, &cx, &cy);
+    if (c0 >= 0) {
+        const int base = (int)u.x * g.ny;
+        const int rmax = max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy));
+        for (int r = 0; r <= rmax; ++r) {
+            for (int y = cy - r; y <= cy + r; ++y) {
+                if (y < 0 || y >= g.ny) continue;
+                const bool edge_row = (y == cy - r) || (y == cy + r);
+                const int step = edge_row ? 1 : max(2 * r, 1);           // interior rows: only the two end cells
+                for (int x = cx - r; x <= cx + r; x += step) {
+                    if (x < 0 || x >= g.nx) continue;
+                    const int c = (base + y) * g.nx + x;
+                    const int e = start[c + 1];
+                    for (int j = start[c]; j < e; ++j) {
+                        const float4 q = sorted[j];
+                        const float d = (u.y - q.y) * (u.y - q.y) + (u.z - q.z) * (u.z - q.z) +
+                                        (u.w - q.w) * (u.w - q.w);
+                        t.push(d, sorted_row[j]);
+                    }
+                }
+            }
+            const float reach = (float)r * g.cell * 0.999f;             // 0.1 % slack for cell-boundary rounding
+            if (r >= 1 && t.b3 <= (double)reach * (double)reach) break;
+        }
+    }
+    dist2[p * 3 + 0] = (float)t.b1; dist2[p * 3 + 1] = (float)t.b2; dist2[p * 3 + 2] = (float)t.b3;
+    idx[p * 3 + 0] = t.i1; idx[p * 3 + 1] = t.i2; idx[p * 3 + 2] = t.i3;
+}
+
 // one thread per (point, channel); consecutive threads -> consecutive channels (coalesced rows)
 __global__ void three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
                                          const int *__restrict__ idx, const float *__restrict__ weight,
@@ -117,6 +241,55 @@ extern "C" int sassd_three_nn(int n, int m, const float *unknown, const float *k
     if (n == 0) return SASSD_OK;
     if (!unknown || (m > 0 && !known)) return SASSD_EINVAL;
     hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream_, n, m, unknown, known,
+                       dist2, idx);
+    return sassd_launch_status();
+}
+
+namespace {
+struct NnLayout { size_t count, start, cursor, sorted, rows, total; int ncell; };
+NnLayout nn_layout(int m, int nx, int ny, int nb)
+{
+    NnLayout L;
+    L.ncell = nx * ny * nb;
+    size_t o = 0;
+    L.count = o;  o = align_up(o + (size_t)L.ncell * 4, 256);
+    L.start = o;  o = align_up(o + (size_t)(L.ncell + 1) * 4, 256);
+    L.cursor = o; o = align_up(o + (size_t)L.ncell * 4, 256);
+    L.sorted = o; o = align_up(o + (size_t)(m > 0 ? m : 1) * 16, 256);
+    L.rows = o;   o = align_up(o + (size_t)(m > 0 ? m : 1) * 4, 256);
+    L.total = o;
+    return L;
+}
+bool nn_grid_ok(int nx, int ny, int nb) { return nx >= 1 && ny >= 1 && nb >= 1 && (long)nx * ny * nb <= (1 << 20); }
+}  // namespace
+
+extern "C" size_t sassd_three_nn_binned_workspace_bytes(int m, int nx, int ny, int batch_size)
+{
+    return nn_grid_ok(nx, ny, batch_size) && m >= 0 ? nn_layout(m, nx, ny, batch_size).total : 0;
+}
+
+extern "C" int sassd_three_nn_binned(int n, int m, const float *unknown, const float *known, float x0, float y0,
+                                     float cell, int nx, int ny, int batch_size, float *dist2, int32_t *idx,
+                                     void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (n < 0 || m < 0 || !dist2 || !idx || !workspace || !(cell > 0.f) || !nn_grid_ok(nx, ny, batch_size))
+        return SASSD_EINVAL;
+    const NnLayout L = nn_layout(m, nx, ny, batch_size);
+    if (workspace_bytes < L.total) return SASSD_ENOSPC;
+    if (n == 0) return SASSD_OK;
+    if (!unknown || (m > 0 && !known)) return SASSD_EINVAL;
+    hipStream_t s = (hipStream_t)stream_;
+    char *ws = (char *)workspace;
+    int *count = (int *)(ws + L.count), *start = (int *)(ws + L.start), *cursor = (int *)(ws + L.cursor);
+    float4 *sorted = (float4 *)(ws + L.sorted);
+    int *rows = (int *)(ws + L.rows);
+    NnBins g;
+    g.nx = nx; g.ny = ny; g.nb = batch_size; g.x0 = x0; g.y0 = y0; g.cell = cell;
+    if (hipMemsetAsync(count, 0, (size_t)L.ncell * 4, s) != hipSuccess) return sassd_launch_status();
+    if (m > 0) hipLaunchKernelGGL(nn_count_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, m, known, g, count);
+    hipLaunchKernelGGL(nn_scan_kernel, dim3(1), dim3(1024), 0, s, L.ncell, count, start, cursor);
+    if (m > 0) hipLaunchKernelGGL(nn_fill_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, m, known, g, cursor, sorted, rows);
+    hipLaunchKernelGGL(three_nn_binned_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, unknown, g, start, sorted, rows,
                        dist2, idx);
     return sassd_launch_status();
 }

@@ -13,27 +13,6 @@
 
 namespace {
 
-struct HashView {
-    unsigned *keys;
-    int *vals;
-    unsigned mask;
-};
-
-inline unsigned hash_cap(int cap_rows)
-{
-    unsigned h = next_pow2((unsigned)(cap_rows > 0 ? cap_rows : 1) * 2u);
-    return h < 1024 ? 1024 : h;
-}
-
-inline HashView hash_view(const void *table, int cap_rows)
-{
-    HashView v;
-    unsigned h = hash_cap(cap_rows);
-    v.keys = (unsigned *)table;
-    v.vals = (int *)((char *)table + (size_t)h * 4);
-    v.mask = h - 1;
-    return v;
-}
 
 __global__ void hash_build_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ n_ptr, int cap, int D,
                                   int H, int W, HashView hv, int32_t *status)

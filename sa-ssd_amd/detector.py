@@ -30,6 +30,17 @@ from .pipeline import InferencePlan
 from .pointnet2_utils import nearest_neighbor_interpolate
 
 
+_CONSTS = {}
+
+
+def _const(dev, values):
+    """Small fp32 device constant, uploaded once per (device, values) instead of one blocking H2D copy per use."""
+    key = (str(dev), tuple(float(v) for v in values))
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
+    return _CONSTS[key]
+
+
 def change_default_args(**kwargs):
     """mmdet/models/utils/__init__.py:41."""
     def layer_wrapper(layer_class):
@@ -164,22 +175,27 @@ class SpMiddleFHD(nn.Module):
         self.point_fc = nn.Linear(160, 64, bias=False)        # training-only auxiliary head (cmn.py:27-29)
         self.point_cls = nn.Linear(64, 1, bias=False)
         self.point_reg = nn.Linear(64, 3, bias=False)
+        # scene extent / bin size for the exact binned 3-NN of the aux head (any values give identical results)
+        self.aux_xy_range, self.aux_bin = (0., -40., 70.4, 40.), 1.6
 
     def build_aux_target(self, nxyz, gt_boxes3d, enlarge=1.0):
         """cmn.py:45-72 with the point-in-box test on the device (sassd_pts_in_boxes3d)."""
-        offsets, labels = [], []
+        pts = nxyz[:, 1:].contiguous()
+        n = pts.shape[0]
+        labels = torch.zeros(n, dtype=torch.uint8, device=pts.device)
+        offsets = torch.zeros(n, 3, device=pts.device)
         for i, boxes3d in enumerate(gt_boxes3d):
-            pts = nxyz[nxyz[:, 0] == i, 1:].contiguous()
+            if boxes3d.shape[0] == 0 or n == 0:
+                continue
             boxes3d = boxes3d.clone().float()
             boxes3d[:, 3:6] *= enlarge
-            if boxes3d.shape[0] == 0 or pts.shape[0] == 0:
-                labels.append(torch.zeros(pts.shape[0], dtype=torch.uint8, device=pts.device))
-                offsets.append(torch.zeros(pts.shape[0], 3, device=pts.device))
-                continue
+            # every point against sample i's boxes, kept only for the points of sample i (no boolean compaction)
             flag, off = K.pts_in_boxes3d(pts, boxes3d.to(pts.device).contiguous())
-            labels.append(flag.max(0)[0].to(torch.uint8))
-            offsets.append(off)
-        return torch.cat(labels), torch.cat(offsets)
+            mine = nxyz[:, 0] == i
+            inside = (flag.max(0)[0] > 0) & mine
+            labels = torch.where(inside, torch.ones_like(labels), labels)
+            offsets = torch.where(inside[:, None], off, offsets)
+        return labels, offsets
 
     def aux_loss(self, points, point_cls, point_reg, gt_bboxes):
         """cmn.py:74-104."""
@@ -197,10 +213,9 @@ class SpMiddleFHD(nn.Module):
     def tensor2points(tensor, offset=(0., -40., -3.), voxel_size=(.05, .05, .1)):
         """mmdet/core/bbox/transforms.py:218-223: voxel centres [b,x,y,z] of a sparse tensor's rows."""
         ind = tensor.indices.float()
-        off = torch.tensor(offset, device=ind.device)
-        vs = torch.tensor(voxel_size, device=ind.device)
+        off, vs = _const(ind.device, offset), _const(ind.device, voxel_size)
         out = ind.clone()
-        out[:, 1:] = ind[:, [3, 2, 1]] * vs + off + .5 * vs
+        out[:, 1:] = ind[:, 1:].flip(1) * vs + off + .5 * vs          # columns (3,2,1) without an index tensor upload
         return tensor.features, out
 
     def forward(self, voxel_features, coors, batch_size, is_test=False):
@@ -218,7 +233,8 @@ class SpMiddleFHD(nn.Module):
         ps = []
         for m, vs in zip(middle, ((.1, .1, .2), (.2, .2, .4), (.4, .4, .8))):
             feat, nxyz = self.tensor2points(m, (0, -40., -3.), vs)
-            ps.append(nearest_neighbor_interpolate(points_mean, nxyz, feat))
+            grid = (self.aux_xy_range, self.aux_bin, batch_size)
+            ps.append(nearest_neighbor_interpolate(points_mean, nxyz, feat, grid))
         pointwise = self.point_fc(torch.cat(ps, dim=-1))
         return x, conv6, (points_mean, self.point_cls(pointwise), self.point_reg(pointwise))
 
@@ -287,9 +303,17 @@ class SSDRotateHead(nn.Module):
         b = box_preds.shape[0]
         multi_labels, multi_targets, multi_anchors = [], [], []
         sim = getattr(T, cfg.assigner.similarity_fn, None) or getattr(iou3d_utils, cfg.assigner.similarity_fn)
+        dev = box_preds.device
+        # class membership of every ground truth, all (class, sample) masks in ONE pinned non-blocking upload
+        flat = np.concatenate([np.asarray(c) == n for n in anchors for c in gt_types] or [np.zeros(0, bool)])
+        up = torch.from_numpy(flat)
+        up = up.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else up
+        off = 0
         for cls_name, cls_anchor in anchors.items():
-            gt_mask = [torch.as_tensor(np.asarray(c) == cls_name, dtype=torch.bool, device=cls_anchor.device)
-                       for c in gt_types]
+            gt_mask = []
+            for c in gt_types:
+                gt_mask.append(up[off:off + len(c)])
+                off += len(c)
             labels, targets, _ = T.multi_apply(
                 T.create_target_torch, cls_anchor, anchors_mask[cls_name], gt_bboxes, gt_labels, gt_mask,
                 similarity_fn=sim(), box_encoding_fn=T.second_box_encode,
@@ -333,16 +357,17 @@ class SSDRotateHead(nn.Module):
         gt_labels = gt_labels if gt_labels is not None else [None] * b
         guided, labels_out = [], []
         for box, cls, dirp, m, gtb, gtl in zip(batch_box, batch_cls, batch_dir, batch_mask, gt_bboxes, gt_labels):
-            box, cls, dirp = box[m], cls[m], dirp[m]
-            dir_labels = torch.max(dirp, dim=-1)[1]
             scores = torch.sigmoid(cls) if self._use_sigmoid_cls else torch.softmax(cls, dim=-1)[..., 1:]
             if self._num_class == 1:
                 top_scores = scores.squeeze(-1)
                 top_labels = torch.zeros(scores.shape[0], dtype=torch.int64, device=scores.device)
             else:
                 top_scores, top_labels = torch.max(scores, dim=-1)
-            sel = top_scores > thr
-            box, top_labels, dir_labels = box[sel], top_labels[sel], dir_labels[sel]
+            # one compaction (one host sync) for mask AND threshold; ascending anchor order like the reference's
+            # two successive boolean selections
+            sel = torch.nonzero(m & (top_scores > thr)).view(-1)
+            box, top_labels = box[sel], top_labels[sel]
+            dir_labels = torch.max(dirp[sel], dim=-1)[1]
             if self._use_direction_classifier:
                 opp = (box[..., -1] > 0) ^ dir_labels.bool()
                 box = torch.cat([box[:, :-1], (box[:, -1] + opp.type_as(box) * np.pi)[:, None]], dim=1)
@@ -382,7 +407,7 @@ class PSWarpHead(nn.Module):
                 scores.append(PSWarpFn.apply(f[i:i + 1], ga.float(), tuple(self.grid_offsets),
                                              1.0 / self.featmap_stride))
                 continue
-            cnt = torch.tensor([k], dtype=torch.int32, device=x.device)
+            cnt = torch.full((1,), k, dtype=torch.int32, device=x.device)
             lg = K.pswarp_sample(f[i:i + 1].contiguous(), ga.contiguous().view(1, k, 7), cnt, k, self.grid_offsets,
                                  1.0 / self.featmap_stride)
             scores.append(lg.view(-1))

@@ -377,6 +377,27 @@ def three_nn(unknown, known):
     return d, i
 
 
+def three_nn_binned(unknown, known, xy_range, cell, batch_size):
+    """three_nn through a BEV counting-sort of `known` (exact, bit-identical results): xy_range = (x0, y0, x1, y1) of
+    the scene, `cell` the bin edge in metres, batch indices 0..batch_size-1."""
+    _chk_cuda(unknown, known)
+    n, m = unknown.shape[0], known.shape[0]
+    dev = unknown.device
+    d2 = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    idx = torch.empty(n, 3, dtype=torch.int32, device=dev)
+    x0, y0, x1, y1 = [float(v) for v in xy_range]
+    nx, ny = max(1, int(np.ceil((x1 - x0) / cell))), max(1, int(np.ceil((y1 - y0) / cell)))
+    L = _C.lib()
+    wsb = L.sassd_three_nn_binned_workspace_bytes(m, nx, ny, int(batch_size))
+    if wsb == 0:
+        raise ValueError("three_nn_binned: grid %dx%dx%d too large" % (nx, ny, batch_size))
+    ws = workspace("three_nn_binned", wsb, dev)
+    _C.check(L.sassd_three_nn_binned(n, m, _C.ptr(unknown), _C.ptr(known), x0, y0, float(cell), nx, ny,
+                                     int(batch_size), _C.ptr(d2), _C.ptr(idx), _C.ptr(ws), wsb, _C.stream()),
+             "sassd_three_nn_binned")
+    return d2, idx
+
+
 def three_interpolate(points, idx, weight):
     _chk_cuda(points, idx, weight)
     m, c = points.shape

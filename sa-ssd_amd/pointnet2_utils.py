@@ -22,6 +22,21 @@ class ThreeNN(Function):
 three_nn = ThreeNN.apply
 
 
+class ThreeNNBinned(Function):
+    """Same outputs as ThreeNN (bit-identical) through sassd_three_nn_binned: O(N+M)-ish instead of O(N*M)."""
+
+    @staticmethod
+    def forward(ctx, unknown, known, xy_range, cell, batch_size):
+        dist2, idx = K.three_nn_binned(unknown.contiguous().float(), known.contiguous().float(), xy_range, cell,
+                                       batch_size)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return (None,) * 5
+
+
 class ThreeInterpolate(Function):
     @staticmethod
     def forward(ctx, features, idx, weight):
@@ -38,9 +53,12 @@ class ThreeInterpolate(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
-def nearest_neighbor_interpolate(unknown, known, known_feats):
-    """mmdet/models/necks/cmn.py:175-189."""
-    dist, idx = three_nn(unknown, known)
+def nearest_neighbor_interpolate(unknown, known, known_feats, grid=None):
+    """mmdet/models/necks/cmn.py:175-189.  grid = (xy_range, cell, batch_size) selects the binned exact search."""
+    if grid is not None:
+        dist, idx = ThreeNNBinned.apply(unknown, known, *grid)
+    else:
+        dist, idx = three_nn(unknown, known)
     dist_recip = 1.0 / (dist + 1e-8)
     weight = dist_recip / torch.sum(dist_recip, dim=1, keepdim=True)
     return three_interpolate(known_feats, idx, weight)

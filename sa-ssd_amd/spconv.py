@@ -31,7 +31,7 @@ class SparseConvTensor:
         return int(np.prod(self.spatial_shape))
 
     def _n_ptr(self):
-        return torch.tensor([self.indices.shape[0]], dtype=torch.int32, device=self.indices.device)
+        return torch.full((1,), self.indices.shape[0], dtype=torch.int32, device=self.indices.device)
 
     def table(self):
         if self._table is None:
@@ -95,7 +95,7 @@ class SparseConvolution(nn.Module):
             y = SparseConvFn.apply(feats, self.weight.view(k, cin, cout), nbr, n_out, self.packed_weight())
             return y + self.bias if self.bias is not None else y
         bias = self.bias.detach() if self.bias is not None else None
-        n_ptr = torch.tensor([n_out], dtype=torch.int32, device=feats.device)
+        n_ptr = torch.full((1,), n_out, dtype=torch.int32, device=feats.device)
         return K.spconv_fwd(feats, nbr, n_ptr, max(n_out, 1), self.packed_weight(), k, cin, cout, None, bias)[:n_out]
 
     def forward(self, inp):

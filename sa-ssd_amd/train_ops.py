@@ -83,9 +83,9 @@ def _limit_period(val, offset=0.5, period=math.pi):
 
 def boxes3d_to_near_torch(boxes3d):
     """rotated (x,y,w,l,r) -> nearest axis-aligned (xmin,ymin,xmax,ymax)."""
-    rb = boxes3d[:, [0, 1, 3, 4, 6]]
-    swap = (torch.abs(_limit_period(rb[..., -1], 0.5, math.pi)) > math.pi / 4)[..., None]
-    cen = torch.where(swap, rb[:, [0, 1, 3, 2]], rb[:, :4])
+    xy, w, l = boxes3d[:, 0:2], boxes3d[:, 3:4], boxes3d[:, 4:5]          # column slices: no index-tensor uploads
+    swap = (torch.abs(_limit_period(boxes3d[:, 6], 0.5, math.pi)) > math.pi / 4)[..., None]
+    cen = torch.cat([xy, torch.where(swap, l, w), torch.where(swap, w, l)], dim=1)
     return torch.cat([cen[:, :2] - cen[:, 2:] / 2, cen[:, :2] + cen[:, 2:] / 2], dim=-1)
 
 
@@ -110,44 +110,34 @@ class NearestIouSimilarity:
 # ---- anchor <-> ground-truth assignment --------------------------------------------------------------------------
 def create_target_torch(all_anchors, anchor_mask, gt_boxes, gt_classes, gt_mask, similarity_fn, box_encoding_fn,
                         matched_threshold=0.6, unmatched_threshold=0.45, box_code_size=7):
-    """Labels (1.. positive class, 0 negative, -1 ignore), regression targets and best-IoU per anchor.
-    (The reference's optional positive/negative subsampling branch, never enabled by the configs, is omitted.)"""
+    """Labels (1.. positive class, 0 negative, -1 ignore), regression targets and best overlap per anchor, with the
+    reference's semantics (target_ops.py:139-277) but FIXED-SHAPE: anchors outside `anchor_mask` and ground truths
+    outside `gt_mask` are neutralised by masking the overlap matrix instead of being compacted away with boolean
+    indexing, so the whole assignment is a handful of dense kernels over [A, G] with no host synchronisation.
+    (The reference's optional positive/negative subsampling branch, never enabled by the configs, is omitted; the
+    third return value is full-size [A] with -1 at masked-out anchors, the reference returns the masked rows.)"""
     total = all_anchors.shape[0]
-    dev = gt_boxes.device
-    anchors = all_anchors[anchor_mask, :] if anchor_mask is not None else all_anchors
+    dev = all_anchors.device
     if gt_classes is None:
         gt_classes = torch.ones([gt_boxes.shape[0]], dtype=torch.int64, device=dev)
-    if gt_mask is not None:
-        gt_boxes, gt_classes = gt_boxes[gt_mask], gt_classes[gt_mask]
-    n = anchors.shape[0]
-    labels = torch.full((n,), -1, dtype=torch.int64, device=dev)
-    have = len(gt_boxes) > 0 and n > 0
-    if have:
-        ov = similarity_fn(anchors, gt_boxes)                           # [n, G]
-        a2g_arg = ov.argmax(dim=1)
-        a2g_max = ov[torch.arange(n, device=dev), a2g_arg]
-        g2a_arg = ov.argmax(dim=0)
-        g2a_max = ov[g2a_arg, torch.arange(ov.shape[1], device=dev)]
-        g2a_max[g2a_max == 0] = -1                                      # gt boxes that match no anchor
-        forced = torch.nonzero(ov == g2a_max)[:, 0]                     # anchors tying a gt's best overlap
-        forced_gt = a2g_arg[forced]
-        labels[forced] = gt_classes[forced_gt]
-        pos = a2g_max >= matched_threshold
-        labels[pos] = gt_classes[a2g_arg[pos]]
-        bg = torch.nonzero(a2g_max < unmatched_threshold)[:, 0]
-        labels[bg] = 0
-        labels[forced] = gt_classes[forced_gt]                          # re-enable the forced matches
-    else:
-        a2g_max = torch.zeros(n).type_as(anchors)
-        labels[:] = 0
-    fg = torch.nonzero(labels > 0)[:, 0]
-    targets = torch.zeros((n, box_code_size), dtype=all_anchors.dtype, device=dev)
-    if have:
-        targets[fg, :] = box_encoding_fn(gt_boxes[a2g_arg[fg], :], anchors[fg, :])
-    if anchor_mask is not None:
-        full_l = labels.new_full((total,), -1)
-        full_l[anchor_mask] = labels
-        full_t = targets.new_zeros((total, box_code_size))
-        full_t[anchor_mask, :] = targets
-        labels, targets = full_l, full_t
-    return labels, targets, a2g_max
+    row_ok = anchor_mask.bool() if anchor_mask is not None else torch.ones(total, dtype=torch.bool, device=dev)
+    labels = torch.full((total,), -1, dtype=torch.int64, device=dev)
+    targets = torch.zeros((total, box_code_size), dtype=all_anchors.dtype, device=dev)
+    if gt_boxes.shape[0] == 0 or total == 0:
+        labels = torch.where(row_ok, torch.zeros_like(labels), labels)
+        return labels, targets, torch.where(row_ok, 0.0, -1.0).type_as(all_anchors)
+    col_ok = gt_mask.bool() if gt_mask is not None else torch.ones(gt_boxes.shape[0], dtype=torch.bool, device=dev)
+    ok = row_ok[:, None] & col_ok[None, :]
+    ov = torch.where(ok, similarity_fn(all_anchors, gt_boxes), torch.full((), -1.0, device=dev))     # [A, G]
+    a2g_max, a2g_arg = ov.max(dim=1)
+    g2a_max = ov.max(dim=0)[0]
+    forced = ((ov == g2a_max[None, :]) & ok & (g2a_max > 0)[None, :]).any(dim=1)   # anchors tying a gt's best overlap
+    cls_of_arg = gt_classes[a2g_arg]
+    labels = torch.where(a2g_max >= matched_threshold, cls_of_arg, labels)
+    labels = torch.where(a2g_max < unmatched_threshold, torch.zeros_like(labels), labels)
+    labels = torch.where(forced, cls_of_arg, labels)
+    labels = torch.where(row_ok, labels, torch.full_like(labels, -1))
+    fg = labels > 0
+    enc = box_encoding_fn(gt_boxes[a2g_arg], all_anchors)
+    targets = torch.where(fg[:, None], enc, targets)
+    return labels, targets, torch.where(row_ok, a2g_max, torch.full_like(a2g_max, -1.0))

@@ -66,3 +66,51 @@ def test_pts_in_boxes3d(dev):
     assert np.abs(rg[same] - r_ref[same]).max() < 1e-6
     f2, r2 = points_ops.pts_in_boxes3d(torch.from_numpy(pts), torch.from_numpy(boxes))       # CPU-tensor API
     assert f2.device.type == "cpu" and np.array_equal(f2.numpy(), fg)
+
+
+def test_three_nn_binned_bit_identical(dev):
+    """The binned search returns exactly what the brute-force kernel (and the CPU oracle) returns: real multi-level
+    voxel centres for a batch of 2, plus adversarial queries (isolated, outside the scene, empty batch element,
+    fewer than three known points) and several bin sizes."""
+    from sassd import spconv, synth
+    import helpers as H
+    shape0, vs0, off = (40, 1600, 1408), np.array([.05, .05, .1], np.float32), (0., -40., -3.)
+    coors, pts = [], []
+    for b, name in enumerate(("small", "k17")):
+        p = H.frame(name, 40 + b)
+        v, co, n = clib.points_to_voxel(p, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 20000)
+        coors.append(np.concatenate([np.full((len(co), 1), b, np.int32), co], 1))
+        pts.append(np.concatenate([np.full((len(co), 1), b, np.float32), clib.voxel_mean(v, n)[:, :3]], 1))
+    coors, unknown = np.concatenate(coors), np.concatenate(pts)
+    extra = np.array([[0, 69.9, 39.9, 0.9], [1, 0.01, -39.99, -2.99], [0, -5.0, 0.0, 0.0], [1, 35.0, 90.0, 5.0],
+                      [0, 35.2, 0.0, -1.0], [1, 12.8, -6.4, -1.4], [2, 1.0, 1.0, 1.0]], np.float32)
+    unknown = np.concatenate([unknown, extra]).astype(np.float32)
+    idx = torch.from_numpy(coors).to(dev)
+    x = spconv.SparseConvTensor(torch.zeros(len(coors), 16, device=dev), idx, shape0, 2)
+    down = spconv.SparseConv3d(16, 16, 3, (2, 2, 2), padding=1, bias=False).to(dev)
+    u = torch.from_numpy(unknown).to(dev)
+    rng = (0., -40., 70.4, 40.)
+    with torch.no_grad():
+        for level in range(1, 4):
+            x = down(x)
+            vs = torch.from_numpy(vs0 * (2 ** level)).to(dev)
+            ii = x.indices.float()
+            known = ii.clone()
+            known[:, 1:] = ii[:, 1:].flip(1) * vs + torch.tensor(off, device=dev) + .5 * vs
+            known = known.contiguous()
+            d_ref, i_ref = K.three_nn(u, known)
+            od, oi = clib.three_nn(unknown, known.cpu().numpy())
+            assert np.array_equal(oi, i_ref.cpu().numpy()) and np.array_equal(od, d_ref.cpu().numpy())
+            for cell in (1.6, 0.4, 7.3, 200.0):
+                d_got, i_got = K.three_nn_binned(u, known, rng, cell, 3)
+                assert torch.equal(i_got, i_ref), (level, cell, int((i_got != i_ref).sum()))
+                assert torch.equal(d_got, d_ref), (level, cell)
+    # fewer than three known points in one batch element, an empty batch element, known points outside the range
+    known = torch.tensor([[0, 1.0, -39., -2.], [0, 1.4, -39., -2.], [1, 0.2, -39.8, -2.6], [1, 500., 500., 0.],
+                          [1, -500., 3., 0.], [1, 20., 3., 0.]], device=dev)
+    q = torch.tensor([[0, 1.5, -39., -2.], [1, 0.2, -39.8, -2.6], [2, 1.0, 1.0, 1.0], [1, 499., 499., 0.]],
+                     device=dev)
+    d_ref, i_ref = K.three_nn(q, known)
+    for cell in (1.6, 30.0):
+        d_got, i_got = K.three_nn_binned(q, known, rng, cell, 3)
+        assert torch.equal(i_got, i_ref) and torch.equal(d_got, d_ref), cell

@@ -55,7 +55,9 @@ def test_create_target(case):
                                          matched_threshold=0.6, unmatched_threshold=0.45, box_code_size=7)
     assert np.array_equal(lab.numpy(), G["ct_%s_labels" % case])          # integer work: exact
     close(tar, G["ct_%s_targets" % case], 1e-6)
-    close(mx, G["ct_%s_max" % case], 1e-6)
+    close(mx[am] if am is not None else mx, G["ct_%s_max" % case], 1e-6)   # ours is full-size, -1 at masked-out rows
+    if am is not None:
+        assert bool((mx[~am] == -1).all()) and bool((lab[~am] == -1).all())
     if case != "nogt":
         assert (lab > 0).sum() > 0
 

@@ -141,6 +141,15 @@ int sassd_conv2d_fwd(const float *x, const float *w_packed, const float *scale, 
                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, int ksize,
                      void *stream);
 
+/* Training: weight gradient of the same convolutions (autograd of nn.Conv2d at cmn.py:240-262 and
+ * ssd_rotate_head.py:120-125,424-429; cuDNN in the reference).  x [B,Cin,H,W], dy [B,Cout,H,W] NCHW fp32 ->
+ * dw [Cout,Cin,k,k] (torch layout), overwritten or accumulated.  Split-K over pixels with a deterministic second-stage
+ * reduction; workspace from sassd_conv2d_wgrad_workspace_bytes.  The data gradient is sassd_conv2d_fwd on dy with the
+ * weights transposed and the taps mirrored (sassd.autograd.Conv2dFn). */
+size_t sassd_conv2d_wgrad_workspace_bytes(int batch, int Cin, int Cout, int H, int W, int ksize);
+int sassd_conv2d_bwd_weight(const float *x, const float *dy, float *dw, int batch, int Cin, int Cout, int H, int W,
+                            int ksize, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (f-1) anchors_mask: mmdet/datasets/kitti.py:333-343 with geometry.py:676-710
  * (sparse_sum_for_anchors_mask -> cumsum -> fused_get_anchors_area > area_threshold).

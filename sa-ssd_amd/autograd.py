@@ -1,7 +1,6 @@
 """torch.autograd glue for the training path: every forward and every data / weight gradient below
-runs in a hand-written HIP kernel of libsassd, with ONE labelled exception -- the dense 2-D convolution's WEIGHT
-gradient still goes through `torch.nn.grad.conv2d_weight` (MIOpen) until the native MFMA wgrad kernel lands
-(DESIGN.md section 7).  There is no CPU fallback."""
+runs in a hand-written HIP kernel of libsassd (BatchNorm / ReLU / Linear between them are torch ops, as in the
+reference).  There is no CPU fallback."""
 import torch
 from torch.autograd import Function
 
@@ -77,8 +76,7 @@ class Conv2dFn(Function):
             wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # [Cin, Cout, k, k], taps mirrored
             dx = K.conv2d_fwd(dy, K.conv2d_pack_weight(wt), cin, ks)
         if ctx.needs_input_grad[1]:
-            # INTERIM (labelled in DESIGN.md): dense weight gradient through the vendor library
-            dw = torch.nn.grad.conv2d_weight(x, weight.shape, dy, padding=ks // 2)
+            dw = K.conv2d_bwd_weight(x, dy, ks)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
         return dx, dw, db, None

@@ -1,0 +1,265 @@
+// conv2d_wgrad.hip -- weight gradient of the dense BEV / head convolutions (training, SURVEY 8 a9/a10/a12 backward):
+//   dW[co][ci][ky][kx] = sum_{b,y,x} dY[b][co][y][x] * X[b][ci][y+ky-P][x+kx-P]        (NCHW fp32, stride 1, P = k/2)
+// i.e. the autograd of torch.nn.Conv2d at mmdet/models/necks/cmn.py:240-262 and
+// mmdet/models/single_stage_heads/ssd_rotate_head.py:120-125,424-429, which the reference gets from cuDNN.
+//
+// A GEMM whose contraction runs over PIXELS: M = Cout, N = Cin*taps, K = B*H*W (70 400 at B = 2).  MFMA-bound
+// (83 GFLOP per 256->256 3x3 layer), so it is tiled for v_mfma_f32_32x32x2_f32:
+//   * WG = 4 waves = 64 couts x 64 cins x all taps; a wave owns 32 couts x 32 cins x 9 taps = 9 accumulator tiles
+//     (144 AGPRs; 18 tiles would overflow the 256 AGPRs and the compiler then shuffles accumulators through VGPRs
+//     on every MFMA) -- every dY value read from LDS feeds 9 MFMAs.  <= 256 VGPRs and 71 KB of LDS per WG keep two
+//     WGs resident per CU, so one WG's barriers / LDS refills hide behind the other's MFMAs.
+//   * split-K over pixels: a WG walks a strip of 44 columns x R rows of one image; X rows live in a 4-slot LDS ring
+//     (each row is loaded once and used by three dY rows), dY rows are double-buffered; the next row is prefetched
+//     into registers while the current one is multiplied.
+//   * LDS rows are [channel][pixel] with an odd pitch, so the per-lane "channel = lane & 31" operand reads are
+//     bank-conflict free without transposing the NCHW data.
+//   * partial sums go to a [split][tap][Cout][Cin] workspace (coalesced 128-B rows) and a second kernel reduces the
+//     splits in a fixed order -> deterministic, no atomics.
+#include "common.h"
+
+#include <algorithm>
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kSeg = 44;                 // strip width in pixels (176 = 4 * 44)
+constexpr int kPitchY = kSeg + 1;        // 45 (odd)
+constexpr int kPitchX = kSeg + 3;        // 47 (odd): columns x0-1 .. x0+44
+constexpr int kCoT = 64, kCiT = 64;
+constexpr int kYRowFloats = kCoT * kPitchY;   // 2880
+constexpr int kXRowFloats = kCiT * kPitchX;   // 3008
+constexpr int kYPer = (kCoT * kSeg + 255) / 256;        // 11 dY values per thread per row
+constexpr int kXPer = (kCiT * (kSeg + 2) + 255) / 256;  // 12 X values per thread per row
+
+struct WgradParams {
+    const float *x, *dy;
+    float *part;
+    int B, Cin, Cout, H, W;
+    int nseg, nrange, rows_per;          // strips per image row, row ranges per image, rows per range
+    int n_ci_t, n_co_t;
+};
+
+template <int TAPS>
+__global__ void __launch_bounds__(256, 2) conv2d_wgrad_kernel(WgradParams p)
+{
+    extern __shared__ float smem[];
+    float *ylds = smem;                              // [2][64][45]
+    float *xlds = smem + 2 * kYRowFloats;            // [4][64][47]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    int wg = blockIdx.x;
+    const int ci_t = wg % p.n_ci_t; wg /= p.n_ci_t;
+    const int co_t = wg % p.n_co_t; wg /= p.n_co_t;
+    const int split = wg;                            // (b, seg, range)
+    const int range = wg % p.nrange; wg /= p.nrange;
+    const int seg = wg % p.nseg;
+    const int b = wg / p.nseg;
+    const int x0 = seg * kSeg;
+    const int r0 = range * p.rows_per, r1 = min(r0 + p.rows_per, p.H);
+    const int co0 = co_t * kCoT, ci0 = ci_t * kCiT;
+    const size_t hw = (size_t)p.H * p.W;
+    const float *xb = p.x + (size_t)b * p.Cin * hw;
+    const float *yb = p.dy + (size_t)b * p.Cout * hw;
+
+    float yreg[kYPer], xreg[kXPer];
+
+    auto fetch_y = [&](int row) {
+#pragma unroll
+        for (int i = 0; i < kYPer; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / kSeg, px = e - c * kSeg;
+            const int co = co0 + c, x = x0 + px;
+            const bool ok = e < kCoT * kSeg && co < p.Cout && x < p.W && row < p.H;
+            const float v = yb[ok ? (size_t)co * hw + (size_t)row * p.W + x : 0];     // unconditional load + select
+            yreg[i] = ok ? v : 0.f;
+        }
+    };
+    auto store_y = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < kYPer; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / kSeg, px = e - c * kSeg;
+            if (e < kCoT * kSeg) ylds[buf * kYRowFloats + c * kPitchY + px] = yreg[i];
+        }
+    };
+    auto fetch_x = [&](int row) {
+#pragma unroll
+        for (int i = 0; i < kXPer; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / (kSeg + 2), px = e - c * (kSeg + 2);
+            const int ci = ci0 + c, x = x0 - 1 + px;
+            const bool ok = e < kCiT * (kSeg + 2) && ci < p.Cin && row >= 0 && row < p.H && x >= 0 && x < p.W;
+            const float v = xb[ok ? (size_t)ci * hw + (size_t)row * p.W + x : 0];
+            xreg[i] = ok ? v : 0.f;
+        }
+    };
+    auto store_x = [&](int row) {
+        const int slot = row & 3;
+#pragma unroll
+        for (int i = 0; i < kXPer; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / (kSeg + 2), px = e - c * (kSeg + 2);
+            if (e < kCiT * (kSeg + 2)) xlds[slot * kXRowFloats + c * kPitchX + px] = xreg[i];
+        }
+    };
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (r0 < r1) {
+        // prologue: X rows r0-1, r0 (and r0+1 is fetched as the first "next" row), dY row r0
+        fetch_x(r0 - 1); store_x(r0 - 1 + 4);        // (+4 keeps the slot index non-negative: (r0-1+4) & 3 == (r0-1) & 3)
+        fetch_x(r0);     store_x(r0);
+        fetch_x(r0 + 1); store_x(r0 + 1);
+        fetch_y(r0);     store_y(0);
+        __syncthreads();
+        for (int y = r0; y < r1; ++y) {
+            const int cur = (y - r0) & 1;
+            const bool more = (y + 1 < r1);
+            if (more) { fetch_y(y + 1); fetch_x(y + 2); }            // global loads in flight during the MFMAs
+            const float *yl = ylds + cur * kYRowFloats + (wm * 32 + (lane & 31)) * kPitchY + (lane >> 5);
+            const float *xl = xlds + (wn * 32 + (lane & 31)) * kPitchX + (lane >> 5);
+            const int s0 = ((y - 1 + 4) & 3) * kXRowFloats, s1 = (y & 3) * kXRowFloats,
+                      s2 = ((y + 1) & 3) * kXRowFloats;
+            // operands of pixel pair pp+1 are read from LDS while the 9 MFMAs of pair pp issue (double-buffered
+            // registers, ds_reads interleaved 1 : 1 with the MFMAs by sched_group_barrier)
+            float av[2], bv[2][TAPS];
+            auto lds_ops = [&](int pp, float &a, float *bq) {
+                a = yl[2 * pp];
+                if (TAPS == 9) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int so = t < 3 ? s0 : (t < 6 ? s1 : s2);
+                        bq[t % TAPS] = xl[so + 2 * pp + (t % 3)];
+                    }
+                } else {
+                    bq[0] = xl[s1 + 2 * pp + 1];
+                }
+            };
+            lds_ops(0, av[0], bv[0]);
+#pragma unroll
+            for (int pp = 0; pp < kSeg / 2; ++pp) {
+                const int c = pp & 1;
+                if (pp + 1 < kSeg / 2) lds_ops(pp + 1, av[c ^ 1], bv[c ^ 1]);
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[c][t], acc[t], 0, 0, 0);
+                if (pp + 1 < kSeg / 2) {
+                    if (TAPS == 9) {                         // 10 ds_reads spread over the 9 MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                }
+            }
+            __syncthreads();                         // everyone is done with row y's dY buffer and X slot (y-1)
+            if (more) { store_y(cur ^ 1); store_x(y + 2); }
+            __syncthreads();
+        }
+    }
+
+    // epilogue: part[split][tap][co][ci]; D element (row = co, col = ci): col = lane & 31,
+    // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float *pt = p.part + (size_t)split * TAPS * p.Cout * p.Cin;
+    const int ci = ci0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < p.Cout && ci < p.Cin) pt[((size_t)t * p.Cout + co) * p.Cin + ci] = acc[t][r];
+        }
+}
+
+// dw[co][ci][tap] = sum_s part[s][tap][co][ci]  (+ dw when accumulate)
+__global__ void conv2d_wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int taps, int Cout, int Cin,
+                                           float *__restrict__ dw, int accumulate)
+{
+    const size_t n = (size_t)taps * Cout * Cin;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+    const int ci = i % Cin;
+    const int co = (i / Cin) % Cout;
+    const int t = i / ((size_t)Cin * Cout);
+    float *o = dw + ((size_t)co * Cin + ci) * taps + t;
+    *o = accumulate ? *o + s : s;
+}
+
+struct WgradPlan { int nseg, nrange, rows_per, n_ci_t, n_co_t, nsplit; };
+WgradPlan wgrad_plan(int B, int Cin, int Cout, int H, int W)
+{
+    WgradPlan q;
+    q.nseg = cdiv(W, kSeg);
+    q.n_ci_t = cdiv(Cin, kCiT);
+    q.n_co_t = cdiv(Cout, kCoT);
+    const int base = q.n_ci_t * q.n_co_t * B * q.nseg;
+    // row ranges per image: minimise (rounds of 512 resident workgroups, 2 per CU) x (rows per workgroup + ~2 rows
+    // of prologue / epilogue)
+    long best = -1;
+    q.rows_per = H; q.nrange = 1;
+    for (int nr = 1; nr <= std::min(H, 64); ++nr) {
+        const int rp = cdiv(H, nr), nrr = cdiv(H, rp);
+        const long cost = (long)cdiv(base * nrr, 512) * (rp + 2);
+        if (best < 0 || cost < best) { best = cost; q.rows_per = rp; q.nrange = nrr; }
+    }
+    q.nsplit = B * q.nseg * q.nrange;
+    return q;
+}
+}  // namespace
+
+extern "C" size_t sassd_conv2d_wgrad_workspace_bytes(int batch, int Cin, int Cout, int H, int W, int ksize)
+{
+    if (batch < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (ksize != 1 && ksize != 3)) return 0;
+    const WgradPlan q = wgrad_plan(batch, Cin, Cout, H, W);
+    return (size_t)q.nsplit * ksize * ksize * Cout * Cin * sizeof(float);
+}
+
+extern "C" int sassd_conv2d_bwd_weight(const float *x, const float *dy, float *dw, int batch, int Cin, int Cout, int H,
+                                       int W, int ksize, int accumulate, void *workspace, size_t workspace_bytes,
+                                       void *stream_)
+{
+    if (!x || !dy || !dw || !workspace || batch < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 ||
+        (ksize != 1 && ksize != 3))
+        return SASSD_EINVAL;
+    if (workspace_bytes < sassd_conv2d_wgrad_workspace_bytes(batch, Cin, Cout, H, W, ksize)) return SASSD_ENOSPC;
+    const WgradPlan q = wgrad_plan(batch, Cin, Cout, H, W);
+    hipStream_t s = (hipStream_t)stream_;
+    WgradParams p;
+    p.x = x; p.dy = dy; p.part = (float *)workspace;
+    p.B = batch; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
+    p.nseg = q.nseg; p.nrange = q.nrange; p.rows_per = q.rows_per; p.n_ci_t = q.n_ci_t; p.n_co_t = q.n_co_t;
+    const size_t lds = (size_t)(2 * kYRowFloats + 4 * kXRowFloats) * sizeof(float);     // 71 168 B
+    const int grid = q.nsplit * q.n_ci_t * q.n_co_t;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)conv2d_wgrad_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)conv2d_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return sassd_launch_status();
+        attr_done = true;
+    }
+    if (ksize == 3)
+        hipLaunchKernelGGL(conv2d_wgrad_kernel<9>, dim3(grid), dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL(conv2d_wgrad_kernel<1>, dim3(grid), dim3(256), lds, s, p);
+    const int taps = ksize * ksize;
+    const size_t n = (size_t)taps * Cout * Cin;
+    hipLaunchKernelGGL(conv2d_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       (const float *)workspace, q.nsplit, taps, Cout, Cin, dw, accumulate);
+    return sassd_launch_status();
+}

@@ -291,22 +291,25 @@ __global__ void nbr_transpose_kernel(const int32_t *__restrict__ nbr, const int3
     if (i >= 0 && i < cap_in) nbrT[(size_t)i * kK + k] = o;      // each (i,k) has at most one o
 }
 
-constexpr int kWgRows = 256;       // output rows per weight-gradient workgroup
+constexpr int kWgRows = 128;       // output rows per weight-gradient workgroup (~2 workgroups per CU at 29k rows)
 
 // One wave = one 16x16 tile of dW[k] (ci tile x co tile) for all 27 offsets; the MFMA K dimension runs over rows:
 //   D[ci][co] += sum_rows X[nbr[row][k]][ci] * dY[row][co]      (4 rows per v_mfma_f32_16x16x4_f32)
 // Per-workgroup partial sums are written to `part` and reduced in fixed order by wgrad_reduce_kernel (deterministic).
+// At most 8 waves (tiles) per workgroup so that every wave keeps its 108 accumulators + the 2 x 27 prefetched
+// operands in <= 256 VGPRs; 64x64 layers use two workgroups (blockIdx.y) per row chunk.
 template <int CIN, int COUT>
-__global__ void __launch_bounds__(((CIN + 15) / 16) * (COUT / 16) * 64)
+__global__ void __launch_bounds__((((CIN + 15) / 16) * (COUT / 16) < 8 ? ((CIN + 15) / 16) * (COUT / 16) : 8) * 64)
 spconv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, const int32_t *__restrict__ nbr,
                     const int32_t *__restrict__ n_ptr, int cap, float *__restrict__ part)
 {
     constexpr int MT = (CIN + 15) / 16, NTT = COUT / 16;
+    constexpr int WPW = MT * NTT < 8 ? MT * NTT : 8;          // waves (16x16 tiles) per workgroup
     __shared__ int nbr_s[kWgRows * kK];
     const int n = min(*n_ptr, cap);
     const int r0 = blockIdx.x * kWgRows;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) + blockIdx.y * WPW;
     const int cit = wave / NTT, cot = wave - cit * NTT;
     const int q = lane >> 4, m16 = lane & 15;
     f32x4 acc[kK];
@@ -314,20 +317,38 @@ spconv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, c
     for (int k = 0; k < kK; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (r0 < n) {                                   // workgroup-uniform
         const int rows = min(kWgRows, n - r0);
-        for (int i = tid; i < rows * kK; i += MT * NTT * 64) nbr_s[i] = nbr[(size_t)r0 * kK + i];
+        for (int i = tid; i < rows * kK; i += WPW * 64) nbr_s[i] = nbr[(size_t)r0 * kK + i];
         __syncthreads();
         const int ci = cit * 16 + m16;
-        for (int s0 = 0; s0 < rows; s0 += 4) {
+        // two-stage software pipeline over 4-row steps: the 27 gathered X values (and the dY value) of step s+1 are
+        // in flight while the MFMAs of step s issue -- the gather latency, not the arithmetic, bounds this kernel
+        float a_buf[2][kK], b_buf[2];
+        unsigned long long live[2];
+        auto fetch = [&](int s0, float *a, float &b, unsigned long long &lv) {
             const int rl = s0 + q;
             const bool rok = rl < rows;
-            const float b = rok ? dy[(size_t)(r0 + rl) * COUT + cot * 16 + m16] : 0.f;
+            b = rok ? dy[(size_t)(r0 + rl) * COUT + cot * 16 + m16] : 0.f;
+            lv = 0ull;
 #pragma unroll
             for (int k = 0; k < kK; ++k) {
                 const int in = rok ? nbr_s[rl * kK + k] : -1;
-                if (__ballot(in >= 0) == 0ull) continue;
-                const float a = (in >= 0 && ci < CIN) ? x[(size_t)in * CIN + ci] : 0.f;
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k], 0, 0, 0);
+                const bool ok = in >= 0 && ci < CIN;
+                const float v = x[ok ? (size_t)in * CIN + ci : 0];          // unconditional load + select
+                a[k] = ok ? v : 0.f;
+                if (__ballot(in >= 0) != 0ull) lv |= 1ull << k;             // wave-uniform: offset k has a pair
             }
+        };
+        fetch(0, a_buf[0], b_buf[0], live[0]);
+        for (int s0 = 0; s0 < rows; s0 += 8) {
+            if (s0 + 4 < rows) fetch(s0 + 4, a_buf[1], b_buf[1], live[1]);
+#pragma unroll
+            for (int k = 0; k < kK; ++k)
+                if ((live[0] >> k) & 1ull) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_buf[0][k], b_buf[0], acc[k], 0, 0, 0);
+            if (s0 + 4 >= rows) break;
+            if (s0 + 8 < rows) fetch(s0 + 8, a_buf[0], b_buf[0], live[0]);
+#pragma unroll
+            for (int k = 0; k < kK; ++k)
+                if ((live[1] >> k) & 1ull) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_buf[1][k], b_buf[1], acc[k], 0, 0, 0);
         }
     }
     // D[row = q*4 + reg][col = m16] -> dW[k][ci = cit*16 + q*4 + reg][co = cot*16 + m16]
@@ -358,9 +379,10 @@ int launch_wgrad(const float *x, const float *dy, const int32_t *nbr, const int3
                  float *dw, int accumulate, hipStream_t stream)
 {
     constexpr int MT = (CIN + 15) / 16, NTT = COUT / 16;
+    constexpr int WPW = MT * NTT < 8 ? MT * NTT : 8;
     const int nwg = cdiv(cap, kWgRows);
-    hipLaunchKernelGGL((spconv_wgrad_kernel<CIN, COUT>), dim3(nwg), dim3(MT * NTT * 64), 0, stream, x, dy, nbr, n_ptr,
-                       cap, part);
+    hipLaunchKernelGGL((spconv_wgrad_kernel<CIN, COUT>), dim3(nwg, MT * NTT / WPW), dim3(WPW * 64), 0, stream, x, dy,
+                       nbr, n_ptr, cap, part);
     const int per = kK * CIN * COUT;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(per, 256)), dim3(256), 0, stream, (const float *)part, n_ptr, cap,
                        per, dw, accumulate);

@@ -235,6 +235,22 @@ def conv2d_fwd(x, w_packed, cout, ksize, scale=None, shift=None, relu=False, y=N
     return y
 
 
+def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False):
+    """x [B,Cin,H,W], dy [B,Cout,H,W] -> dw [Cout,Cin,k,k] on the fp32-MFMA split-K kernel."""
+    _chk_cuda(x, dy)
+    b, cin, h, w = x.shape
+    cout = dy.shape[1]
+    L = _C.lib()
+    if dw is None:
+        dw = torch.empty(cout, cin, ksize, ksize, dtype=torch.float32, device=x.device)
+    wsb = L.sassd_conv2d_wgrad_workspace_bytes(b, cin, cout, h, w, ksize)
+    ws = workspace("conv2d_wgrad", wsb, x.device)
+    _C.check(L.sassd_conv2d_bwd_weight(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), b, cin, cout, h, w, ksize,
+                                       1 if accumulate else 0, _C.ptr(ws), wsb, _C.stream()),
+             "sassd_conv2d_bwd_weight")
+    return dw
+
+
 # --------------------------------------------------------------------------------------------------
 def anchor_mask(coors, row_begin_ptr, row_end_ptr, h0, w0, anchors_bv, voxel_size, coors_range, area_threshold,
                 mask=None):

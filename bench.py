@@ -223,6 +223,10 @@ def main():
     sp_ms = seg_ms["sparse"]
     sp_gbs = (work["bytes_gs"] + work["rulebook_bytes"]) / (sp_ms * 1e-3) / 1e9
     fps = args.steps * B * world / dt
+    traffic = None                       # PMC passes cannot run inside this process: read the committed measurement
+    tj = os.path.join(ROOT, "profiles", "r01_conv2d_hbm_traffic.json")
+    if os.path.exists(tj) and B == 1:
+        traffic = json.load(open(tj))["traffic_bytes_per_launch"]
     out = {
         "metric": "KITTI-Car inference frames/sec (whole job)", "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -234,7 +238,9 @@ def main():
                    "vs_baseline_ref": "reference readme.md:2 '25 FPS' (hardware unstated), per-GPU fps / 25"},
         "roofline": {"bound": "mfma", "kernel": "conv2d_kernel<4,9> (BEV 256->256 3x3, fp32 MFMA 32x32x2)",
                      "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                     "frac": round(achieved_tf / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                     "frac": round(achieved_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
+                     "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "
+                                     "passes, profiles/r01_conv2d_hbm_traffic.json)",
                      "flops_per_launch": conv_flops, "ms_per_launch": round(conv_ms, 4)},
         "roofline_sparse": {"bound": "hbm", "kernels": "7 rulebooks + 14 spconv_fwd_kernel launches",
                             "achieved": round(sp_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -141,6 +141,16 @@ int sassd_conv2d_fwd(const float *x, const float *w_packed, const float *scale, 
                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, int ksize,
                      void *stream);
 
+/* Winograd F(2x2,3x3) variant of the 3x3 / stride 1 / pad 1 convolution (the BEVNet layers cmn.py:240-262): 2.25x
+ * fewer multiplications on the fp32 MFMA, transforms fused (nothing but x, packed weights and y touches HBM).  Same
+ * epilogue as sassd_conv2d_fwd (y = relu?(conv * scale[co] + shift[co]), NULL scale/shift = 1/0).  Requires
+ * Cin % 16 == 0, Cout % 32 == 0, even H and W (sassd_conv2d_wino_supported); relative error ~1e-6 vs the direct kernel. */
+int sassd_conv2d_wino_supported(int Cin, int Cout, int H, int W);
+size_t sassd_conv2d_wino_packed_floats(int Cin, int Cout);
+int sassd_conv2d_wino_pack_weight(const float *w, int Cout, int Cin, float *packed, void *stream);
+int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, const float *scale, const float *shift, int relu,
+                          float *y, int batch, int Cin, int Cout, int H, int W, void *stream);
+
 /* Training: weight gradient of the same convolutions (autograd of nn.Conv2d at cmn.py:240-262 and
  * ssd_rotate_head.py:120-125,424-429; cuDNN in the reference).  x [B,Cin,H,W], dy [B,Cout,H,W] NCHW fp32 ->
  * dw [Cout,Cin,k,k] (torch layout), overwritten or accumulated.  Split-K over pixels with a deterministic second-stage

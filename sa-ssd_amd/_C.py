@@ -75,6 +75,10 @@ _SIGS = {
     "sassd_pts_in_boxes3d": (_I, [_P, _I, _P, _I, _P, _P, _P]),
     "sassd_three_nn_binned_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sassd_three_nn_binned": (_I, [_I, _I, _P, _P, _F, _F, _F, _I, _I, _I, _P, _P, _P, _SZ, _P]),
+    "sassd_conv2d_wino_supported": (_I, [_I, _I, _I, _I]),
+    "sassd_conv2d_wino_packed_floats": (_SZ, [_I, _I]),
+    "sassd_conv2d_wino_pack_weight": (_I, [_P, _I, _I, _P, _P]),
+    "sassd_conv2d_wino_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "sassd_conv2d_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_grad_sumsq": (_I, [_P, C.c_long, _P, _P]),

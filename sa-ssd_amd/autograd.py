@@ -53,15 +53,23 @@ class SparseConvFn(Function):
         return dx, dw, None, None, None
 
 
+def _conv_any(x, weight, ks, packed=None, wino=None, shift=None):
+    """3x3 layers take the Winograd F(2x2,3x3) kernel when the shape allows, everything else the direct kernel."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if ks == 3 and K.conv2d_wino_supported(cin, cout, x.shape[2], x.shape[3]):
+        return K.conv2d_wino_fwd(x, wino if wino is not None else K.conv2d_wino_pack_weight(weight), cout, None, shift)
+    return K.conv2d_fwd(x, packed if packed is not None else K.conv2d_pack_weight(weight), cout, ks, None, shift)
+
+
 class Conv2dFn(Function):
-    """NCHW fp32 conv (3x3 pad 1 / 1x1) + optional bias on the fp32-MFMA kernel; data gradient = the same kernel with
-    flipped, transposed weights."""
+    """NCHW fp32 conv (3x3 pad 1 / 1x1) + optional bias on the fp32-MFMA kernels; data gradient = the same kernels
+    with flipped, transposed weights; weight gradient = the split-K MFMA kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed):
+    def forward(ctx, x, weight, bias, packed, wino):
         x = x.contiguous()
-        cout, cin, ks, _ = weight.shape
-        y = K.conv2d_fwd(x, packed, cout, ks, None, bias.detach().contiguous() if bias is not None else None, False)
+        ks = weight.shape[2]
+        y = _conv_any(x, weight.detach(), ks, packed, wino, bias.detach().contiguous() if bias is not None else None)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -70,16 +78,16 @@ class Conv2dFn(Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        cout, cin, ks, _ = weight.shape
+        ks = weight.shape[2]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # [Cin, Cout, k, k], taps mirrored
-            dx = K.conv2d_fwd(dy, K.conv2d_pack_weight(wt), cin, ks)
+            dx = _conv_any(dy, wt, ks)
         if ctx.needs_input_grad[1]:
             dw = K.conv2d_bwd_weight(x, dy, ks)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class DensifyFn(Function):

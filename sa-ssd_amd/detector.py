@@ -124,7 +124,21 @@ class _HipConv2d(nn.Conv2d):
             self._pk, self._pkv = K.conv2d_pack_weight(self.weight.detach().float().contiguous()), v
         return self._pk
 
+    def packed_wino(self, h, w):
+        """Winograd-packed weights when this layer / feature-map shape supports the F(2x2,3x3) kernel, else None."""
+        if self.kernel_size[0] != 3 or not K.conv2d_wino_supported(self.in_channels, self.out_channels, h, w):
+            return None
+        v = self.weight._version
+        if getattr(self, "_pkw", None) is None or self._pkwv != v or self._pkw.device != self.weight.device:
+            self._pkw, self._pkwv = K.conv2d_wino_pack_weight(self.weight.detach().float().contiguous()), v
+        return self._pkw
+
     def hip_forward(self, x, scale=None, shift=None, relu=False):
+        if shift is None and self.bias is not None:
+            shift = self.bias.detach().float().contiguous()
+        pw = self.packed_wino(x.shape[2], x.shape[3])
+        if pw is not None:
+            return K.conv2d_wino_fwd(x.contiguous().float(), pw, self.out_channels, scale, shift, relu)
         self.packed_weight()
         if shift is None and self.bias is not None:
             shift = self.bias.detach().float().contiguous()
@@ -133,7 +147,8 @@ class _HipConv2d(nn.Conv2d):
 
     def forward(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            return Conv2dFn.apply(x.float(), self.weight, self.bias, self.packed_weight())
+            pw = self.packed_wino(x.shape[2], x.shape[3])
+            return Conv2dFn.apply(x.float(), self.weight, self.bias, None if pw is not None else self.packed_weight(), pw)
         return self.hip_forward(x)
 
 

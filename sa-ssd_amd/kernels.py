@@ -235,6 +235,37 @@ def conv2d_fwd(x, w_packed, cout, ksize, scale=None, shift=None, relu=False, y=N
     return y
 
 
+def conv2d_wino_supported(cin, cout, h, w):
+    return bool(_C.lib().sassd_conv2d_wino_supported(int(cin), int(cout), int(h), int(w)))
+
+
+def conv2d_wino_pack_weight(w):
+    """w [Cout,Cin,3,3] -> G g G^T packed in MFMA A-operand order (once per weight update)."""
+    _chk_cuda(w)
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    L = _C.lib()
+    n = L.sassd_conv2d_wino_packed_floats(cin, cout)
+    if n == 0:
+        raise ValueError("winograd conv needs Cin % 16 == 0")
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
+    _C.check(L.sassd_conv2d_wino_pack_weight(_C.ptr(w.contiguous()), cout, cin, _C.ptr(packed), _C.stream()),
+             "sassd_conv2d_wino_pack_weight")
+    return packed
+
+
+def conv2d_wino_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=None):
+    """3x3 pad-1 conv through Winograd F(2x2,3x3) on the fp32 MFMA; same epilogue as conv2d_fwd."""
+    _chk_cuda(x, w_packed)
+    b, cin, h, w = x.shape
+    if y is None:
+        y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().sassd_conv2d_wino_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift),
+                                            1 if relu else 0, _C.ptr(y), b, cin, cout, h, w, _C.stream()),
+             "sassd_conv2d_wino_fwd")
+    return y
+
+
 def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False):
     """x [B,Cin,H,W], dy [B,Cout,H,W] -> dw [Cout,Cin,k,k] on the fp32-MFMA split-K kernel."""
     _chk_cuda(x, dy)

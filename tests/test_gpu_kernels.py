@@ -258,3 +258,29 @@ def test_spconv_backward(dev, cin, cout, strided):
         dx = K.spconv_bwd_data(dyd, nbT, n_i, cap_i, K.spconv_pack_weight_t(w.detach().to(dev)), 27, cin, cout)
         e = (dx[:nin].cpu() - x.grad).abs().max().item()
         assert e < 2e-4 * max(1.0, x.grad.abs().max().item()), e
+
+
+@pytest.mark.parametrize("b,cin,cout,hw,relu", [(1, 16, 32, (4, 6), False), (2, 32, 64, (10, 14), True),
+                                               (1, 320, 256, (200, 176), True), (2, 256, 256, (50, 44), False),
+                                               (1, 48, 96, (2, 2), True), (3, 64, 160, (6, 130), True)])
+def test_conv2d_winograd(dev, b, cin, cout, hw, relu):
+    """Winograd F(2x2,3x3) conv against torch-CPU conv2d (fp32 reference of the same op) and against the direct HIP
+    kernel: odd tile counts, tiles wrapping rows / images inside a 32-tile group, cout not a multiple of 64, borders."""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(b, cin, *hw, generator=g)
+    x[:, :, : hw[0] // 2] *= (torch.rand(b, cin, hw[0] // 2, hw[1], generator=g) > 0.7).float()    # sparse like BEV
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x, w, None, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    ref = torch.relu(ref) if relu else ref
+    assert K.conv2d_wino_supported(cin, cout, *hw)
+    xd, wd = x.to(dev), w.to(dev)
+    y = K.conv2d_wino_fwd(xd, K.conv2d_wino_pack_weight(wd), cout, sc.to(dev), sh.to(dev), relu)
+    err = (y.cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    if hw[1] >= 4:
+        yd = K.conv2d_fwd(xd, K.conv2d_pack_weight(wd), cout, 3, sc.to(dev), sh.to(dev), relu)
+        assert (y - yd).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    y2 = K.conv2d_wino_fwd(xd, K.conv2d_wino_pack_weight(wd), cout)              # no epilogue
+    assert (y2.cpu() - torch.nn.functional.conv2d(x, w, None, 1, 1)).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert not K.conv2d_wino_supported(28, 28, 200, 176) and not K.conv2d_wino_supported(256, 256, 199, 176)

@@ -5,19 +5,23 @@
 // fewer multiplications: F(2x2,3x3) needs 16 instead of 36 per 2x2 output tile and channel pair (2.25x), at the price
 // of cheap add-only transforms:   Y = A^T [ (G g G^T) (.) (B^T d B) ] A,   summed over input channels.
 //
-// One kernel, everything fused (no transformed tensors in HBM):
+// One kernel, everything fused (no transformed tensors in HBM), WAVE-SPECIALISED:
 //   * work unit (workgroup, 8 waves) = 64 couts x 32 output tiles (2x2 pixels each, linear tile order -> 8800 tiles
-//     = 275 groups, no padding waste) x all 16 Winograd positions;  wave (xi = w & 3, cb = w >> 2) owns the 4 positions
-//     (xi, nu = 0..3) of a 32-cout block: 4 accumulator tiles of v_mfma_f32_32x32x2_f32 (64 VGPRs).
-//   * per chunk of 16 input channels every thread loads ONE 4x4 input patch (its tile, its channel) straight from
-//     global memory, transforms it in registers (32 adds) and writes the 16 values B^T d B into LDS in exactly the
-//     layout the MFMA B-operand reads want (one ds_read_b128 per position and half chunk);
-//   * the pre-transformed weights G g G^T are packed offline in MFMA A-operand order, so a wave reads its own
-//     weights with one coalesced 16-byte load per position and half chunk, prefetched one half chunk ahead -- they
-//     have no reuse inside a workgroup, so they never touch LDS;
-//   * one barrier per 16-channel chunk (32 MFMAs per wave); the output transform A^T M A is split: each wave
-//     reduces over nu in registers, the four xi-waves are combined through LDS, then scale/shift/ReLU and float2
-//     stores of the 2x2 pixels.
+//     = 275 groups, no padding waste) x all 16 Winograd positions.
+//   * waves 0-3 are MFMA waves: wave xi owns the 4 positions (xi, nu = 0..3) of both 32-cout blocks = 8 accumulator
+//     tiles of v_mfma_f32_32x32x2_f32 (128 VGPRs), 64 MFMAs per 16-channel chunk.  Their only other instructions are
+//     8 ds_read_b128 (B operands) and 16 coalesced 16-byte weight loads per chunk: the pre-transformed weights
+//     G g G^T are packed offline in MFMA A-operand order and have no reuse inside a workgroup, so they go straight
+//     to registers, prefetched half a chunk ahead (cout groups are the slowest grid index: the 1 MB slice in use
+//     stays L2-resident).
+//   * waves 4-7 are LOADER waves: each thread owns one tile and two channels of the chunk; it loads the two 4x4 input
+//     patches straight from global memory (per-lane byte offsets computed once, a scalar base advances per chunk),
+//     transforms them in registers (B^T d B: 32 adds each) and writes the 16 values into LDS in exactly the layout
+//     the B-operand reads want.  One SIMD = one MFMA wave + one loader wave, so the MFMA pipe never waits behind
+//     VMEM issue: measured ablations of the unspecialised versions showed MFMA time (0.165 ms) and load/transform
+//     issue time (0.17 ms) adding up almost serially (0.27-0.33 ms), whatever the prefetch depth.
+//   * one barrier per chunk; the output transform A^T M A is split: each MFMA wave reduces over nu in registers, the
+//     four xi are combined through LDS by all 8 waves, then scale/shift/ReLU and float2 stores of the 2x2 pixels.
 // Numerics: F(2,3) in fp32 has a relative error ~1e-6 (transform matrices hold only 0, +-1, +-1/2).
 #include "common.h"
 
@@ -37,6 +41,7 @@ struct WinoParams {
     int TH, TW, tiles;                   // tile rows / cols per image, total tiles (B * TH * TW)
     int ncb64;                           // cout groups of 64
     int relu;
+    int dbg;                             // reserved for ablation builds
 };
 
 // w [Cout][Cin][3][3] -> U = G g G^T packed as [cb32][half chunk of 8 ci][pos 16][lane 64][4]:
@@ -70,147 +75,167 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
     extern __shared__ float smem[];                  // 2 x V buffer (64 KB); reused by the output reduction
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xi = wave & 3, cbw = wave >> 2;        // position row, 32-cout block inside the 64
-    const int grp = blockIdx.x / P.ncb64, cg = blockIdx.x - grp * P.ncb64;
+    // cout group slowest: all workgroups in flight share ONE 64-cout slice of the transformed weights
+    const int ngrp = gridDim.x / P.ncb64;
+    const int cg = blockIdx.x / ngrp, grp = blockIdx.x - cg * ngrp;
     const int HW = P.H * P.W;
+    const int nchunk = P.Cin / kKC;
+    f32x16 acc[4][2];                                // MFMA waves only: [nu][cout block]
 
-    // ---- loader role: thread -> (tile = tid & 31, channel-in-chunk = tid >> 5) ---------------------------------------
-    const int ltile = tid & 31, lci = tid >> 5;
-    const int gt = grp * kNT + ltile;                // global tile index (may run past the end in the last group)
-    int tb = 0, ty = 0, tx = 0;
-    const bool tile_ok = gt < P.tiles;
-    if (tile_ok) {
-        tb = gt / (P.TH * P.TW);
-        const int r = gt - tb * P.TH * P.TW;
-        ty = r / P.TW;
-        tx = r - ty * P.TW;
-    }
-    // 4 patch rows (2ty-1 .. 2ty+2) x 4 columns (2tx-1 .. 2tx+2); element offsets clamped to a valid address
-    int roff[4];
-    unsigned vmask = 0;                              // bit (r*4 + c): inside the image
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int yy = 2 * ty - 1 + r;
-        const bool rok = tile_ok && yy >= 0 && yy < P.H;
-        roff[r] = rok ? yy * P.W + 2 * tx - 1 : 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int xx = 2 * tx - 1 + c;
-            if (rok && xx >= 0 && xx < P.W) vmask |= 1u << (r * 4 + c);
+    if (wave >= 4) {
+        // ================================ loader waves ================================================================
+        const int lt = tid - 256;
+        const int ltile = lt & 31, cil = lt >> 5;    // tile, channels cil and cil + 8 of the chunk
+        const int gt = grp * kNT + ltile;            // global tile index (may run past the end in the last group)
+        int tb = 0, ty = 0, tx = 0;
+        const bool tile_ok = gt < P.tiles;
+        if (tile_ok) {
+            tb = gt / (P.TH * P.TW);
+            const int r = gt - tb * P.TH * P.TW;
+            ty = r / P.TW;
+            tx = r - ty * P.TW;
         }
-    }
-    const float *xb = P.x + (size_t)tb * P.Cin * HW;
-    float raw[16];
-    auto fetch_patch = [&](int chunk) {
-        const float *src = xb + (size_t)(chunk * kKC + lci) * HW;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                // unconditional load from a clamped address; the zero-padding select happens in transform_store so
-                // that nothing consumes the load (no s_waitcnt) while the MFMAs of the first half chunk issue
-                raw[r * 4 + c] = src[((vmask >> (r * 4 + c)) & 1u) ? roff[r] + c : 0];
-            }
-    };
-    // B^T d B in registers, then scatter to V[pos][half][kh][tile][s]
-    auto transform_store = [&](float *vbuf) {
-        float t[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) raw[e] = ((vmask >> e) & 1u) ? raw[e] : 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t[0 * 4 + c] = raw[0 * 4 + c] - raw[2 * 4 + c];
-            t[1 * 4 + c] = raw[1 * 4 + c] + raw[2 * 4 + c];
-            t[2 * 4 + c] = raw[2 * 4 + c] - raw[1 * 4 + c];
-            t[3 * 4 + c] = raw[1 * 4 + c] - raw[3 * 4 + c];
-        }
-        const int h = lci >> 3, kh = lci & 1, s = (lci & 7) >> 1;
-        float *dst = vbuf + ((h * 2 + kh) * kNT + ltile) * 4 + s;
+        // 4 patch rows (2ty-1 .. 2ty+2) x 4 columns (2tx-1 .. 2tx+2): per-lane BYTE offsets (batch, channel-in-chunk,
+        // row, column; clamped to a valid element where the patch leaves the image) are computed ONCE -- per chunk only
+        // a wave-uniform base pointer advances (saddr + 32-bit voffset addressing, no VALU address arithmetic)
+        unsigned off[16];
+        unsigned vmask = 0;                          // bit (r*4 + c): inside the image
+        const int lane_base = (tb * P.Cin + cil) * HW;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            dst[(r * 4 + 0) * (2 * 2 * kNT * 4)] = t[r * 4 + 0] - t[r * 4 + 2];
-            dst[(r * 4 + 1) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] + t[r * 4 + 2];
-            dst[(r * 4 + 2) * (2 * 2 * kNT * 4)] = t[r * 4 + 2] - t[r * 4 + 1];
-            dst[(r * 4 + 3) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] - t[r * 4 + 3];
+            const int yy = 2 * ty - 1 + r;
+            const bool rok = tile_ok && yy >= 0 && yy < P.H;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int xx = 2 * tx - 1 + c;
+                const bool ok = rok && xx >= 0 && xx < P.W;
+                if (ok) vmask |= 1u << (r * 4 + c);
+                off[r * 4 + c] = 4u * (unsigned)(lane_base + (ok ? yy * P.W + xx : 0));
+            }
         }
-    };
-
-    // ---- compute role ---------------------------------------------------------------------------------------------------
-    const int cb32 = cg * 2 + cbw;                   // global 32-cout block
-    const int nhc = P.Cin / 8;
-    const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(P.wp) + ((size_t)cb32 * nhc * 16 + xi * 4) * 64 + lane;
-    auto fetch_w = [&](int hc, f32x4 *a) {
+        const bool wave_interior = __ballot(vmask != 0xFFFFu) == 0ull;  // wave-uniform: no zero padding needed
+        float rawA[16], rawB[16];
+        auto fetch_patches = [&](int chunk) {
+            const char *sa = reinterpret_cast<const char *>(P.x + (size_t)chunk * kKC * HW);    // wave-uniform
+            const char *sb = sa + (size_t)8 * HW * sizeof(float);
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) a[nu] = wsrc[((size_t)hc * 16 + nu) * 64];
-    };
-    f32x16 acc[4];
+            for (int e = 0; e < 16; ++e) rawA[e] = *reinterpret_cast<const float *>(sa + off[e]);
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
+            for (int e = 0; e < 16; ++e) rawB[e] = *reinterpret_cast<const float *>(sb + off[e]);
+        };
+        // B^T d B in registers, then scatter to V[pos][half][kh][tile][s]
+        auto transform_store = [&](float *vbuf, float *raw, int h) {
+            float t[16];
+            if (!wave_interior) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
-
-    auto mma_half = [&](const float *vbuf, int h, const f32x4 *a) {
-        const f32x4 *vb = reinterpret_cast<const f32x4 *>(vbuf) + ((h * 2 + (lane >> 5)) * kNT + (lane & 31));
-        f32x4 bq[4];
+                for (int e = 0; e < 16; ++e) raw[e] = ((vmask >> e) & 1u) ? raw[e] : 0.f;
+            }
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) bq[nu] = vb[(xi * 4 + nu) * (2 * 2 * kNT)];
+            for (int c = 0; c < 4; ++c) {
+                t[0 * 4 + c] = raw[0 * 4 + c] - raw[2 * 4 + c];
+                t[1 * 4 + c] = raw[1 * 4 + c] + raw[2 * 4 + c];
+                t[2 * 4 + c] = raw[2 * 4 + c] - raw[1 * 4 + c];
+                t[3 * 4 + c] = raw[1 * 4 + c] - raw[3 * 4 + c];
+            }
+            const int kh = cil & 1, s = cil >> 1;
+            float *dst = vbuf + ((h * 2 + kh) * kNT + ltile) * 4 + s;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu)
-                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nu][s], bq[nu][s], acc[nu], 0, 0, 0);
-    };
-
-    const int nchunk = P.Cin / kKC;
-    f32x4 a0[4], a1[4];
-    fetch_patch(0);
-    fetch_w(0, a0);
-    transform_store(smem);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        float *vcur = smem + (c & 1) * kVBuf, *vnxt = smem + ((c + 1) & 1) * kVBuf;
-        // branch-free body (the last iteration refetches / retransforms chunk nchunk-1 into the unused buffer) so that
-        // the scheduler can interleave the loader's VALU / LDS-write work with the MFMAs of the same wave: the two
-        // waves of a SIMD run in lockstep between barriers and cannot cover for each other
-        const int cn = min(c + 1, nchunk - 1);
-        fetch_w(2 * c + 1, a1);                      // weights of the second half chunk
-        fetch_patch(cn);                             // next chunk's input patch: in flight during 16 MFMAs
-        __builtin_amdgcn_sched_barrier(0);           // keep every consumer of those loads below the first half's MFMAs
-        mma_half(vcur, 0, a0);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch_w(2 * cn, a0);
-        transform_store(vnxt);                       // vnxt was last read during chunk c-1 (barrier since then)
-        mma_half(vcur, 1, a1);
+            for (int r = 0; r < 4; ++r) {
+                dst[(r * 4 + 0) * (2 * 2 * kNT * 4)] = t[r * 4 + 0] - t[r * 4 + 2];
+                dst[(r * 4 + 1) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] + t[r * 4 + 2];
+                dst[(r * 4 + 2) * (2 * 2 * kNT * 4)] = t[r * 4 + 2] - t[r * 4 + 1];
+                dst[(r * 4 + 3) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] - t[r * 4 + 3];
+            }
+        };
+        fetch_patches(0);
+        transform_store(smem, rawA, 0);
+        transform_store(smem, rawB, 1);
+        fetch_patches(min(1, nchunk - 1));           // chunk 1 in flight across the first barrier
         __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            float *vnxt = smem + ((c + 1) & 1) * kVBuf;          // last read by the MFMA waves during chunk c-1
+            if (c + 1 < nchunk) {
+                transform_store(vnxt, rawA, 0);
+                transform_store(vnxt, rawB, 1);
+                if (c + 2 < nchunk) fetch_patches(c + 2);        // in flight during the whole next chunk
+            }
+            __syncthreads();
+        }
+    } else {
+        // ================================ MFMA waves ==================================================================
+        const int xi = wave;
+        const int nhc = P.Cin / 8;
+        // weights of (cout block cb, position (xi, nu), half chunk hc): float4 at wsrc[((cb*nhc + hc)*16 + nu) * 64]
+        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(P.wp) + ((size_t)(cg * 2) * nhc * 16 + xi * 4) * 64 + lane;
+        f32x4 wq[2][2][4];                           // [buffer][cb][nu]
+        auto fetch_w = [&](int hc, f32x4 (*wdst)[4]) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) wdst[cb][nu] = wsrc[(((size_t)cb * nhc + hc) * 16 + nu) * 64];
+        };
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nu][cb][r] = 0.f;
+        fetch_w(0, wq[0]);
+        __syncthreads();
+        for (int c = 0; c < nchunk; ++c) {
+            const float *vcur = smem + (c & 1) * kVBuf;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                fetch_w(min(2 * c + h + 1, nhc - 1), wq[(h + 1) & 1]);       // next half chunk's weights
+                const f32x4 *vb = reinterpret_cast<const f32x4 *>(vcur) + ((h * 2 + (lane >> 5)) * kNT + (lane & 31));
+                f32x4 bq[4];
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) bq[nu] = vb[(xi * 4 + nu) * (2 * 2 * kNT)];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+                            acc[nu][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[h][cb][nu][s], bq[nu][s], acc[nu][cb],
+                                                                               0, 0, 0);
+            }
+            __syncthreads();
+        }
     }
 
-    // ---- output transform: over nu in registers, over xi through LDS ---------------------------------------------------
+    // ---- output transform: over nu in registers (MFMA waves), over xi through LDS (all waves) --------------------------
     // P_j[xi] = sum_nu M[xi][nu] A[nu][j],  A^T = [[1,1,1,0],[0,1,-1,-1]]
-    float *red = smem;                               // [cbw 2][xi 4][j 2][reg 16][lane 64]  = 64 KB
+    float *red = smem;                               // [cb 2][xi 4][j 2][reg 16][lane 64]  = 64 KB
+    if (wave < 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float p0 = acc[0][r] + acc[1][r] + acc[2][r];
-        const float p1 = acc[1][r] - acc[2][r] - acc[3][r];
-        red[(((cbw * 4 + xi) * 2 + 0) * 16 + r) * 64 + lane] = p0;
-        red[(((cbw * 4 + xi) * 2 + 1) * 16 + r) * 64 + lane] = p1;
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p0 = acc[0][cb][r] + acc[1][cb][r] + acc[2][cb][r];
+                const float p1 = acc[1][cb][r] - acc[2][cb][r] - acc[3][cb][r];
+                red[(((cb * 4 + wave) * 2 + 0) * 16 + r) * 64 + lane] = p0;
+                red[(((cb * 4 + wave) * 2 + 1) * 16 + r) * 64 + lane] = p1;
+            }
     }
     __syncthreads();
-    // wave (cbw, q = xi) finishes registers 4q .. 4q+3 of its cout block: Y[i][j] = sum_xi A^T[i][xi] P_j[xi]
+    // wave w finishes registers 4*(w & 3) .. +3 of cout block (w >> 2): Y[i][j] = sum_xi A^T[i][xi] P_j[xi]
     const int otile = grp * kNT + (lane & 31);
     if (otile < P.tiles) {
         const int ob = otile / (P.TH * P.TW);
         const int orr = otile - ob * P.TH * P.TW;
         const int oty = orr / P.TW, otx = orr - oty * P.TW;
+        const int cb = wave >> 2;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int r = xi * 4 + rr;
-            const int co = cb32 * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int r = (wave & 3) * 4 + rr;
+            const int co = (cg * 2 + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (co >= P.Cout) continue;
             float pj[4][2];
 #pragma unroll
             for (int x4 = 0; x4 < 4; ++x4)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) pj[x4][j] = red[(((cbw * 4 + x4) * 2 + j) * 16 + r) * 64 + lane];
+                for (int j = 0; j < 2; ++j) pj[x4][j] = red[(((cb * 4 + x4) * 2 + j) * 16 + r) * 64 + lane];
             const float sc = P.scale ? P.scale[co] : 1.f, sh = P.shift ? P.shift[co] : 0.f;
             float *dst = P.y + ((size_t)ob * P.Cout + co) * HW + (size_t)(2 * oty) * P.W + 2 * otx;
 #pragma unroll
@@ -227,7 +252,10 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
         }
     }
 }
+int g_wino_dbg = 0;
 }  // namespace
+
+extern "C" void sassd_debug_set_wino(int flags) { g_wino_dbg = flags; }
 
 extern "C" int sassd_conv2d_wino_supported(int Cin, int Cout, int H, int W)
 {
@@ -257,12 +285,14 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
 {
     if (!x || !w_packed || !y || batch < 1 || !sassd_conv2d_wino_supported(Cin, Cout, H, W)) return SASSD_EINVAL;
     if (((uintptr_t)y & 7) || ((uintptr_t)w_packed & 15)) return SASSD_EINVAL;
+    if ((size_t)batch * Cin * H * W >= (1u << 29)) return SASSD_EINVAL;         // 32-bit per-lane element offsets
     WinoParams P;
     P.x = x; P.wp = w_packed; P.scale = scale; P.shift = shift; P.y = y;
     P.B = batch; P.Cin = Cin; P.Cout = Cout; P.H = H; P.W = W;
     P.TH = H / 2; P.TW = W / 2; P.tiles = batch * P.TH * P.TW;
     P.ncb64 = cdiv(Cout, kCoW);
     P.relu = relu;
+    P.dbg = g_wino_dbg;
     const size_t lds = (size_t)2 * kVBuf * sizeof(float);           // 65 536 B
     static bool attr_done = false;
     if (!attr_done) {

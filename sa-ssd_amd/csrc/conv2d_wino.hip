@@ -14,12 +14,14 @@
 //     G g G^T are packed offline in MFMA A-operand order and have no reuse inside a workgroup, so they go straight
 //     to registers, prefetched half a chunk ahead (cout groups are the slowest grid index: the 1 MB slice in use
 //     stays L2-resident).
-//   * waves 4-7 are LOADER waves: each thread owns one tile and two channels of the chunk; it loads the two 4x4 input
-//     patches straight from global memory (per-lane byte offsets computed once, a scalar base advances per chunk),
-//     transforms them in registers (B^T d B: 32 adds each) and writes the 16 values into LDS in exactly the layout
-//     the B-operand reads want.  One SIMD = one MFMA wave + one loader wave, so the MFMA pipe never waits behind
-//     VMEM issue: measured ablations of the unspecialised versions showed MFMA time (0.165 ms) and load/transform
-//     issue time (0.17 ms) adding up almost serially (0.27-0.33 ms), whatever the prefetch depth.
+//   * waves 4-7 are LOADER waves.  The input rows a 32-tile group needs (<= 2 runs of tiles inside one tile row each:
+//     4 image rows x <= 72 columns per run and channel) are staged in LDS by 16-byte global->LDS DMA (zero page for
+//     everything outside the image), 36 wave-instructions per 16-channel chunk instead of the 128 scalar-dword
+//     gathers of a per-thread 4x4 patch fetch; each thread then reads its two 4x4 patches (its tile, channels c and
+//     c + 8) from LDS, transforms them in registers (B^T d B: 32 adds each) and writes the 16 values into LDS in
+//     exactly the layout the B-operand reads want.  VMEM instruction COUNT is what matters: measured ablations
+//     showed MFMA time (0.165 ms) and memory-instruction time (16 cycles per wave-instruction in the texture
+//     addresser) adding up almost serially on a CU, whatever the prefetch depth or wave arrangement.
 //   * one barrier per chunk; the output transform A^T M A is split: each MFMA wave reduces over nu in registers, the
 //     four xi are combined through LDS by all 8 waves, then scale/shift/ReLU and float2 stores of the 2x2 pixels.
 // Numerics: F(2,3) in fp32 has a relative error ~1e-6 (transform matrices hold only 0, +-1, +-1/2).
@@ -33,6 +35,14 @@ constexpr int kNT = 32;                  // tiles per workgroup
 constexpr int kCoW = 64;                 // couts per workgroup
 constexpr int kKC = 16;                  // input channels per chunk
 constexpr int kVBuf = 16 * 2 * 2 * kNT * 4;        // floats per V buffer: [pos][half][kh][tile][4]  (8192 = 32 KB)
+constexpr int kRawW = 72;                // staged columns per run (66 needed + alignment slack), 18 float4
+constexpr int kRawBuf = kKC * 2 * 4 * kRawW;       // floats per raw-row buffer: [ci][run][row][col]  (9216 = 36 KB)
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+
+__device__ __attribute__((aligned(16))) float g_wino_zero[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ long long g_wino_prof[16];      // -DSASSD_WINO_PROF builds: per-phase cycle counts of workgroup 0 (P.dbg & 1)
 
 struct WinoParams {
     const float *x, *wp, *scale, *shift;
@@ -72,7 +82,7 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
 
 __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
 {
-    extern __shared__ float smem[];                  // 2 x V buffer (64 KB); reused by the output reduction
+    extern __shared__ float smem[];                  // 2 x V buffer (64 KB; reused by the output reduction) + 2 x raw rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // cout group slowest: all workgroups in flight share ONE 64-cout slice of the transformed weights
@@ -82,54 +92,59 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
     const int nchunk = P.Cin / kKC;
     f32x16 acc[4][2];                                // MFMA waves only: [nu][cout block]
 
+    float *rawbuf = smem + 2 * kVBuf;                // 2 x raw-row buffer
     if (wave >= 4) {
         // ================================ loader waves ================================================================
         const int lt = tid - 256;
-        const int ltile = lt & 31, cil = lt >> 5;    // tile, channels cil and cil + 8 of the chunk
-        const int gt = grp * kNT + ltile;            // global tile index (may run past the end in the last group)
-        int tb = 0, ty = 0, tx = 0;
-        const bool tile_ok = gt < P.tiles;
-        if (tile_ok) {
-            tb = gt / (P.TH * P.TW);
-            const int r = gt - tb * P.TH * P.TW;
-            ty = r / P.TW;
-            tx = r - ty * P.TW;
+        // the group's 32 linear tiles form at most two runs, each inside one tile row (TW >= 32 is required)
+        const int g0 = grp * kNT;
+        const int tpi = P.TH * P.TW;
+        int rb[2], rty[2], rtx[2], rn[2];            // image, tile row, first tile column, length of each run
+        {
+            const int b0 = g0 / tpi, r0 = g0 - b0 * tpi;
+            rb[0] = b0; rty[0] = r0 / P.TW; rtx[0] = r0 - rty[0] * P.TW;
+            rn[0] = min(min(kNT, P.TW - rtx[0]), P.tiles - g0);
+            const int g1 = g0 + rn[0];
+            rn[1] = max(min(kNT - rn[0], P.tiles - g1), 0);
+            const int b1 = g1 / tpi, r1 = g1 - b1 * tpi;
+            rb[1] = b1; rty[1] = r1 / P.TW; rtx[1] = 0;
         }
-        // 4 patch rows (2ty-1 .. 2ty+2) x 4 columns (2tx-1 .. 2tx+2): per-lane BYTE offsets (batch, channel-in-chunk,
-        // row, column; clamped to a valid element where the patch leaves the image) are computed ONCE -- per chunk only
-        // a wave-uniform base pointer advances (saddr + 32-bit voffset addressing, no VALU address arithmetic)
-        unsigned off[16];
-        unsigned vmask = 0;                          // bit (r*4 + c): inside the image
-        const int lane_base = (tb * P.Cin + cil) * HW;
+        int cola[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int yy = 2 * ty - 1 + r;
-            const bool rok = tile_ok && yy >= 0 && yy < P.H;
+        for (int q = 0; q < 2; ++q) cola[q] = (2 * rtx[q] - 1) & ~3;        // 16-byte aligned first staged column
+        // ---- DMA role: float4 i = lt + 256*k of the raw buffer, i = ((ci*2 + run)*4 + row)*18 + f4 --------------------
+        const float *dsrc[9];
+        unsigned dvalid = 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int xx = 2 * tx - 1 + c;
-                const bool ok = rok && xx >= 0 && xx < P.W;
-                if (ok) vmask |= 1u << (r * 4 + c);
-                off[r * 4 + c] = 4u * (unsigned)(lane_base + (ok ? yy * P.W + xx : 0));
+        for (int k = 0; k < 9; ++k) {
+            const int i = lt + 256 * k;
+            const int f4 = i % 18, row = (i / 18) & 3, run = (i / 72) & 1, ci = i / 144;
+            const int yy = 2 * rty[run] - 1 + row, xx = cola[run] + 4 * f4;
+            const bool ok = rn[run] > 0 && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;    // W % 4 == 0: all or nothing
+            dsrc[k] = ok ? P.x + ((size_t)(rb[run] * P.Cin + ci) * P.H + yy) * P.W + xx : g_wino_zero;
+            if (ok) dvalid |= 1u << k;
+        }
+        const size_t cstride = (size_t)kKC * HW;
+        const int wl = wave - 4;
+        auto dma_rows = [&](float *dst) {            // issues the next chunk's rows and advances the pointers
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)dsrc[k], (lds_ptr_t)(dst + (wl * 64 + 256 * k) * 4), 16, 0, 0);
+                dsrc[k] += ((dvalid >> k) & 1u) ? cstride : 0;
             }
-        }
-        const bool wave_interior = __ballot(vmask != 0xFFFFu) == 0ull;  // wave-uniform: no zero padding needed
-        float rawA[16], rawB[16];
-        auto fetch_patches = [&](int chunk) {
-            const char *sa = reinterpret_cast<const char *>(P.x + (size_t)chunk * kKC * HW);    // wave-uniform
-            const char *sb = sa + (size_t)8 * HW * sizeof(float);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) rawA[e] = *reinterpret_cast<const float *>(sa + off[e]);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) rawB[e] = *reinterpret_cast<const float *>(sb + off[e]);
         };
-        // B^T d B in registers, then scatter to V[pos][half][kh][tile][s]
-        auto transform_store = [&](float *vbuf, float *raw, int h) {
-            float t[16];
-            if (!wave_interior) {
+        // ---- transform role: thread -> (tile = lt & 31, channels cil and cil + 8 of the chunk) ------------------------
+        const int ltile = lt & 31, cil = lt >> 5;
+        const int trun = ltile < rn[0] ? 0 : 1;
+        const int ttx = trun == 0 ? rtx[0] + ltile : ltile - rn[0];
+        const int pbase = (trun * 4) * kRawW + (2 * ttx - 1 - cola[trun]);    // + (ci*2*4 + r) * kRawW + c
+        auto transform_store = [&](const float *rawrows, float *vbuf, int h) {
+            const float *src = rawrows + ((cil + 8 * h) * 8) * kRawW + pbase;
+            float raw[16], t[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) raw[e] = ((vmask >> e) & 1u) ? raw[e] : 0.f;
-            }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) raw[r * 4 + c] = src[r * kRawW + c];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 t[0 * 4 + c] = raw[0 * 4 + c] - raw[2 * 4 + c];
@@ -138,6 +153,8 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
                 t[3 * 4 + c] = raw[1 * 4 + c] - raw[3 * 4 + c];
             }
             const int kh = cil & 1, s = cil >> 1;
+            // (a tile-fastest layout makes these scalar writes bank-conflict free but costs the MFMA waves 4x the
+            //  B-operand read instructions: measured 7 % slower overall)
             float *dst = vbuf + ((h * 2 + kh) * kNT + ltile) * 4 + s;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -147,20 +164,44 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
                 dst[(r * 4 + 3) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] - t[r * 4 + 3];
             }
         };
-        fetch_patches(0);
-        transform_store(smem, rawA, 0);
-        transform_store(smem, rawB, 1);
-        fetch_patches(min(1, nchunk - 1));           // chunk 1 in flight across the first barrier
+        dma_rows(rawbuf);                            // chunk 0 -> raw[0]
+        __syncthreads();                             // (the compiler drains vmcnt before every barrier)
+        transform_store(rawbuf, smem, 0);
+        transform_store(rawbuf, smem, 1);
+        if (nchunk > 1) dma_rows(rawbuf + kRawBuf);  // chunk 1 -> raw[1]
         __syncthreads();
+#ifdef SASSD_WINO_PROF
+        long long lt_tr = 0, lt_dma = 0, lt_bar = 0;
+#endif
         for (int c = 0; c < nchunk; ++c) {
-            float *vnxt = smem + ((c + 1) & 1) * kVBuf;          // last read by the MFMA waves during chunk c-1
+            // raw[(c+1)&1] holds chunk c+1 (landed before the last barrier); V[(c+1)&1] was last read during chunk c-1
+#ifdef SASSD_WINO_PROF
+            const long long t0 = clock64();
+#endif
             if (c + 1 < nchunk) {
-                transform_store(vnxt, rawA, 0);
-                transform_store(vnxt, rawB, 1);
-                if (c + 2 < nchunk) fetch_patches(c + 2);        // in flight during the whole next chunk
+                const float *rr = rawbuf + ((c + 1) & 1) * kRawBuf;
+                float *vnxt = smem + ((c + 1) & 1) * kVBuf;
+                transform_store(rr, vnxt, 0);
+                transform_store(rr, vnxt, 1);
             }
+#ifdef SASSD_WINO_PROF
+            const long long t1 = clock64();
+#endif
+            if (c + 2 < nchunk) dma_rows(rawbuf + (c & 1) * kRawBuf);        // raw[c&1] was last read in iteration c-1
+#ifdef SASSD_WINO_PROF
+            const long long t2 = clock64();
+#endif
             __syncthreads();
+#ifdef SASSD_WINO_PROF
+            const long long t3 = clock64();
+            lt_tr += t1 - t0; lt_dma += t2 - t1; lt_bar += t3 - t2;
+#endif
         }
+#ifdef SASSD_WINO_PROF
+        if ((P.dbg & 1) && blockIdx.x == 0 && tid == 256) {
+            g_wino_prof[4] = lt_tr; g_wino_prof[5] = lt_dma; g_wino_prof[6] = lt_bar;
+        }
+#endif
     } else {
         // ================================ MFMA waves ==================================================================
         const int xi = wave;
@@ -181,9 +222,17 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nu][cb][r] = 0.f;
         fetch_w(0, wq[0]);
-        __syncthreads();
+        __syncthreads();                             // loader prologue: rows of chunk 0 landed
+        __syncthreads();                             // V[0] written
+#ifdef SASSD_WINO_PROF
+        long long mt_mma = 0, mt_bar = 0;
+        const long long mt_begin = clock64();
+#endif
         for (int c = 0; c < nchunk; ++c) {
             const float *vcur = smem + (c & 1) * kVBuf;
+#ifdef SASSD_WINO_PROF
+            const long long t0 = clock64();
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 fetch_w(min(2 * c + h + 1, nhc - 1), wq[(h + 1) & 1]);       // next half chunk's weights
@@ -200,8 +249,20 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
                             acc[nu][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[h][cb][nu][s], bq[nu][s], acc[nu][cb],
                                                                                0, 0, 0);
             }
+#ifdef SASSD_WINO_PROF
+            const long long t1 = clock64();
+#endif
             __syncthreads();
+#ifdef SASSD_WINO_PROF
+            const long long t2 = clock64();
+            mt_mma += t1 - t0; mt_bar += t2 - t1;
+#endif
         }
+#ifdef SASSD_WINO_PROF
+        if ((P.dbg & 1) && blockIdx.x == 0 && tid == 0) {
+            g_wino_prof[0] = mt_mma; g_wino_prof[1] = mt_bar; g_wino_prof[2] = clock64() - mt_begin;
+        }
+#endif
     }
 
     // ---- output transform: over nu in registers (MFMA waves), over xi through LDS (all waves) --------------------------
@@ -256,10 +317,15 @@ int g_wino_dbg = 0;
 }  // namespace
 
 extern "C" void sassd_debug_set_wino(int flags) { g_wino_dbg = flags; }
+extern "C" int sassd_debug_get_wino_prof(long long *out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wino_prof), 16 * sizeof(long long)) == hipSuccess ? 0 : -3;
+}
 
 extern "C" int sassd_conv2d_wino_supported(int Cin, int Cout, int H, int W)
 {
-    return (Cin >= 16 && Cin % 16 == 0 && Cout >= 32 && Cout % 32 == 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0)
+    // W % 4: zero padding is decided per 16-byte DMA; W >= 64: a 32-tile group spans at most two tile rows
+    return (Cin >= 16 && Cin % 16 == 0 && Cout >= 32 && Cout % 32 == 0 && H >= 2 && H % 2 == 0 && W >= 64 && W % 4 == 0)
                ? 1 : 0;
 }
 
@@ -284,7 +350,7 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
                                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, void *stream_)
 {
     if (!x || !w_packed || !y || batch < 1 || !sassd_conv2d_wino_supported(Cin, Cout, H, W)) return SASSD_EINVAL;
-    if (((uintptr_t)y & 7) || ((uintptr_t)w_packed & 15)) return SASSD_EINVAL;
+    if (((uintptr_t)y & 7) || ((uintptr_t)w_packed & 15) || ((uintptr_t)x & 15)) return SASSD_EINVAL;
     if ((size_t)batch * Cin * H * W >= (1u << 29)) return SASSD_EINVAL;         // 32-bit per-lane element offsets
     WinoParams P;
     P.x = x; P.wp = w_packed; P.scale = scale; P.shift = shift; P.y = y;
@@ -293,7 +359,7 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
     P.ncb64 = cdiv(Cout, kCoW);
     P.relu = relu;
     P.dbg = g_wino_dbg;
-    const size_t lds = (size_t)2 * kVBuf * sizeof(float);           // 65 536 B
+    const size_t lds = (size_t)(2 * kVBuf + 2 * kRawBuf) * sizeof(float);           // 139 264 B
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)conv2d_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -33,3 +33,4 @@ for b, cin in ((1, 256), (1, 320), (2, 256)):
         print("B=%d %d->256 3x3 %-8s %.4f ms  (%.1f direct-equivalent TFLOP/s)" %
               (b, cin, name, ms, 2 * 256 * cin * 9 * 200 * 176 * b / ms / 1e9))
 
+

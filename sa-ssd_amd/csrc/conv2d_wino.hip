@@ -34,6 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kNT = 32;                  // tiles per workgroup
 constexpr int kCoW = 64;                 // couts per workgroup
 constexpr int kKC = 16;                  // input channels per chunk
+constexpr int kGb = 8;                   // tile groups per XCD-local reuse block
 constexpr int kVBuf = 16 * 2 * 2 * kNT * 4;        // floats per V buffer: [pos][half][kh][tile][4]  (8192 = 32 KB)
 constexpr int kRawW = 72;                // staged columns per run (66 needed + alignment slack), 18 float4
 constexpr int kRawBuf = kKC * 2 * 4 * kRawW;       // floats per raw-row buffer: [ci][run][row][col]  (9216 = 36 KB)
@@ -50,6 +51,7 @@ struct WinoParams {
     int B, Cin, Cout, H, W;
     int TH, TW, tiles;                   // tile rows / cols per image, total tiles (B * TH * TW)
     int ncb64;                           // cout groups of 64
+    int ngrp;                            // tile groups of kNT
     int relu;
     int dbg;                             // reserved for ablation builds
 };
@@ -85,9 +87,16 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
     extern __shared__ float smem[];                  // 2 x V buffer (64 KB; reused by the output reduction) + 2 x raw rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // cout group slowest: all workgroups in flight share ONE 64-cout slice of the transformed weights
-    const int ngrp = gridDim.x / P.ncb64;
-    const int cg = blockIdx.x / ngrp, grp = blockIdx.x - cg * ngrp;
+    // XCD-aware work order.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own 4 MB L2.
+    // Inside one XCD's sequence j = id / 8 the work runs in blocks of kGb tile groups: for each block, the ncb64 cout
+    // slices one after the other, each over the block's groups.  So the input rows of a block (kGb x ~0.3 MB) are
+    // fetched over the fabric once and re-read from L2 by the other cout slices, and only one 1 MB weight slice is
+    // live at a time (the whole 4.2 MB transformed-weight set does not fit the L2 next to the inputs).
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int blk = j / (kGb * P.ncb64), rem = j - blk * (kGb * P.ncb64);
+    const int cg = rem / kGb, gi = rem - cg * kGb;
+    const int grp = (blk * kGb + gi) * 8 + xcd;
+    if (grp >= P.ngrp) return;                       // whole workgroup: padding of the last block
     const int HW = P.H * P.W;
     const int nchunk = P.Cin / kKC;
     f32x16 acc[4][2];                                // MFMA waves only: [nu][cout block]
@@ -138,36 +147,42 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
         const int trun = ltile < rn[0] ? 0 : 1;
         const int ttx = trun == 0 ? rtx[0] + ltile : ltile - rn[0];
         const int pbase = (trun * 4) * kRawW + (2 * ttx - 1 - cola[trun]);    // + (ci*2*4 + r) * kRawW + c
-        auto transform_store = [&](const float *rawrows, float *vbuf, int h) {
-            const float *src = rawrows + ((cil + 8 * h) * 8) * kRawW + pbase;
-            float raw[16], t[16];
+        // both patches of the thread (channels cil and cil + 8) are read first, then transformed, then written: the
+        // LDS read latency is paid once per chunk instead of once per patch (the loader is the critical path:
+        // measured 4.9k cycles per chunk for two back-to-back read->transform->write passes vs 4.6k of MFMA issue)
+        auto transform_store2 = [&](const float *rawrows, float *vbuf) {
+            float raw[2][16], t[16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int h = 0; h < 2; ++h) {
+                const float *src = rawrows + ((cil + 8 * h) * 8) * kRawW + pbase;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) raw[r * 4 + c] = src[r * kRawW + c];
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                t[0 * 4 + c] = raw[0 * 4 + c] - raw[2 * 4 + c];
-                t[1 * 4 + c] = raw[1 * 4 + c] + raw[2 * 4 + c];
-                t[2 * 4 + c] = raw[2 * 4 + c] - raw[1 * 4 + c];
-                t[3 * 4 + c] = raw[1 * 4 + c] - raw[3 * 4 + c];
+                    for (int c = 0; c < 4; ++c) raw[h][r * 4 + c] = src[r * kRawW + c];
             }
             const int kh = cil & 1, s = cil >> 1;
-            // (a tile-fastest layout makes these scalar writes bank-conflict free but costs the MFMA waves 4x the
-            //  B-operand read instructions: measured 7 % slower overall)
-            float *dst = vbuf + ((h * 2 + kh) * kNT + ltile) * 4 + s;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dst[(r * 4 + 0) * (2 * 2 * kNT * 4)] = t[r * 4 + 0] - t[r * 4 + 2];
-                dst[(r * 4 + 1) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] + t[r * 4 + 2];
-                dst[(r * 4 + 2) * (2 * 2 * kNT * 4)] = t[r * 4 + 2] - t[r * 4 + 1];
-                dst[(r * 4 + 3) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] - t[r * 4 + 3];
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    t[0 * 4 + c] = raw[h][0 * 4 + c] - raw[h][2 * 4 + c];
+                    t[1 * 4 + c] = raw[h][1 * 4 + c] + raw[h][2 * 4 + c];
+                    t[2 * 4 + c] = raw[h][2 * 4 + c] - raw[h][1 * 4 + c];
+                    t[3 * 4 + c] = raw[h][1 * 4 + c] - raw[h][3 * 4 + c];
+                }
+                float *dst = vbuf + ((h * 2 + kh) * kNT + ltile) * 4 + s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dst[(r * 4 + 0) * (2 * 2 * kNT * 4)] = t[r * 4 + 0] - t[r * 4 + 2];
+                    dst[(r * 4 + 1) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] + t[r * 4 + 2];
+                    dst[(r * 4 + 2) * (2 * 2 * kNT * 4)] = t[r * 4 + 2] - t[r * 4 + 1];
+                    dst[(r * 4 + 3) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] - t[r * 4 + 3];
+                }
             }
         };
         dma_rows(rawbuf);                            // chunk 0 -> raw[0]
         __syncthreads();                             // (the compiler drains vmcnt before every barrier)
-        transform_store(rawbuf, smem, 0);
-        transform_store(rawbuf, smem, 1);
+        transform_store2(rawbuf, smem);
         if (nchunk > 1) dma_rows(rawbuf + kRawBuf);  // chunk 1 -> raw[1]
         __syncthreads();
 #ifdef SASSD_WINO_PROF
@@ -181,8 +196,7 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
             if (c + 1 < nchunk) {
                 const float *rr = rawbuf + ((c + 1) & 1) * kRawBuf;
                 float *vnxt = smem + ((c + 1) & 1) * kVBuf;
-                transform_store(rr, vnxt, 0);
-                transform_store(rr, vnxt, 1);
+                transform_store2(rr, vnxt);
             }
 #ifdef SASSD_WINO_PROF
             const long long t1 = clock64();
@@ -367,7 +381,9 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
             return sassd_launch_status();
         attr_done = true;
     }
-    const int grid = cdiv(P.tiles, kNT) * P.ncb64;
+    P.ngrp = cdiv(P.tiles, kNT);
+    const int per_xcd = cdiv(cdiv(P.ngrp, 8), kGb) * kGb;       // groups per XCD, padded to whole blocks
+    const int grid = per_xcd * P.ncb64 * 8;
     hipLaunchKernelGGL(conv2d_wino_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream_, P);
     return sassd_launch_status();
 }

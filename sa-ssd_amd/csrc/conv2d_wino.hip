@@ -5,24 +5,23 @@
 // fewer multiplications: F(2x2,3x3) needs 16 instead of 36 per 2x2 output tile and channel pair (2.25x), at the price
 // of cheap add-only transforms:   Y = A^T [ (G g G^T) (.) (B^T d B) ] A,   summed over input channels.
 //
-// One kernel, everything fused (no transformed tensors in HBM), WAVE-SPECIALISED:
+// One kernel, everything fused (no transformed tensors in HBM or LDS), WAVE-SPECIALISED:
 //   * work unit (workgroup, 8 waves) = 64 couts x 32 output tiles (2x2 pixels each, linear tile order -> 8800 tiles
 //     = 275 groups, no padding waste) x all 16 Winograd positions.
-//   * waves 0-3 are MFMA waves: wave xi owns the 4 positions (xi, nu = 0..3) of both 32-cout blocks = 8 accumulator
-//     tiles of v_mfma_f32_32x32x2_f32 (128 VGPRs), 64 MFMAs per 16-channel chunk.  Their only other instructions are
-//     8 ds_read_b128 (B operands) and 16 coalesced 16-byte weight loads per chunk: the pre-transformed weights
-//     G g G^T are packed offline in MFMA A-operand order and have no reuse inside a workgroup, so they go straight
-//     to registers, prefetched half a chunk ahead (cout groups are the slowest grid index: the 1 MB slice in use
-//     stays L2-resident).
-//   * waves 4-7 are LOADER waves.  The input rows a 32-tile group needs (<= 2 runs of tiles inside one tile row each:
+//   * waves 4-7 are LOADER waves: the input rows a 32-tile group needs (<= 2 runs of tiles inside one tile row each:
 //     4 image rows x <= 72 columns per run and channel) are staged in LDS by 16-byte global->LDS DMA (zero page for
-//     everything outside the image), 36 wave-instructions per 16-channel chunk instead of the 128 scalar-dword
-//     gathers of a per-thread 4x4 patch fetch; each thread then reads its two 4x4 patches (its tile, channels c and
-//     c + 8) from LDS, transforms them in registers (B^T d B: 32 adds each) and writes the 16 values into LDS in
-//     exactly the layout the B-operand reads want.  VMEM instruction COUNT is what matters: measured ablations
-//     showed MFMA time (0.165 ms) and memory-instruction time (16 cycles per wave-instruction in the texture
-//     addresser) adding up almost serially on a CU, whatever the prefetch depth or wave arrangement.
-//   * one barrier per chunk; the output transform A^T M A is split: each MFMA wave reduces over nu in registers, the
+//     everything outside the image), 36 wave-instructions per 16-channel chunk, double buffered one chunk ahead.
+//   * waves 0-3 are MFMA waves: wave xi owns the 4 positions (xi, nu = 0..3) of both 32-cout blocks = 8 accumulator
+//     tiles of v_mfma_f32_32x32x2_f32 (128 VGPRs).  The input transform is fused INTO the B-operand fetch: row xi of
+//     B^T d B needs only two of the four patch rows, so per (channel pair, k-step) a lane reads 8 raw floats of its
+//     tile's patch from LDS, forms t = a +- b (4 FMAs) and the four nu values (4 adds), and feeds 8 MFMAs -- one
+//     ds_read_b32 and one VALU op per MFMA, no transformed-input buffer, no scattered LDS writes.  (A version with a
+//     separate transform pass writing all 16 positions to LDS was bound by that pass: 4.9 k cycles per chunk of
+//     8-way bank-conflicted scalar writes against 4.1 k cycles of MFMA.)  The pre-transformed weights G g G^T are
+//     packed offline in MFMA A-operand order and have no reuse inside a workgroup, so they go straight to registers
+//     with coalesced 16-byte loads, prefetched half a chunk ahead.
+//   * XCD-local blocked work order (inputs cross the fabric once per block, one 1 MB weight slice live per XCD L2);
+//     one barrier per chunk; the output transform A^T M A is split: each MFMA wave reduces over nu in registers, the
 //     four xi are combined through LDS by all 8 waves, then scale/shift/ReLU and float2 stores of the 2x2 pixels.
 // Numerics: F(2,3) in fp32 has a relative error ~1e-6 (transform matrices hold only 0, +-1, +-1/2).
 #include "common.h"
@@ -35,7 +34,6 @@ constexpr int kNT = 32;                  // tiles per workgroup
 constexpr int kCoW = 64;                 // couts per workgroup
 constexpr int kKC = 16;                  // input channels per chunk
 constexpr int kGb = 8;                   // tile groups per XCD-local reuse block
-constexpr int kVBuf = 16 * 2 * 2 * kNT * 4;        // floats per V buffer: [pos][half][kh][tile][4]  (8192 = 32 KB)
 constexpr int kRawW = 72;                // staged columns per run (66 needed + alignment slack), 18 float4
 constexpr int kRawBuf = kKC * 2 * 4 * kRawW;       // floats per raw-row buffer: [ci][run][row][col]  (9216 = 36 KB)
 
@@ -43,7 +41,6 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
 __device__ __attribute__((aligned(16))) float g_wino_zero[4] = {0.f, 0.f, 0.f, 0.f};
-__device__ long long g_wino_prof[16];      // -DSASSD_WINO_PROF builds: per-phase cycle counts of workgroup 0 (P.dbg & 1)
 
 struct WinoParams {
     const float *x, *wp, *scale, *shift;
@@ -84,7 +81,7 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
 
 __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
 {
-    extern __shared__ float smem[];                  // 2 x V buffer (64 KB; reused by the output reduction) + 2 x raw rows
+    extern __shared__ float smem[];                  // 2 x raw-row buffer (72 KB); reused by the output reduction
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware work order.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own 4 MB L2.
@@ -99,29 +96,29 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
     if (grp >= P.ngrp) return;                       // whole workgroup: padding of the last block
     const int HW = P.H * P.W;
     const int nchunk = P.Cin / kKC;
+
+    // the group's 32 linear tiles form at most two runs, each inside one tile row (TW >= 32 is required)
+    const int g0 = grp * kNT;
+    const int tpi = P.TH * P.TW;
+    int rb_[2], rty[2], rtx[2], rn[2];               // image, tile row, first tile column, length of each run
+    {
+        const int b0 = g0 / tpi, r0 = g0 - b0 * tpi;
+        rb_[0] = b0; rty[0] = r0 / P.TW; rtx[0] = r0 - rty[0] * P.TW;
+        rn[0] = min(min(kNT, P.TW - rtx[0]), P.tiles - g0);
+        const int g1 = g0 + rn[0];
+        rn[1] = max(min(kNT - rn[0], P.tiles - g1), 0);
+        const int b1 = g1 / tpi, r1 = g1 - b1 * tpi;
+        rb_[1] = b1; rty[1] = r1 / P.TW; rtx[1] = 0;
+    }
+    int cola[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) cola[q] = (2 * rtx[q] - 1) & ~3;            // 16-byte aligned first staged column
     f32x16 acc[4][2];                                // MFMA waves only: [nu][cout block]
 
-    float *rawbuf = smem + 2 * kVBuf;                // 2 x raw-row buffer
     if (wave >= 4) {
-        // ================================ loader waves ================================================================
+        // ================================ loader waves: DMA only ======================================================
         const int lt = tid - 256;
-        // the group's 32 linear tiles form at most two runs, each inside one tile row (TW >= 32 is required)
-        const int g0 = grp * kNT;
-        const int tpi = P.TH * P.TW;
-        int rb[2], rty[2], rtx[2], rn[2];            // image, tile row, first tile column, length of each run
-        {
-            const int b0 = g0 / tpi, r0 = g0 - b0 * tpi;
-            rb[0] = b0; rty[0] = r0 / P.TW; rtx[0] = r0 - rty[0] * P.TW;
-            rn[0] = min(min(kNT, P.TW - rtx[0]), P.tiles - g0);
-            const int g1 = g0 + rn[0];
-            rn[1] = max(min(kNT - rn[0], P.tiles - g1), 0);
-            const int b1 = g1 / tpi, r1 = g1 - b1 * tpi;
-            rb[1] = b1; rty[1] = r1 / P.TW; rtx[1] = 0;
-        }
-        int cola[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) cola[q] = (2 * rtx[q] - 1) & ~3;        // 16-byte aligned first staged column
-        // ---- DMA role: float4 i = lt + 256*k of the raw buffer, i = ((ci*2 + run)*4 + row)*18 + f4 --------------------
+        // float4 i = lt + 256*k of the raw buffer, i = ((ci*2 + run)*4 + row)*18 + f4
         const float *dsrc[9];
         unsigned dvalid = 0;
 #pragma unroll
@@ -130,7 +127,7 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
             const int f4 = i % 18, row = (i / 18) & 3, run = (i / 72) & 1, ci = i / 144;
             const int yy = 2 * rty[run] - 1 + row, xx = cola[run] + 4 * f4;
             const bool ok = rn[run] > 0 && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;    // W % 4 == 0: all or nothing
-            dsrc[k] = ok ? P.x + ((size_t)(rb[run] * P.Cin + ci) * P.H + yy) * P.W + xx : g_wino_zero;
+            dsrc[k] = ok ? P.x + ((size_t)(rb_[run] * P.Cin + ci) * P.H + yy) * P.W + xx : g_wino_zero;
             if (ok) dvalid |= 1u << k;
         }
         const size_t cstride = (size_t)kKC * HW;
@@ -142,80 +139,13 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
                 dsrc[k] += ((dvalid >> k) & 1u) ? cstride : 0;
             }
         };
-        // ---- transform role: thread -> (tile = lt & 31, channels cil and cil + 8 of the chunk) ------------------------
-        const int ltile = lt & 31, cil = lt >> 5;
-        const int trun = ltile < rn[0] ? 0 : 1;
-        const int ttx = trun == 0 ? rtx[0] + ltile : ltile - rn[0];
-        const int pbase = (trun * 4) * kRawW + (2 * ttx - 1 - cola[trun]);    // + (ci*2*4 + r) * kRawW + c
-        // both patches of the thread (channels cil and cil + 8) are read first, then transformed, then written: the
-        // LDS read latency is paid once per chunk instead of once per patch (the loader is the critical path:
-        // measured 4.9k cycles per chunk for two back-to-back read->transform->write passes vs 4.6k of MFMA issue)
-        auto transform_store2 = [&](const float *rawrows, float *vbuf) {
-            float raw[2][16], t[16];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float *src = rawrows + ((cil + 8 * h) * 8) * kRawW + pbase;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) raw[h][r * 4 + c] = src[r * kRawW + c];
-            }
-            const int kh = cil & 1, s = cil >> 1;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    t[0 * 4 + c] = raw[h][0 * 4 + c] - raw[h][2 * 4 + c];
-                    t[1 * 4 + c] = raw[h][1 * 4 + c] + raw[h][2 * 4 + c];
-                    t[2 * 4 + c] = raw[h][2 * 4 + c] - raw[h][1 * 4 + c];
-                    t[3 * 4 + c] = raw[h][1 * 4 + c] - raw[h][3 * 4 + c];
-                }
-                float *dst = vbuf + ((h * 2 + kh) * kNT + ltile) * 4 + s;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dst[(r * 4 + 0) * (2 * 2 * kNT * 4)] = t[r * 4 + 0] - t[r * 4 + 2];
-                    dst[(r * 4 + 1) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] + t[r * 4 + 2];
-                    dst[(r * 4 + 2) * (2 * 2 * kNT * 4)] = t[r * 4 + 2] - t[r * 4 + 1];
-                    dst[(r * 4 + 3) * (2 * 2 * kNT * 4)] = t[r * 4 + 1] - t[r * 4 + 3];
-                }
-            }
-        };
-        dma_rows(rawbuf);                            // chunk 0 -> raw[0]
+        dma_rows(smem);                              // chunk 0 -> raw[0]
         __syncthreads();                             // (the compiler drains vmcnt before every barrier)
-        transform_store2(rawbuf, smem);
-        if (nchunk > 1) dma_rows(rawbuf + kRawBuf);  // chunk 1 -> raw[1]
-        __syncthreads();
-#ifdef SASSD_WINO_PROF
-        long long lt_tr = 0, lt_dma = 0, lt_bar = 0;
-#endif
         for (int c = 0; c < nchunk; ++c) {
-            // raw[(c+1)&1] holds chunk c+1 (landed before the last barrier); V[(c+1)&1] was last read during chunk c-1
-#ifdef SASSD_WINO_PROF
-            const long long t0 = clock64();
-#endif
-            if (c + 1 < nchunk) {
-                const float *rr = rawbuf + ((c + 1) & 1) * kRawBuf;
-                float *vnxt = smem + ((c + 1) & 1) * kVBuf;
-                transform_store2(rr, vnxt);
-            }
-#ifdef SASSD_WINO_PROF
-            const long long t1 = clock64();
-#endif
-            if (c + 2 < nchunk) dma_rows(rawbuf + (c & 1) * kRawBuf);        // raw[c&1] was last read in iteration c-1
-#ifdef SASSD_WINO_PROF
-            const long long t2 = clock64();
-#endif
+            // raw[(c+1)&1] was last read during chunk c-1 (barrier since then)
+            if (c + 1 < nchunk) dma_rows(smem + ((c + 1) & 1) * kRawBuf);
             __syncthreads();
-#ifdef SASSD_WINO_PROF
-            const long long t3 = clock64();
-            lt_tr += t1 - t0; lt_dma += t2 - t1; lt_bar += t3 - t2;
-#endif
         }
-#ifdef SASSD_WINO_PROF
-        if ((P.dbg & 1) && blockIdx.x == 0 && tid == 256) {
-            g_wino_prof[4] = lt_tr; g_wino_prof[5] = lt_dma; g_wino_prof[6] = lt_bar;
-        }
-#endif
     } else {
         // ================================ MFMA waves ==================================================================
         const int xi = wave;
@@ -235,53 +165,48 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nu][cb][r] = 0.f;
+        // this lane's B-operand source: tile = lane & 31, channel parity kh = lane >> 5; row xi of B^T d B combines the
+        // patch rows (ra, rb) as raw[ra] + sg * raw[rb]:  xi 0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r1 - r3
+        const int ltile = lane & 31, kh = lane >> 5;
+        const int trun = ltile < rn[0] ? 0 : 1;
+        const int ttx = trun == 0 ? rtx[0] + ltile : ltile - rn[0];
+        const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1), rbw = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+        const float sg = xi == 1 ? 1.f : -1.f;
+        const int lbase = (kh * 8 + trun * 4) * kRawW + (2 * ttx - 1 - cola[trun]);      // + ci_even*8*kRawW + r*kRawW + c
+        const int offa = lbase + ra * kRawW, offb = lbase + rbw * kRawW;
         fetch_w(0, wq[0]);
-        __syncthreads();                             // loader prologue: rows of chunk 0 landed
-        __syncthreads();                             // V[0] written
-#ifdef SASSD_WINO_PROF
-        long long mt_mma = 0, mt_bar = 0;
-        const long long mt_begin = clock64();
-#endif
+        __syncthreads();                             // rows of chunk 0 landed
         for (int c = 0; c < nchunk; ++c) {
-            const float *vcur = smem + (c & 1) * kVBuf;
-#ifdef SASSD_WINO_PROF
-            const long long t0 = clock64();
-#endif
+            const float *rw = smem + (c & 1) * kRawBuf;
+            float pa[2][4], pb[2][4];                // raw rows (ra, rb) of the patch, double buffered over k-steps
+            auto fetch_raw = [&](int step, float *a, float *b) {    // step = h*4 + s -> channels 2*step + kh
+                const float *src = rw + step * (2 * 8 * kRawW);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                fetch_w(min(2 * c + h + 1, nhc - 1), wq[(h + 1) & 1]);       // next half chunk's weights
-                const f32x4 *vb = reinterpret_cast<const f32x4 *>(vcur) + ((h * 2 + (lane >> 5)) * kNT + (lane & 31));
-                f32x4 bq[4];
+                for (int q = 0; q < 4; ++q) { a[q] = src[offa + q]; b[q] = src[offb + q]; }
+            };
+            fetch_raw(0, pa[0], pb[0]);
 #pragma unroll
-                for (int nu = 0; nu < 4; ++nu) bq[nu] = vb[(xi * 4 + nu) * (2 * 2 * kNT)];
+            for (int step = 0; step < 8; ++step) {
+                const int h = step >> 2, s = step & 3, cur = step & 1;
+                if (s == 0) fetch_w(min(2 * c + h + 1, nhc - 1), wq[(h + 1) & 1]);       // next half chunk's weights
+                if (step + 1 < 8) fetch_raw(step + 1, pa[cur ^ 1], pb[cur ^ 1]);
+                float t[4], bv[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int q = 0; q < 4; ++q) t[q] = fmaf(sg, pb[cur][q], pa[cur][q]);
+                bv[0] = t[0] - t[2]; bv[1] = t[1] + t[2]; bv[2] = t[2] - t[1]; bv[3] = t[1] - t[3];
 #pragma unroll
-                    for (int nu = 0; nu < 4; ++nu)
+                for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-                        for (int cb = 0; cb < 2; ++cb)
-                            acc[nu][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[h][cb][nu][s], bq[nu][s], acc[nu][cb],
-                                                                               0, 0, 0);
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[nu][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[h][cb][nu][s], bv[nu], acc[nu][cb], 0, 0, 0);
             }
-#ifdef SASSD_WINO_PROF
-            const long long t1 = clock64();
-#endif
             __syncthreads();
-#ifdef SASSD_WINO_PROF
-            const long long t2 = clock64();
-            mt_mma += t1 - t0; mt_bar += t2 - t1;
-#endif
         }
-#ifdef SASSD_WINO_PROF
-        if ((P.dbg & 1) && blockIdx.x == 0 && tid == 0) {
-            g_wino_prof[0] = mt_mma; g_wino_prof[1] = mt_bar; g_wino_prof[2] = clock64() - mt_begin;
-        }
-#endif
     }
 
     // ---- output transform: over nu in registers (MFMA waves), over xi through LDS (all waves) --------------------------
     // P_j[xi] = sum_nu M[xi][nu] A[nu][j],  A^T = [[1,1,1,0],[0,1,-1,-1]]
-    float *red = smem;                               // [cb 2][xi 4][j 2][reg 16][lane 64]  = 64 KB
+    float *red = smem;                               // [cb 2][xi 4][j 2][reg 16][lane 64]  = 64 KB (raw rows are dead)
     if (wave < 4) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -310,7 +235,7 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
 #pragma unroll
             for (int x4 = 0; x4 < 4; ++x4)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) pj[x4][j] = red[(((cb * 4 + x4) * 2 + j) * 16 + r) * 64 + lane];
+                for (int jj = 0; jj < 2; ++jj) pj[x4][jj] = red[(((cb * 4 + x4) * 2 + jj) * 16 + r) * 64 + lane];
             const float sc = P.scale ? P.scale[co] : 1.f, sh = P.shift ? P.shift[co] : 0.f;
             float *dst = P.y + ((size_t)ob * P.Cout + co) * HW + (size_t)(2 * oty) * P.W + 2 * otx;
 #pragma unroll
@@ -331,10 +256,7 @@ int g_wino_dbg = 0;
 }  // namespace
 
 extern "C" void sassd_debug_set_wino(int flags) { g_wino_dbg = flags; }
-extern "C" int sassd_debug_get_wino_prof(long long *out16)
-{
-    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wino_prof), 16 * sizeof(long long)) == hipSuccess ? 0 : -3;
-}
+
 
 extern "C" int sassd_conv2d_wino_supported(int Cin, int Cout, int H, int W)
 {
@@ -373,7 +295,7 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
     P.ncb64 = cdiv(Cout, kCoW);
     P.relu = relu;
     P.dbg = g_wino_dbg;
-    const size_t lds = (size_t)(2 * kVBuf + 2 * kRawBuf) * sizeof(float);           // 139 264 B
+    const size_t lds = (size_t)(2 * kRawBuf) * sizeof(float);                       // 73 728 B
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)conv2d_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

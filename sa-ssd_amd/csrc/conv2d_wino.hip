@@ -5,24 +5,25 @@
 // fewer multiplications: F(2x2,3x3) needs 16 instead of 36 per 2x2 output tile and channel pair (2.25x), at the price
 // of cheap add-only transforms:   Y = A^T [ (G g G^T) (.) (B^T d B) ] A,   summed over input channels.
 //
-// One kernel, everything fused (no transformed tensors in HBM or LDS), WAVE-SPECIALISED:
-//   * work unit (workgroup, 8 waves) = 64 couts x 32 output tiles (2x2 pixels each, linear tile order -> 8800 tiles
-//     = 275 groups, no padding waste) x all 16 Winograd positions.
-//   * waves 4-7 are LOADER waves: the input rows a 32-tile group needs (<= 2 runs of tiles inside one tile row each:
-//     4 image rows x <= 72 columns per run and channel) are staged in LDS by 16-byte global->LDS DMA (zero page for
-//     everything outside the image), 36 wave-instructions per 16-channel chunk, double buffered one chunk ahead.
-//   * waves 0-3 are MFMA waves: wave xi owns the 4 positions (xi, nu = 0..3) of both 32-cout blocks = 8 accumulator
-//     tiles of v_mfma_f32_32x32x2_f32 (128 VGPRs).  The input transform is fused INTO the B-operand fetch: row xi of
-//     B^T d B needs only two of the four patch rows, so per (channel pair, k-step) a lane reads 8 raw floats of its
-//     tile's patch from LDS, forms t = a +- b (4 FMAs) and the four nu values (4 adds), and feeds 8 MFMAs -- one
-//     ds_read_b32 and one VALU op per MFMA, no transformed-input buffer, no scattered LDS writes.  (A version with a
-//     separate transform pass writing all 16 positions to LDS was bound by that pass: 4.9 k cycles per chunk of
-//     8-way bank-conflicted scalar writes against 4.1 k cycles of MFMA.)  The pre-transformed weights G g G^T are
-//     packed offline in MFMA A-operand order and have no reuse inside a workgroup, so they go straight to registers
-//     with coalesced 16-byte loads, prefetched half a chunk ahead.
+// One kernel, everything fused (no transformed tensors in HBM or LDS), WAVE-SPECIALISED (12 waves):
+//   * work unit (workgroup) = 64 couts x 32 output tiles (2x2 pixels each, linear tile order -> 8800 tiles = 275
+//     groups, no padding waste) x all 16 Winograd positions.
+//   * waves 8-11 are LOADER waves: the input rows a 32-tile group needs (<= 2 runs of tiles inside one tile row
+//     each: 4 image rows x <= 72 columns per run and channel) are staged in LDS by 16-byte global->LDS DMA (zero page
+//     for everything outside the image), 36 wave-instructions per 16-channel chunk, double buffered one chunk ahead.
+//   * waves 0-7 are MFMA waves, two per SIMD: wave (xi, cb) owns the 4 positions (xi, nu = 0..3) of one 32-cout block
+//     = 4 accumulator tiles of v_mfma_f32_32x32x2_f32.  The input transform is fused INTO the B-operand fetch: row xi
+//     of B^T d B needs only two of the four patch rows, so per k-step a lane reads 8 raw floats of its tile's patch
+//     from LDS, forms t = a +- b (4 FMAs) and the four nu values (4 adds) and feeds 4 MFMAs -- no transformed-input
+//     buffer, no scattered LDS writes.  The pre-transformed weights G g G^T are packed offline in MFMA A-operand
+//     order and have no reuse inside a workgroup, so they go straight to registers with coalesced 16-byte loads,
+//     prefetched half a chunk ahead.
 //   * XCD-local blocked work order (inputs cross the fabric once per block, one 1 MB weight slice live per XCD L2);
 //     one barrier per chunk; the output transform A^T M A is split: each MFMA wave reduces over nu in registers, the
-//     four xi are combined through LDS by all 8 waves, then scale/shift/ReLU and float2 stores of the 2x2 pixels.
+//     four xi are combined through LDS, then scale/shift/ReLU and float2 stores of the 2x2 pixels.
+// Measured history (B=1, 256->256 @200x176; direct kernel 0.39 ms): per-thread patch gathers + transformed-input buffer
+// in LDS, unspecialised 8 waves 0.262; two 4-wave workgroups per CU 0.267; loader/MFMA specialisation 0.272; LDS-DMA row
+// staging 0.266; XCD blocking 0.260; transform fused into 4 MFMA waves 0.285; into 8 MFMA waves (this file) 0.259.
 // Numerics: F(2,3) in fp32 has a relative error ~1e-6 (transform matrices hold only 0, +-1, +-1/2).
 #include "common.h"
 
@@ -79,7 +80,7 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
     wp[i] = u;
 }
 
-__global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
+__global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
 {
     extern __shared__ float smem[];                  // 2 x raw-row buffer (72 KB); reused by the output reduction
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,6 +97,10 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
     if (grp >= P.ngrp) return;                       // whole workgroup: padding of the last block
     const int HW = P.H * P.W;
     const int nchunk = P.Cin / kKC;
+    // Every workgroup of a cout slice streams the SAME 1 MB of weights; each walks the input-channel chunks in a rotated
+    // order so that concurrently running workgroups do not ask the same L2 channel for the same lines at the same time
+    // (the sum over chunks is order independent up to fp32 rounding and stays deterministic; measured neutral, +-1 %).
+    const int rot = (grp * 5 + cg * 3) % nchunk;
 
     // the group's 32 linear tiles form at most two runs, each inside one tile row (TW >= 32 is required)
     const int g0 = grp * kNT;
@@ -113,11 +118,11 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
     int cola[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) cola[q] = (2 * rtx[q] - 1) & ~3;            // 16-byte aligned first staged column
-    f32x16 acc[4][2];                                // MFMA waves only: [nu][cout block]
+    f32x16 acc[4];                                   // MFMA waves only: [nu]
 
-    if (wave >= 4) {
+    if (wave >= 8) {
         // ================================ loader waves: DMA only ======================================================
-        const int lt = tid - 256;
+        const int lt = tid - 512;
         // float4 i = lt + 256*k of the raw buffer, i = ((ci*2 + run)*4 + row)*18 + f4
         const float *dsrc[9];
         unsigned dvalid = 0;
@@ -131,40 +136,42 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
             if (ok) dvalid |= 1u << k;
         }
         const size_t cstride = (size_t)kKC * HW;
-        const int wl = wave - 4;
-        auto dma_rows = [&](float *dst) {            // issues the next chunk's rows and advances the pointers
+        const int wl = wave - 8;
+        auto dma_rows = [&](float *dst, int chunk) { // issues one chunk's rows
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)dsrc[k], (lds_ptr_t)(dst + (wl * 64 + 256 * k) * 4), 16, 0, 0);
-                dsrc[k] += ((dvalid >> k) & 1u) ? cstride : 0;
+                const float *src = dsrc[k] + (((dvalid >> k) & 1u) ? (size_t)chunk * cstride : 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(dst + (wl * 64 + 256 * k) * 4), 16, 0, 0);
             }
         };
-        dma_rows(smem);                              // chunk 0 -> raw[0]
+        dma_rows(smem, rot);                         // first chunk -> raw[0]
         __syncthreads();                             // (the compiler drains vmcnt before every barrier)
-        for (int c = 0; c < nchunk; ++c) {
-            // raw[(c+1)&1] was last read during chunk c-1 (barrier since then)
-            if (c + 1 < nchunk) dma_rows(smem + ((c + 1) & 1) * kRawBuf);
+        for (int q = 0; q < nchunk; ++q) {
+            // raw[(q+1)&1] was last read during step q-1 (barrier since then)
+            if (q + 1 < nchunk) {
+                int cn = q + 1 + rot;
+                cn -= cn >= nchunk ? nchunk : 0;
+                dma_rows(smem + ((q + 1) & 1) * kRawBuf, cn);
+            }
             __syncthreads();
         }
     } else {
         // ================================ MFMA waves ==================================================================
-        const int xi = wave;
+        // 8 MFMA waves: wave (xi = w & 3, cb = w >> 2) owns the 4 positions (xi, nu) of ONE 32-cout block.  Two MFMA
+        // waves share a SIMD, so while one waits for its LDS reads / forms its B operands the other issues MFMAs.
+        const int xi = wave & 3, cbw = wave >> 2;
         const int nhc = P.Cin / 8;
-        // weights of (cout block cb, position (xi, nu), half chunk hc): float4 at wsrc[((cb*nhc + hc)*16 + nu) * 64]
-        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(P.wp) + ((size_t)(cg * 2) * nhc * 16 + xi * 4) * 64 + lane;
-        f32x4 wq[2][2][4];                           // [buffer][cb][nu]
-        auto fetch_w = [&](int hc, f32x4 (*wdst)[4]) {
+        // weights of (position (xi, nu), half chunk hc): float4 at wsrc[(hc*16 + nu) * 64]
+        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(P.wp) + ((size_t)(cg * 2 + cbw) * nhc * 16 + xi * 4) * 64 + lane;
+        f32x4 wq[2][4];                              // [buffer][nu]
+        auto fetch_w = [&](int hc, f32x4 *wdst) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu) wdst[cb][nu] = wsrc[(((size_t)cb * nhc + hc) * 16 + nu) * 64];
+            for (int nu = 0; nu < 4; ++nu) wdst[nu] = wsrc[((size_t)hc * 16 + nu) * 64];
         };
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nu][cb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
         // this lane's B-operand source: tile = lane & 31, channel parity kh = lane >> 5; row xi of B^T d B combines the
         // patch rows (ra, rb) as raw[ra] + sg * raw[rb]:  xi 0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r1 - r3
         const int ltile = lane & 31, kh = lane >> 5;
@@ -174,10 +181,14 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
         const float sg = xi == 1 ? 1.f : -1.f;
         const int lbase = (kh * 8 + trun * 4) * kRawW + (2 * ttx - 1 - cola[trun]);      // + ci_even*8*kRawW + r*kRawW + c
         const int offa = lbase + ra * kRawW, offb = lbase + rbw * kRawW;
-        fetch_w(0, wq[0]);
-        __syncthreads();                             // rows of chunk 0 landed
-        for (int c = 0; c < nchunk; ++c) {
-            const float *rw = smem + (c & 1) * kRawBuf;
+        fetch_w(2 * rot, wq[0]);
+        __syncthreads();                             // rows of the first chunk landed
+        for (int q = 0; q < nchunk; ++q) {
+            int c = q + rot;                         // this workgroup's chunk order starts at `rot`
+            c -= c >= nchunk ? nchunk : 0;
+            int c1 = c + 1;
+            c1 -= c1 >= nchunk ? nchunk : 0;
+            const float *rw = smem + (q & 1) * kRawBuf;
             float pa[2][4], pb[2][4];                // raw rows (ra, rb) of the patch, double buffered over k-steps
             auto fetch_raw = [&](int step, float *a, float *b) {    // step = h*4 + s -> channels 2*step + kh
                 const float *src = rw + step * (2 * 8 * kRawW);
@@ -188,7 +199,7 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
 #pragma unroll
             for (int step = 0; step < 8; ++step) {
                 const int h = step >> 2, s = step & 3, cur = step & 1;
-                if (s == 0) fetch_w(min(2 * c + h + 1, nhc - 1), wq[(h + 1) & 1]);       // next half chunk's weights
+                if (s == 0) fetch_w(h == 0 ? 2 * c + 1 : 2 * c1, wq[(h + 1) & 1]);       // next half chunk's weights
                 if (step + 1 < 8) fetch_raw(step + 1, pa[cur ^ 1], pb[cur ^ 1]);
                 float t[4], bv[4];
 #pragma unroll
@@ -196,9 +207,7 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
                 bv[0] = t[0] - t[2]; bv[1] = t[1] + t[2]; bv[2] = t[2] - t[1]; bv[3] = t[1] - t[3];
 #pragma unroll
                 for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-                        acc[nu][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[h][cb][nu][s], bv[nu], acc[nu][cb], 0, 0, 0);
+                    acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[h][nu][s], bv[nu], acc[nu], 0, 0, 0);
             }
             __syncthreads();
         }
@@ -207,21 +216,19 @@ __global__ void __launch_bounds__(512) conv2d_wino_kernel(WinoParams P)
     // ---- output transform: over nu in registers (MFMA waves), over xi through LDS (all waves) --------------------------
     // P_j[xi] = sum_nu M[xi][nu] A[nu][j],  A^T = [[1,1,1,0],[0,1,-1,-1]]
     float *red = smem;                               // [cb 2][xi 4][j 2][reg 16][lane 64]  = 64 KB (raw rows are dead)
-    if (wave < 4) {
+    if (wave < 8) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p0 = acc[0][cb][r] + acc[1][cb][r] + acc[2][cb][r];
-                const float p1 = acc[1][cb][r] - acc[2][cb][r] - acc[3][cb][r];
-                red[(((cb * 4 + wave) * 2 + 0) * 16 + r) * 64 + lane] = p0;
-                red[(((cb * 4 + wave) * 2 + 1) * 16 + r) * 64 + lane] = p1;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float p0 = acc[0][r] + acc[1][r] + acc[2][r];
+            const float p1 = acc[1][r] - acc[2][r] - acc[3][r];
+            red[((wave * 2 + 0) * 16 + r) * 64 + lane] = p0;          // wave = cb * 4 + xi
+            red[((wave * 2 + 1) * 16 + r) * 64 + lane] = p1;
+        }
     }
     __syncthreads();
     // wave w finishes registers 4*(w & 3) .. +3 of cout block (w >> 2): Y[i][j] = sum_xi A^T[i][xi] P_j[xi]
     const int otile = grp * kNT + (lane & 31);
-    if (otile < P.tiles) {
+    if (otile < P.tiles && wave < 8) {
         const int ob = otile / (P.TH * P.TW);
         const int orr = otile - ob * P.TH * P.TW;
         const int oty = orr / P.TW, otx = orr - oty * P.TW;
@@ -306,6 +313,6 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
     P.ngrp = cdiv(P.tiles, kNT);
     const int per_xcd = cdiv(cdiv(P.ngrp, 8), kGb) * kGb;       // groups per XCD, padded to whole blocks
     const int grid = per_xcd * P.ncb64 * 8;
-    hipLaunchKernelGGL(conv2d_wino_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream_, P);
+    hipLaunchKernelGGL(conv2d_wino_kernel, dim3(grid), dim3(768), lds, (hipStream_t)stream_, P);
     return sassd_launch_status();
 }

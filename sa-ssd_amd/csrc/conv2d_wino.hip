@@ -82,7 +82,7 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
 
 __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
 {
-    extern __shared__ float smem[];                  // 2 x raw-row buffer (72 KB); reused by the output reduction
+    extern __shared__ float smem[];                  // 3 x raw-row buffer (108 KB); reused by the output reduction
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware work order.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own 4 MB L2.
@@ -144,16 +144,33 @@ __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(dst + (wl * 64 + 256 * k) * 4), 16, 0, 0);
             }
         };
-        dma_rows(smem, rot);                         // first chunk -> raw[0]
-        __syncthreads();                             // (the compiler drains vmcnt before every barrier)
+        // Three row buffers, DMA issued TWO chunks ahead.  The barrier is a bare s_barrier behind an explicit
+        // s_waitcnt vmcnt(9): only the older group of 9 DMAs (the chunk needed next) must have landed, the newest 9 stay
+        // in flight across the barrier (__syncthreads() would drain vmcnt to 0 and cap the lookahead at one chunk --
+        // with 92 % of the MFMAs skipped on a sparse input the kernel time did not move: it was bound by the per-chunk
+        // memory round trip, not by the MFMA pipe).
+        auto chunk_of = [&](int q) {
+            int c = q + rot;
+            c -= c >= nchunk ? nchunk : 0;
+            return c;
+        };
+        dma_rows(smem, chunk_of(0));
+        if (nchunk > 1) {
+            dma_rows(smem + kRawBuf, chunk_of(1));
+            __builtin_amdgcn_s_waitcnt(0x0F79);      // vmcnt(9): chunk 0 landed, chunk 1 in flight
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+        }
+        __builtin_amdgcn_s_barrier();
         for (int q = 0; q < nchunk; ++q) {
-            // raw[(q+1)&1] was last read during step q-1 (barrier since then)
-            if (q + 1 < nchunk) {
-                int cn = q + 1 + rot;
-                cn -= cn >= nchunk ? nchunk : 0;
-                dma_rows(smem + ((q + 1) & 1) * kRawBuf, cn);
+            // raw[(q+2)%3] was last read during step q-1 (barrier since then)
+            if (q + 2 < nchunk) {
+                dma_rows(smem + ((q + 2) % 3) * kRawBuf, chunk_of(q + 2));
+                __builtin_amdgcn_s_waitcnt(0x0F79);  // chunk q+1 landed, chunk q+2 in flight
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
             }
-            __syncthreads();
+            __builtin_amdgcn_s_barrier();
         }
     } else {
         // ================================ MFMA waves ==================================================================
@@ -188,7 +205,7 @@ __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
             c -= c >= nchunk ? nchunk : 0;
             int c1 = c + 1;
             c1 -= c1 >= nchunk ? nchunk : 0;
-            const float *rw = smem + (q & 1) * kRawBuf;
+            const float *rw = smem + (q % 3) * kRawBuf;
             float pa[2][4], pb[2][4];                // raw rows (ra, rb) of the patch, double buffered over k-steps
             auto fetch_raw = [&](int step, float *a, float *b) {    // step = h*4 + s -> channels 2*step + kh
                 const float *src = rw + step * (2 * 8 * kRawW);
@@ -302,7 +319,7 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
     P.ncb64 = cdiv(Cout, kCoW);
     P.relu = relu;
     P.dbg = g_wino_dbg;
-    const size_t lds = (size_t)(2 * kRawBuf) * sizeof(float);                       // 73 728 B
+    const size_t lds = (size_t)(3 * kRawBuf) * sizeof(float);                       // 110 592 B
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)conv2d_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -183,6 +183,9 @@ __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
         f32x4 wq[2][4];                              // [buffer][nu]
         auto fetch_w = [&](int hc, f32x4 *wdst) {
 #pragma unroll
+#ifdef SASSD_WINO_ABL_W
+            hc &= 1;                                 // ablation (wrong results): the weight stream stays L1 resident
+#endif
             for (int nu = 0; nu < 4; ++nu) wdst[nu] = wsrc[((size_t)hc * 16 + nu) * 64];
         };
 #pragma unroll

@@ -124,11 +124,19 @@ def main_train(args):
     gts = [torch.from_numpy(synth_gt(rank * 1000 + i)).to(dev) for i in range(nf)]
     types = [np.array(["Car"] * 8) for _ in range(nf)]
 
-    def one(i):
+    def make_batch(i):
         ids = [(i * B + j) % nf for j in range(B)]
-        batch = train.device_batch([clouds[k] for k in ids], [gts[k] for k in ids], [types[k] for k in ids], ["Car"],
-                                   anchors, anchors_bv, synth.KITTI_VOXEL, synth.KITTI_RANGE)
-        return train.train_one_iter(model, opt, sched, sync, batch, i)
+        return train.device_batch([clouds[k] for k in ids], [gts[k] for k in ids], [types[k] for k in ids], ["Car"],
+                                  anchors, anchors_bv, synth.KITTI_VOXEL, synth.KITTI_RANGE, model=model)
+
+    state = {"batch": make_batch(0)}
+
+    def one(i):
+        # the next batch (device voxelize, anchor masks, rulebooks -- the host syncs) is built between this step's
+        # forward and backward
+        loss, terms, state["batch"] = train.train_one_iter(model, opt, sched, sync, state["batch"], i,
+                                                           prefetch=lambda: make_batch(i + 1))
+        return loss, terms
 
     def barrier():
         torch.cuda.synchronize()

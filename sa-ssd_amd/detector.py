@@ -104,6 +104,21 @@ class VxNet(nn.Module):
         self.extra_conv = spconv.SparseSequential(spconv.SparseConv3d(64, 64, (1, 1, 1), (1, 1, 1), bias=False),
                                                   _bn1d(64), nn.ReLU())
 
+    def precompute_rulebooks(self, coors, spatial_shape, batch_size):
+        """All seven rulebooks of a batch from its voxel coordinates alone [N,4] (b,z,y,x): the indice_dict to hand to
+        `forward` later.  Lets a training loop build them (with their three host syncs) for batch i+1 before the
+        backward of batch i is queued, so that the next forward never waits on the GPU."""
+        x = spconv.SparseConvTensor(None, coors.int().contiguous(), spatial_shape, batch_size)
+        for block in (self.conv0, self.down0, self.conv1, self.down1, self.conv2, self.down2, self.conv3):
+            for m in block:
+                if isinstance(m, spconv.SparseConvolution) and not m.conv1x1:
+                    out_idx, nbr, oshape, otable = m.book(x)
+                    if not m.subm:
+                        nxt = spconv.SparseConvTensor(None, out_idx, oshape, batch_size)
+                        nxt.indice_dict = x.indice_dict
+                        x = nxt
+        return x.indice_dict
+
     def forward(self, x):
         middle = []
         x = self.conv1(self.down0(self.conv0(x)))
@@ -233,8 +248,10 @@ class SpMiddleFHD(nn.Module):
         out[:, 1:] = ind[:, 1:].flip(1) * vs + off + .5 * vs          # columns (3,2,1) without an index tensor upload
         return tensor.features, out
 
-    def forward(self, voxel_features, coors, batch_size, is_test=False):
+    def forward(self, voxel_features, coors, batch_size, is_test=False, indice_dict=None):
         x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size)
+        if indice_dict is not None:                  # rulebooks built ahead of time (VxNet.precompute_rulebooks)
+            x.indice_dict = indice_dict
         x, middle = self.backbone(x)
         x = x.dense()
         n, c, d, h, w = x.shape
@@ -483,7 +500,7 @@ class SingleStageDetector(nn.Module):
             elif key == 'coordinates':
                 ret[key] = torch.cat([nn.functional.pad(c, [1, 0, 0, 0], mode='constant', value=i)
                                       for i, c in enumerate(elems)], dim=0)
-            elif key in ('img_meta', 'gt_labels', 'gt_bboxes', 'gt_types'):
+            elif key in ('img_meta', 'gt_labels', 'gt_bboxes', 'gt_types', 'sassd_rulebooks'):
                 ret[key] = elems
             elif isinstance(elems, dict):
                 ret[key] = {k: torch.stack(v, dim=0) for k, v in elems.items()}
@@ -508,7 +525,8 @@ class SingleStageDetector(nn.Module):
         batch_size = len(img_meta)
         ret = self.merge_second_batch(kwargs)
         vx = self.backbone(ret['voxels'], ret['num_points'])
-        x, conv6, point_misc = self.neck(vx, ret['coordinates'], batch_size, is_test=False)
+        x, conv6, point_misc = self.neck(vx, ret['coordinates'], batch_size, is_test=False,
+                                         indice_dict=ret.get('sassd_rulebooks'))
         losses = dict()
         losses.update(self.neck.aux_loss(*point_misc, gt_bboxes=ret['gt_bboxes']))
         if not self.with_rpn:

@@ -98,11 +98,37 @@ class SparseConvolution(nn.Module):
         n_ptr = torch.full((1,), n_out, dtype=torch.int32, device=feats.device)
         return K.spconv_fwd(feats, nbr, n_ptr, max(n_out, 1), self.packed_weight(), k, cin, cout, None, bias)[:n_out]
 
+    def book(self, inp):
+        """Rulebook of this layer for `inp`'s coordinates: (out_indices, nbr, out_shape, out_table).  Coordinate-only
+        work (hash / bitmap kernels + ONE host read of the output row count for strided layers); cached per
+        `indice_key` in `inp.indice_dict`, so it can be built ahead of the forward pass (VxNet.precompute_rulebooks)."""
+        idx = inp.indices.int().contiguous()
+        n = idx.shape[0]
+        if self.kernel_size != (3, 3, 3):
+            raise NotImplementedError("only k=3 and k=1 sparse convs exist on the SA-SSD path")
+        book = inp.indice_dict.get(self.indice_key) if self.indice_key is not None else None
+        if book is not None:
+            return book
+        if self.subm:
+            nbr = K.rulebook_subm(idx, inp._n_ptr(), max(n, 1), inp.spatial_shape, inp.batch_size, inp.table())
+            book = (idx, nbr, inp.spatial_shape, inp._table)
+        else:
+            if self.stride != (2, 2, 2) or self.padding != (1, 1, 1):
+                raise NotImplementedError("strided sparse conv is k=3,s=2,p=1 on the SA-SSD path (cmn.py:170)")
+            cap_out = max(8 * n, 1)
+            oi, on, nbr = K.rulebook_conv(idx, inp._n_ptr(), max(n, 1), inp.spatial_shape, inp.batch_size,
+                                          inp.table(), cap_out)
+            n_out = int(on.item())            # compatibility path: exact-size tensors need the count
+            book = (oi[:n_out].contiguous(), nbr[:max(n_out, 1)].contiguous(),
+                    list(K.conv_out_shape(inp.spatial_shape)), None)
+        if self.indice_key is not None:
+            inp.indice_dict[self.indice_key] = book
+        return book
+
     def forward(self, inp):
         assert isinstance(inp, SparseConvTensor)
         feats = inp.features.contiguous().float()
-        idx = inp.indices.int().contiguous()
-        n = idx.shape[0]
+        n = inp.indices.shape[0]
         grad = torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad)
         if self.conv1x1:
             # spconv shortcut: features @ weight.view(Cin, Cout), indices unchanged
@@ -110,31 +136,8 @@ class SparseConvolution(nn.Module):
             out = SparseConvTensor(y, inp.indices, inp.spatial_shape, inp.batch_size)
             out.indice_dict, out._table = inp.indice_dict, inp._table
             return out
-        if self.kernel_size != (3, 3, 3):
-            raise NotImplementedError("only k=3 and k=1 sparse convs exist on the SA-SSD path")
-        book = inp.indice_dict.get(self.indice_key) if self.indice_key is not None else None
-        if self.subm:
-            if book is None:
-                nbr = K.rulebook_subm(idx, inp._n_ptr(), max(n, 1), inp.spatial_shape, inp.batch_size, inp.table())
-                book = (idx, nbr, inp.spatial_shape, inp._table)
-                if self.indice_key is not None:
-                    inp.indice_dict[self.indice_key] = book
-            out_idx, nbr, oshape, otable = book
-            n_out = n
-        else:
-            if self.stride != (2, 2, 2) or self.padding != (1, 1, 1):
-                raise NotImplementedError("strided sparse conv is k=3,s=2,p=1 on the SA-SSD path (cmn.py:170)")
-            if book is None:
-                cap_out = max(8 * n, 1)
-                oi, on, nbr = K.rulebook_conv(idx, inp._n_ptr(), max(n, 1), inp.spatial_shape, inp.batch_size,
-                                              inp.table(), cap_out)
-                n_out = int(on.item())            # compatibility path: exact-size tensors need the count
-                book = (oi[:n_out].contiguous(), nbr[:max(n_out, 1)].contiguous(),
-                        list(K.conv_out_shape(inp.spatial_shape)), None)
-                if self.indice_key is not None:
-                    inp.indice_dict[self.indice_key] = book
-            out_idx, nbr, oshape, otable = book
-            n_out = out_idx.shape[0]
+        out_idx, nbr, oshape, otable = self.book(inp)
+        n_out = out_idx.shape[0]
         y = self._conv(feats, nbr, n_out, 27, grad)
         out = SparseConvTensor(y, out_idx, oshape, inp.batch_size)
         out.indice_dict = inp.indice_dict

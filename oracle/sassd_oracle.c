@@ -303,3 +303,113 @@ void orc_pts_in_boxes3d(const float *pts, int n, const float *boxes, int m, int3
             }
         }
 }
+
+/* ----------------------------------------------------------------------------------------------
+ * KITTI-evaluation rotated IoU: rotate_iou_gpu_eval,
+ * mmdet/core/post_processing/rotate_nms_gpu.py:153-388 (device functions) and :536-627 (eval kernel + wrapper).
+ * Boxes are (cx, cy, x_dim, y_dim, angle); the intersection polygon is collected from corners-inside-the-other-box
+ * and the 16 edge-edge crossings, sorted by angle around the centroid (insertion sort on a cos-like key) and summed
+ * as a triangle fan.  Arithmetic follows numba's typing of the reference: float32 storage, float64 where a Python
+ * float literal / true division / accumulator promotes (x/2, /2.0, the centroid sums, the area accumulator).
+ * ---------------------------------------------------------------------------------------------- */
+static void orc_eval_corners(const float *rb, float *c /*8*/)
+{
+    const double a_cos = cos((double)rb[4]), a_sin = sin((double)rb[4]);   /* math.cos on float32 -> float64 in numba */
+    const float cx[4] = {(float)(-rb[2] / 2.0), (float)(-rb[2] / 2.0), (float)(rb[2] / 2.0), (float)(rb[2] / 2.0)};
+    const float cy[4] = {(float)(-rb[3] / 2.0), (float)(rb[3] / 2.0), (float)(rb[3] / 2.0), (float)(-rb[3] / 2.0)};
+    for (int i = 0; i < 4; ++i) {
+        c[2 * i] = (float)(a_cos * cx[i] + a_sin * cy[i] + rb[0]);
+        c[2 * i + 1] = (float)(-a_sin * cx[i] + a_cos * cy[i] + rb[1]);
+    }
+}
+
+static int orc_eval_pt_in_quad(float px, float py, const float *c)
+{
+    const float ab0 = c[2] - c[0], ab1 = c[3] - c[1], ad0 = c[6] - c[0], ad1 = c[7] - c[1];
+    const float ap0 = px - c[0], ap1 = py - c[1];
+    const float abab = ab0 * ab0 + ab1 * ab1, abap = ab0 * ap0 + ab1 * ap1;
+    const float adad = ad0 * ad0 + ad1 * ad1, adap = ad0 * ap0 + ad1 * ap1;
+    return abab >= abap && abap >= 0 && adad >= adap && adap >= 0;
+}
+
+static int orc_eval_seg_isect(const float *p1, const float *p2, int i, int j, float *out)
+{
+    const float A0 = p1[2 * i], A1 = p1[2 * i + 1], B0 = p1[2 * ((i + 1) % 4)], B1 = p1[2 * ((i + 1) % 4) + 1];
+    const float C0 = p2[2 * j], C1 = p2[2 * j + 1], D0 = p2[2 * ((j + 1) % 4)], D1 = p2[2 * ((j + 1) % 4) + 1];
+    const float BA0 = B0 - A0, BA1 = B1 - A1, DA0 = D0 - A0, CA0 = C0 - A0, DA1 = D1 - A1, CA1 = C1 - A1;
+    const int acd = DA1 * CA0 > CA1 * DA0;
+    const int bcd = (D1 - B1) * (C0 - B0) > (C1 - B1) * (D0 - B0);
+    if (acd != bcd) {
+        const int abc = CA1 * BA0 > BA1 * CA0, abd = DA1 * BA0 > BA1 * DA0;
+        if (abc != abd) {
+            const float DC0 = D0 - C0, DC1 = D1 - C1;
+            const float ABBA = A0 * B1 - B0 * A1, CDDC = C0 * D1 - D0 * C1;
+            const float DH = BA1 * DC0 - BA0 * DC1, Dx = ABBA * DC0 - BA0 * CDDC, Dy = ABBA * DC1 - BA1 * CDDC;
+            out[0] = Dx / DH;
+            out[1] = Dy / DH;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+static double orc_eval_inter(const float *rb1, const float *rb2)
+{
+    float c1[8], c2[8], ip[16 + 32];
+    int n = 0;
+    orc_eval_corners(rb1, c1);
+    orc_eval_corners(rb2, c2);
+    for (int i = 0; i < 4; ++i) {
+        if (orc_eval_pt_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { ip[2 * n] = c1[2 * i]; ip[2 * n + 1] = c1[2 * i + 1]; ++n; }
+        if (orc_eval_pt_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { ip[2 * n] = c2[2 * i]; ip[2 * n + 1] = c2[2 * i + 1]; ++n; }
+    }
+    float tp[2];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (orc_eval_seg_isect(c1, c2, i, j, tp)) { ip[2 * n] = tp[0]; ip[2 * n + 1] = tp[1]; ++n; }
+    if (n > 0) {                                         /* sort_vertex_in_convex_polygon */
+        float cen[2] = {0.f, 0.f}, vs[24];
+        for (int i = 0; i < n; ++i) { cen[0] += ip[2 * i]; cen[1] += ip[2 * i + 1]; }
+        cen[0] /= n; cen[1] /= n;
+        for (int i = 0; i < n; ++i) {
+            float v0 = ip[2 * i] - cen[0], v1 = ip[2 * i + 1] - cen[1];
+            const double d = sqrt((double)(v0 * v0 + v1 * v1));
+            v0 = (float)(v0 / d); v1 = (float)(v1 / d);
+            if (v1 < 0) v0 = -2 - v0;
+            vs[i] = v0;
+        }
+        for (int i = 1; i < n; ++i) {
+            if (vs[i - 1] > vs[i]) {
+                const float temp = vs[i], tx = ip[2 * i], ty = ip[2 * i + 1];
+                int j = i;
+                while (j > 0 && vs[j - 1] > temp) {
+                    vs[j] = vs[j - 1]; ip[2 * j] = ip[2 * j - 2]; ip[2 * j + 1] = ip[2 * j - 1]; --j;
+                }
+                vs[j] = temp; ip[2 * j] = tx; ip[2 * j + 1] = ty;
+            }
+        }
+    }
+    double area = 0.0;
+    for (int i = 0; i < n - 2; ++i) {
+        const float *a = ip, *b = ip + 2 * i + 2, *c = ip + 2 * i + 4;
+        area += fabs(((a[0] - c[0]) * (b[1] - c[1]) - (a[1] - c[1]) * (b[0] - c[0])) / 2.0);
+    }
+    return area;
+}
+
+/* iou[n][k] = f(query k, box n): criterion -1 IoU, 0 inter / area(query), 1 inter / area(box), else inter */
+void orc_rotate_iou_eval(const float *boxes, int n, const float *qboxes, int k, int criterion, float *iou)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) {
+            const float *r1 = qboxes + 5 * j, *r2 = boxes + 5 * i;
+            const float a1 = r1[2] * r1[3], a2 = r2[2] * r2[3];
+            const double in = orc_eval_inter(r1, r2);
+            double v;
+            if (criterion == -1) v = in / (a1 + a2 - in);
+            else if (criterion == 0) v = in / a1;
+            else if (criterion == 1) v = in / a2;
+            else v = in;
+            iou[(size_t)i * k + j] = (float)v;
+        }
+}

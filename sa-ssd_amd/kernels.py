@@ -501,3 +501,14 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, sumsq, lr, beta1, beta2, eps, we
     _C.check(_C.lib().sassd_adam_step(_C.ptr(param), _C.ptr(grad), _C.ptr(exp_avg), _C.ptr(exp_avg_sq),
                                       param.numel(), _C.ptr(sumsq), lr, beta1, beta2, eps, weight_decay, int(step),
                                       max_norm, grad_scale, _C.stream()), "sassd_adam_step")
+
+
+def rotate_iou_eval(boxes, query_boxes, criterion=-1):
+    """boxes [N,5], query_boxes [K,5] (cx, cy, x_dim, y_dim, angle) device tensors -> [N,K] overlap matrix of the KITTI
+    evaluation (criterion -1 IoU, 0 / 1 intersection over the query's / the box's area)."""
+    _chk_cuda(boxes, query_boxes)
+    n, k = boxes.shape[0], query_boxes.shape[0]
+    out = torch.zeros(n, k, dtype=torch.float32, device=boxes.device)
+    _C.check(_C.lib().sassd_rotate_iou_eval(_C.ptr(boxes), n, _C.ptr(query_boxes), k, int(criterion), _C.ptr(out),
+                                            _C.stream()), "sassd_rotate_iou_eval")
+    return out

@@ -285,3 +285,26 @@ def test_conv2d_winograd(dev, b, cin, cout, hw, relu):
     assert (y2.cpu() - torch.nn.functional.conv2d(x, w, None, 1, 1)).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
     assert not K.conv2d_wino_supported(28, 28, 200, 176) and not K.conv2d_wino_supported(256, 256, 199, 176)
     assert not K.conv2d_wino_supported(256, 256, 200, 44) and not K.conv2d_wino_supported(256, 256, 200, 66)
+
+
+def test_rotate_iou_eval(dev):
+    """KITTI-eval rotated IoU kernel vs the C oracle (same algorithm) and vs golden values produced by the reference's
+    own numba device functions; numpy-level mirror of rotate_iou_gpu_eval included."""
+    import os
+    from oracle import clib
+    from sassd import eval_ops
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_iou_ref.npz"))
+    b, q = torch.from_numpy(G["boxes"]).to(dev), torch.from_numpy(G["query"]).to(dev)
+    for crit in (-1, 0, 1, 2):
+        got = K.rotate_iou_eval(b, q, crit).cpu().numpy()
+        assert np.abs(got - clib.rotate_iou_eval(G["boxes"], G["query"], crit)).max() < 1e-6, crit
+        if crit < 2:
+            assert np.abs(got - G["iou_%d" % crit]).max() < 3e-6, crit
+    rng = np.random.default_rng(4)
+    big = np.stack([rng.uniform(0, 60, 700), rng.uniform(-30, 30, 700), rng.uniform(1, 3, 700), rng.uniform(2, 6, 700),
+                    rng.uniform(-4, 4, 700)], 1).astype(np.float64)
+    out = eval_ops.rotate_iou_gpu_eval(big, big[:300], -1)
+    assert out.dtype == np.float64 and out.shape == (700, 300)
+    ref = clib.rotate_iou_eval(big.astype(np.float32), big[:300].astype(np.float32), -1)
+    assert np.abs(out - ref).max() < 1e-6 and (out >= 0).all()
+    assert eval_ops.rotate_iou_gpu_eval(big[:0], big, 0).shape == (0, 700)

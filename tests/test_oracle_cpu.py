@@ -136,3 +136,15 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     assert lib.sassd_voxelize_workspace_bytes(21500, 5) > 0
     assert lib.sassd_conv2d_packed_floats(256, 28, 3) == 256 * 9 * 32
     assert lib.sassd_conv2d_packed_floats(28, 28, 1) == 32 * 32
+
+
+def test_eval_rotate_iou_oracle_vs_reference_functions():
+    """oracle rotate_iou_eval vs the reference's own numba device functions executed as plain Python
+    (tests/golden/make_golden_eval.py): all three criteria, incl. coincident / contained / disjoint boxes."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_iou_ref.npz"))
+    for crit in (-1, 0, 1):
+        got = clib.rotate_iou_eval(G["boxes"], G["query"], crit)
+        assert np.abs(got - G["iou_%d" % crit]).max() < 2e-6, crit
+    assert abs(float(G["iou_-1"][9, 9]) - 0.25) < 1e-6            # contained box of a quarter of the area
+    assert float(G["iou_-1"][10, 10]) == 0.0                       # disjoint

@@ -23,7 +23,9 @@
 //     four xi are combined through LDS, then scale/shift/ReLU and float2 stores of the 2x2 pixels.
 // Measured history (B=1, 256->256 @200x176; direct kernel 0.39 ms): per-thread patch gathers + transformed-input buffer
 // in LDS, unspecialised 8 waves 0.262; two 4-wave workgroups per CU 0.267; loader/MFMA specialisation 0.272; LDS-DMA row
-// staging 0.266; XCD blocking 0.260; transform fused into 4 MFMA waves 0.285; into 8 MFMA waves (this file) 0.259.
+// staging 0.266; XCD blocking 0.260; transform fused into 4 MFMA waves 0.285; into 8 MFMA waves (this file) 0.259; row DMA
+// two chunks ahead 0.264; 8 MFMA + 8 loader waves with a transformed-input buffer 0.264; 32-channel chunks (half the
+// barriers, this file) 0.259; accumulators pinned to AGPRs 0.251.  Time is affine in Cin (tools/wino_scaling.py).
 // Numerics: F(2,3) in fp32 has a relative error ~1e-6 (transform matrices hold only 0, +-1, +-1/2).
 #include "common.h"
 
@@ -33,10 +35,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kNT = 32;                  // tiles per workgroup
 constexpr int kCoW = 64;                 // couts per workgroup
-constexpr int kKC = 16;                  // input channels per chunk
+constexpr int kKC = 32;                  // input channels per chunk (one barrier per chunk: 64 MFMAs per MFMA wave)
+constexpr int kNDma = kKC * 2 * 4 * 18 / 256;      // DMA wave-loads per loader thread and chunk (18)
 constexpr int kGb = 8;                   // tile groups per XCD-local reuse block
 constexpr int kRawW = 72;                // staged columns per run (66 needed + alignment slack), 18 float4
-constexpr int kRawBuf = kKC * 2 * 4 * kRawW;       // floats per raw-row buffer: [ci][run][row][col]  (9216 = 36 KB)
+constexpr int kRawBuf = kKC * 2 * 4 * kRawW;       // floats per raw-row buffer: [ci][run][row][col]  (18432 = 72 KB)
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
@@ -82,7 +85,7 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
 
 __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
 {
-    extern __shared__ float smem[];                  // 3 x raw-row buffer (108 KB); reused by the output reduction
+    extern __shared__ float smem[];                  // 2 x raw-row buffer (144 KB); reused by the output reduction
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware work order.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own 4 MB L2.
@@ -124,10 +127,10 @@ __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
         // ================================ loader waves: DMA only ======================================================
         const int lt = tid - 512;
         // float4 i = lt + 256*k of the raw buffer, i = ((ci*2 + run)*4 + row)*18 + f4
-        const float *dsrc[9];
+        const float *dsrc[kNDma];
         unsigned dvalid = 0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < kNDma; ++k) {
             const int i = lt + 256 * k;
             const int f4 = i % 18, row = (i / 18) & 3, run = (i / 72) & 1, ci = i / 144;
             const int yy = 2 * rty[run] - 1 + row, xx = cola[run] + 4 * f4;
@@ -139,38 +142,26 @@ __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
         const int wl = wave - 8;
         auto dma_rows = [&](float *dst, int chunk) { // issues one chunk's rows
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
+            for (int k = 0; k < kNDma; ++k) {
                 const float *src = dsrc[k] + (((dvalid >> k) & 1u) ? (size_t)chunk * cstride : 0);
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(dst + (wl * 64 + 256 * k) * 4), 16, 0, 0);
             }
         };
-        // Three row buffers, DMA issued TWO chunks ahead.  The barrier is a bare s_barrier behind an explicit
-        // s_waitcnt vmcnt(9): only the older group of 9 DMAs (the chunk needed next) must have landed, the newest 9 stay
-        // in flight across the barrier (__syncthreads() would drain vmcnt to 0 and cap the lookahead at one chunk --
-        // with 92 % of the MFMAs skipped on a sparse input the kernel time did not move: it was bound by the per-chunk
-        // memory round trip, not by the MFMA pipe).
+        // Two row buffers, DMA issued one chunk ahead at the top of the iteration; __syncthreads() (the compiler drains
+        // vmcnt before it) makes the chunk visible.  A chunk is 32 channels = 64 MFMAs per MFMA wave (8.2 k cycles per
+        // SIMD), longer than the DMA round trip: with 16-channel chunks every variant of this kernel measured the same
+        // ~7.5 k cycles per chunk whatever work the chunk contained.
         auto chunk_of = [&](int q) {
             int c = q + rot;
             c -= c >= nchunk ? nchunk : 0;
             return c;
         };
         dma_rows(smem, chunk_of(0));
-        if (nchunk > 1) {
-            dma_rows(smem + kRawBuf, chunk_of(1));
-            __builtin_amdgcn_s_waitcnt(0x0F79);      // vmcnt(9): chunk 0 landed, chunk 1 in flight
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-        }
-        __builtin_amdgcn_s_barrier();
+        __syncthreads();
         for (int q = 0; q < nchunk; ++q) {
-            // raw[(q+2)%3] was last read during step q-1 (barrier since then)
-            if (q + 2 < nchunk) {
-                dma_rows(smem + ((q + 2) % 3) * kRawBuf, chunk_of(q + 2));
-                __builtin_amdgcn_s_waitcnt(0x0F79);  // chunk q+1 landed, chunk q+2 in flight
-            } else {
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-            }
-            __builtin_amdgcn_s_barrier();
+            // raw[(q+1)&1] was last read during step q-1 (barrier since then)
+            if (q + 1 < nchunk) dma_rows(smem + ((q + 1) & 1) * kRawBuf, chunk_of(q + 1));
+            __syncthreads();
         }
     } else {
         // ================================ MFMA waves ==================================================================
@@ -201,14 +192,14 @@ __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
         const float sg = xi == 1 ? 1.f : -1.f;
         const int lbase = (kh * 8 + trun * 4) * kRawW + (2 * ttx - 1 - cola[trun]);      // + ci_even*8*kRawW + r*kRawW + c
         const int offa = lbase + ra * kRawW, offb = lbase + rbw * kRawW;
-        fetch_w(2 * rot, wq[0]);
+        fetch_w((kKC / 8) * rot, wq[0]);
         __syncthreads();                             // rows of the first chunk landed
         for (int q = 0; q < nchunk; ++q) {
             int c = q + rot;                         // this workgroup's chunk order starts at `rot`
             c -= c >= nchunk ? nchunk : 0;
             int c1 = c + 1;
             c1 -= c1 >= nchunk ? nchunk : 0;
-            const float *rw = smem + (q % 3) * kRawBuf;
+            const float *rw = smem + (q & 1) * kRawBuf;
             float pa[2][4], pb[2][4];                // raw rows (ra, rb) of the patch, double buffered over k-steps
             auto fetch_raw = [&](int step, float *a, float *b) {    // step = h*4 + s -> channels 2*step + kh
                 const float *src = rw + step * (2 * 8 * kRawW);
@@ -217,10 +208,11 @@ __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
             };
             fetch_raw(0, pa[0], pb[0]);
 #pragma unroll
-            for (int step = 0; step < 8; ++step) {
-                const int h = step >> 2, s = step & 3, cur = step & 1;
-                if (s == 0) fetch_w(h == 0 ? 2 * c + 1 : 2 * c1, wq[(h + 1) & 1]);       // next half chunk's weights
-                if (step + 1 < 8) fetch_raw(step + 1, pa[cur ^ 1], pb[cur ^ 1]);
+            for (int step = 0; step < kKC / 2; ++step) {
+                const int hh = step >> 2, h = hh & 1, s = step & 3, cur = step & 1;      // hh: 8-channel slice of the chunk
+                if (s == 0)                          // next 8-channel slice's weights (first slice of the next chunk at the end)
+                    fetch_w(hh + 1 < kKC / 8 ? (kKC / 8) * c + hh + 1 : (kKC / 8) * c1, wq[(h + 1) & 1]);
+                if (step + 1 < kKC / 2) fetch_raw(step + 1, pa[cur ^ 1], pb[cur ^ 1]);
                 float t[4], bv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) t[q] = fmaf(sg, pb[cur][q], pa[cur][q]);
@@ -288,20 +280,20 @@ extern "C" void sassd_debug_set_wino(int flags) { g_wino_dbg = flags; }
 extern "C" int sassd_conv2d_wino_supported(int Cin, int Cout, int H, int W)
 {
     // W % 4: zero padding is decided per 16-byte DMA; W >= 64: a 32-tile group spans at most two tile rows
-    return (Cin >= 16 && Cin % 16 == 0 && Cout >= 32 && Cout % 32 == 0 && H >= 2 && H % 2 == 0 && W >= 64 && W % 4 == 0)
+    return (Cin >= kKC && Cin % kKC == 0 && Cout >= 32 && Cout % 32 == 0 && H >= 2 && H % 2 == 0 && W >= 64 && W % 4 == 0)
                ? 1 : 0;
 }
 
 extern "C" size_t sassd_conv2d_wino_packed_floats(int Cin, int Cout)
 {
-    if (Cin < 16 || Cin % 16 || Cout < 1) return 0;
+    if (Cin < kKC || Cin % kKC || Cout < 1) return 0;
     const int ncb32 = cdiv(cdiv(Cout, 64) * 64, 32);
     return (size_t)ncb32 * (Cin / 8) * 16 * 256;
 }
 
 extern "C" int sassd_conv2d_wino_pack_weight(const float *w, int Cout, int Cin, float *packed, void *stream_)
 {
-    if (!w || !packed || Cin < 16 || Cin % 16 || Cout < 1) return SASSD_EINVAL;
+    if (!w || !packed || Cin < kKC || Cin % kKC || Cout < 1) return SASSD_EINVAL;
     const int ncb32 = cdiv(cdiv(Cout, 64) * 64, 32);
     const size_t total = (size_t)ncb32 * (Cin / 8) * 16 * 256;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, w,
@@ -322,7 +314,7 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
     P.ncb64 = cdiv(Cout, kCoW);
     P.relu = relu;
     P.dbg = g_wino_dbg;
-    const size_t lds = (size_t)(3 * kRawBuf) * sizeof(float);                       // 110 592 B
+    const size_t lds = (size_t)(2 * kRawBuf) * sizeof(float);                       // 147 456 B
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)conv2d_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -260,9 +260,9 @@ def test_spconv_backward(dev, cin, cout, strided):
         assert e < 2e-4 * max(1.0, x.grad.abs().max().item()), e
 
 
-@pytest.mark.parametrize("b,cin,cout,hw,relu", [(1, 16, 32, (4, 64), False), (2, 32, 64, (10, 72), True),
+@pytest.mark.parametrize("b,cin,cout,hw,relu", [(1, 32, 32, (4, 64), False), (2, 64, 64, (10, 72), True),
                                                (1, 320, 256, (200, 176), True), (2, 256, 256, (50, 88), False),
-                                               (1, 48, 96, (2, 64), True), (3, 64, 160, (6, 132), True)])
+                                               (1, 96, 96, (2, 64), True), (3, 64, 160, (6, 132), True)])
 def test_conv2d_winograd(dev, b, cin, cout, hw, relu):
     """Winograd F(2x2,3x3) conv against torch-CPU conv2d (fp32 reference of the same op) and against the direct HIP
     kernel: odd tile counts, tiles wrapping rows / images inside a 32-tile group, cout not a multiple of 64, borders."""
@@ -285,6 +285,7 @@ def test_conv2d_winograd(dev, b, cin, cout, hw, relu):
     assert (y2.cpu() - torch.nn.functional.conv2d(x, w, None, 1, 1)).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
     assert not K.conv2d_wino_supported(28, 28, 200, 176) and not K.conv2d_wino_supported(256, 256, 199, 176)
     assert not K.conv2d_wino_supported(256, 256, 200, 44) and not K.conv2d_wino_supported(256, 256, 200, 66)
+    assert not K.conv2d_wino_supported(48, 256, 200, 176)
 
 
 def test_rotate_iou_eval(dev):

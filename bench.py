@@ -13,8 +13,9 @@ batch-1 pass; --inflight 1 gives the strictly sequential number, also reported a
 
 The JSON line also carries:
   roofline      dominant kernel (BEV 3x3 conv, Winograd on the fp32 MFMA): algorithmic FLOPs per launch / mean launch
-                duration measured live with HIP events on the launch stream in the timed region, vs the 157.3 TF
-                fp32-MFMA peak; `isolated` = the same from a one-frame-at-a-time pass after the timed region.
+                duration measured live with HIP events on the launch stream, one frame at a time (pass right after the
+                timed region), vs the 157.3 TF fp32-MFMA peak; `timed_region` = the same launches while three frames
+                share the GPU.
   roofline_sparse  the sparse path (7 rulebooks + 14 sparse convs) against the HBM roofline, from B_gs bytes.
   cpu_baseline  the CPU oracle (a faithful port: C voxelizer/NMS + torch-CPU sparse/dense convs) timed on this
                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
@@ -273,19 +274,22 @@ def main():
                    "vs_baseline_ref": "reference readme.md:2 '25 FPS' (hardware unstated), per-GPU fps / 25"},
         "roofline": {"bound": "mfma", "kernel": "conv2d_wino_kernel (BEV 256->256 3x3, Winograd F(2x2,3x3) on fp32 MFMA "
                                                 "32x32x2)",
-                     "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                     "frac": round(achieved_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
+                     "achieved": round(iso_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                     "frac": round(iso_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
                      "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "
                                      "passes, profiles/r01_conv2d_hbm_traffic.json)",
-                     "flops_per_launch": conv_flops, "ms_per_launch": round(conv_ms, 4),
-                     "note": "achieved = algorithmic (direct-convolution) flops of SURVEY 8(d) / mean launch duration in "
-                             "the timed region, where %d frames are in flight on separate streams and share the GPU; "
-                             "'isolated' = the same kernel with one frame at a time; the kernel EXECUTES 16/36 of "
-                             "those flops on the MFMA (mfma_pipe_frac)" % S,
-                     "isolated": {"ms_per_launch": round(conv_iso, 4), "achieved": round(iso_tf, 2),
-                                  "frac": round(iso_tf / PEAK_F32_MFMA_TF, 4),
-                                  "executed_flops_per_launch": wino_flops,
-                                  "mfma_pipe_frac": round(wino_flops / (conv_iso * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4)}},
+                     "flops_per_launch": conv_flops, "ms_per_launch": round(conv_iso, 4),
+                     "executed_flops_per_launch": wino_flops,
+                     "mfma_pipe_frac": round(wino_flops / (conv_iso * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
+                     "note": "achieved = algorithmic (direct-convolution) flops of SURVEY 8(d) / mean launch duration, HIP "
+                             "events on the launch stream, one frame at a time (the pass right after the timed region; "
+                             "this is the duration rocprofv3 --kernel-trace reports, profiles/); the kernel EXECUTES "
+                             "16/36 of those flops on the MFMA (mfma_pipe_frac), which is how frac can exceed 1",
+                     "timed_region": {"frames_in_flight": S, "ms_per_launch": round(conv_ms, 4),
+                                      "achieved": round(achieved_tf, 2),
+                                      "frac": round(achieved_tf / PEAK_F32_MFMA_TF, 4),
+                                      "note": "same launches inside the timed region, where frames on separate streams "
+                                              "share the GPU"}},
         "roofline_sparse": {"bound": "hbm", "kernels": "7 rulebooks + 14 spconv_fwd_kernel launches (isolated pass)",
                             "achieved": round(sp_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": round(sp_gbs / PEAK_HBM_GBS, 4),

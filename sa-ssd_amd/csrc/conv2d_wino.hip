@@ -206,20 +206,31 @@ __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { a[q] = src[offa + q]; b[q] = src[offb + q]; }
             };
+            // Software pipeline over the k-steps, pinned with sched_barrier (left alone the compiler sinks every LDS read
+            // next to its use: 4 MFMAs per exposed LDS round trip, s_nop hazards between the transform and the MFMA):
+            //   step k:  issue the LDS reads of step k+2  |  transform step k+1 (reads issued a step ago)  |  MFMAs of k
+            float bv[2][4];
+            auto transform = [&](const float *a, const float *b, float *o) {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = fmaf(sg, b[e], a[e]);
+                o[0] = t[0] - t[2]; o[1] = t[1] + t[2]; o[2] = t[2] - t[1]; o[3] = t[1] - t[3];
+            };
             fetch_raw(0, pa[0], pb[0]);
+            fetch_raw(1, pa[1], pb[1]);
+            transform(pa[0], pb[0], bv[0]);
 #pragma unroll
             for (int step = 0; step < kKC / 2; ++step) {
                 const int hh = step >> 2, h = hh & 1, s = step & 3, cur = step & 1;      // hh: 8-channel slice of the chunk
                 if (s == 0)                          // next 8-channel slice's weights (first slice of the next chunk at the end)
                     fetch_w(hh + 1 < kKC / 8 ? (kKC / 8) * c + hh + 1 : (kKC / 8) * c1, wq[(h + 1) & 1]);
-                if (step + 1 < kKC / 2) fetch_raw(step + 1, pa[cur ^ 1], pb[cur ^ 1]);
-                float t[4], bv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t[q] = fmaf(sg, pb[cur][q], pa[cur][q]);
-                bv[0] = t[0] - t[2]; bv[1] = t[1] + t[2]; bv[2] = t[2] - t[1]; bv[3] = t[1] - t[3];
+                if (step + 2 < kKC / 2) fetch_raw(step + 2, pa[cur], pb[cur]);           // raw set `cur` was consumed last step
+                __builtin_amdgcn_sched_barrier(0);
+                if (step + 1 < kKC / 2) transform(pa[cur ^ 1], pb[cur ^ 1], bv[cur ^ 1]);
 #pragma unroll
                 for (int nu = 0; nu < 4; ++nu)
-                    acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[h][nu][s], bv[nu], acc[nu], 0, 0, 0);
+                    acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[h][nu][s], bv[cur][nu], acc[nu], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
         }

@@ -144,7 +144,8 @@ int sassd_conv2d_fwd(const float *x, const float *w_packed, const float *scale, 
 /* Winograd F(2x2,3x3) variant of the 3x3 / stride 1 / pad 1 convolution (the BEVNet layers cmn.py:240-262): 2.25x
  * fewer multiplications on the fp32 MFMA, transforms fused (nothing but x, packed weights and y touches HBM).  Same
  * epilogue as sassd_conv2d_fwd (y = relu?(conv * scale[co] + shift[co]), NULL scale/shift = 1/0).  Requires
- * Cin % 16 == 0, Cout % 32 == 0, even H and W (sassd_conv2d_wino_supported); relative error ~1e-6 vs the direct kernel. */
+ * Cin % 32 == 0, Cout % 32 == 0, even H, W % 4 == 0 and W >= 64 (sassd_conv2d_wino_supported; anything else takes
+ * sassd_conv2d_fwd); relative error ~1e-6 vs the direct kernel. */
 int sassd_conv2d_wino_supported(int Cin, int Cout, int H, int W);
 size_t sassd_conv2d_wino_packed_floats(int Cin, int Cout);
 int sassd_conv2d_wino_pack_weight(const float *w, int Cout, int Cin, float *packed, void *stream);

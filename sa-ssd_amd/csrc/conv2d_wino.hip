@@ -25,7 +25,10 @@
 // in LDS, unspecialised 8 waves 0.262; two 4-wave workgroups per CU 0.267; loader/MFMA specialisation 0.272; LDS-DMA row
 // staging 0.266; XCD blocking 0.260; transform fused into 4 MFMA waves 0.285; into 8 MFMA waves (this file) 0.259; row DMA
 // two chunks ahead 0.264; 8 MFMA + 8 loader waves with a transformed-input buffer 0.264; 32-channel chunks (half the
-// barriers, this file) 0.259; accumulators pinned to AGPRs 0.251.  Time is affine in Cin (tools/wino_scaling.py).
+// barriers, this file) 0.259; accumulators pinned to AGPRs 0.251; + k-step software pipeline pinned with sched_barrier
+// 0.251; + no SLP / load-store vectorizer (Makefile: 90 fewer VALU instructions per 64 MFMAs -- VALU never co-executes
+// with MFMA, SQ_VALU_MFMA_COEXEC_CYCLES = 0) 0.235; a 128-cout workgroup of 8 MFMA+DMA waves (8 MFMAs per transform)
+// 0.257 at B=1 (550 workgroups: 3 rounds) and no gain at B=2.  Time is affine in Cin (tools/wino_scaling.py).
 // Numerics: F(2,3) in fp32 has a relative error ~1e-6 (transform matrices hold only 0, +-1, +-1/2).
 #include "common.h"
 

@@ -183,3 +183,20 @@ def test_flat_params_views():
     assert torch.equal(m[0].weight, before["0.weight"] * 2)
     f.zero_grad()
     assert float(m[2].weight.grad.abs().sum()) == 0
+
+
+def test_rpn_loss_with_an_empty_sample():
+    """A frame without ground truth (all anchors inside the mask become negatives) must not break the batch."""
+    head = SSDRotateHead(num_class=1, num_output_filters=8, num_anchor_per_loc=2, box_code_size=7)
+    anc, msk, gtb, gtl, gtt = _rpn_inputs()
+    gtb[1], gtl[1], gtt[1] = gtb[1][:0], gtl[1][:0], gtt[1][:0]
+    box, cls, dr = (t(k).clone().requires_grad_() for k in ("rpn_box", "rpn_cls", "rpn_dir"))
+    cfg = ConfigDict(assigner=ConfigDict(Car=ConfigDict(pos_iou_thr=0.6, neg_iou_thr=0.45, min_pos_iou=0.45),
+                                         ignore_iof_thr=-1, similarity_fn="NearestIouSimilarity"), anchor_thr=0.1)
+    ls = head.loss(box, cls, dr, gtb, gtl, gtt, anc, msk, cfg)
+    tot = sum(v.sum() for v in ls.values())
+    assert torch.isfinite(tot)
+    tot.backward()
+    assert torch.isfinite(box.grad).all() and float(box.grad[1].abs().sum()) == 0.0     # no positives -> no box loss
+    guided, labels = head.get_guided_anchors(box.detach(), cls.detach(), dr.detach(), anc, msk, gtb, gtl, thr=0.1)
+    assert guided[1].shape[1] == 7 and len(labels[1]) == len(guided[1])

@@ -63,7 +63,7 @@ class OneCycle:
     def values(self, step):
         lr, mom = self.optimizer.lr, self.optimizer.mom
         for (s, e, (a, b)), (_, _, (ma, mb)) in zip(self.lr_phases, self.mom_phases):
-            if step >= s:
+            if step >= s and e > s:                  # (a phase of zero length -- tiny total_step -- is skipped)
                 lr, mom = annealing_cos(a, b, (step - s) / (e - s)), annealing_cos(ma, mb, (step - s) / (e - s))
         return lr, mom
 

@@ -148,3 +148,14 @@ def test_eval_rotate_iou_oracle_vs_reference_functions():
         assert np.abs(got - G["iou_%d" % crit]).max() < 2e-6, crit
     assert abs(float(G["iou_-1"][9, 9]) - 0.25) < 1e-6            # contained box of a quarter of the area
     assert float(G["iou_-1"][10, 10]) == 0.0                       # disjoint
+
+
+def test_pts_in_boxes3d_oracle_vs_reference_cpp():
+    """oracle pts_in_boxes3d vs the reference's own C++ (points_op.cpp compiled from /root/reference by
+    tests/golden/make_golden_points_op.py): flags and centre offsets bit-exact, incl. overlapping boxes (last box wins)
+    and the 10 m coarse-reject distance."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "pts_in_boxes_ref.npz"))
+    flag, reg = clib.pts_in_boxes3d(G["pts"], G["boxes"])
+    assert np.array_equal(flag, G["flag"]) and np.array_equal(reg, G["reg"])
+    assert int(G["flag"].max(0).sum()) > 300

@@ -4,8 +4,10 @@
   oracle/_ref/libref_iou3d.so  <- /root/reference/mmdet/ops/iou3d/src/iou3d_kernel.cu lines 1-221
                                   (the reference's own __device__ functions compiled for the HOST;
                                   only when /root/reference exists; source is piped to g++, never copied)
-  oracle/_ref/libref_points_op.so is NOT built: points_op.cpp needs torch headers (27 s build) and only
-                                  serves the training-side pts_in_boxes3d row (later round).
+  oracle/_ref/libref_interp.so <- /root/reference/mmdet/ops/pointnet2/src/interpolate_gpu.cu, the three __global__
+                                  kernels (lines 9-56, 80-102, 124-146) compiled for the HOST: blockIdx / threadIdx are
+                                  plain globals that a wrapper loops over, atomicAdd is a plain add
+  oracle/_ref/points_op_cpu/   <- points_op.cpp JIT-built against torch by tests/golden/make_golden_points_op.py
 """
 import os
 import subprocess
@@ -30,6 +32,55 @@ _WRAP = r"""
 extern "C" float ref_box_overlap(const float* a, const float* b) { return box_overlap(a, b); }
 extern "C" float ref_iou_bev(const float* a, const float* b) { return iou_bev(a, b); }
 """
+
+
+REF_INTERP_CU = "/root/reference/mmdet/ops/pointnet2/src/interpolate_gpu.cu"
+_INTERP_PRELUDE = r"""
+#include <cmath>
+#include <cstdio>
+#define __device__
+#define __global__
+#define __restrict__
+struct Idx3 { int x, y, z; };
+static Idx3 blockIdx, threadIdx, blockDim = {1, 1, 1};
+static inline void atomicAdd(float* p, float v) { *p += v; }
+"""
+_INTERP_WRAP = r"""
+extern "C" void ref_three_nn(int n, int m, const float* unknown, const float* known, float* dist2, int* idx) {
+    for (int p = 0; p < n; ++p) { blockIdx.x = p; threadIdx.x = 0; three_nn_kernel_fast(n, m, unknown, known, dist2, idx); }
+}
+extern "C" void ref_three_interpolate(int c, int m, int n, const float* points, const int* idx, const float* weight,
+                                      float* out) {
+    for (int p = 0; p < n; ++p) for (int ch = 0; ch < c; ++ch) {
+        blockIdx.x = p; blockIdx.y = ch; threadIdx.x = 0;
+        three_interpolate_kernel_fast(c, m, n, points, idx, weight, out);
+    }
+}
+extern "C" void ref_three_interpolate_grad(int c, int n, int m, const float* grad_out, const int* idx,
+                                           const float* weight, float* grad_points) {
+    for (int p = 0; p < n; ++p) for (int ch = 0; ch < c; ++ch) {
+        blockIdx.x = p; blockIdx.y = ch; threadIdx.x = 0;
+        three_interpolate_grad_kernel_fast(c, n, m, grad_out, idx, weight, grad_points);
+    }
+}
+"""
+
+
+def build_ref_interp(force=False):
+    """The reference's three_nn / three_interpolate(_grad) CUDA kernels compiled for the host (only where the
+    reference tree is mounted).  Returns the .so path or None."""
+    dst = os.path.join(REF, "libref_interp.so")
+    if not os.path.exists(REF_INTERP_CU):
+        return dst if os.path.exists(dst) else None
+    os.makedirs(REF, exist_ok=True)
+    if force or not _newer(dst, [REF_INTERP_CU, __file__]):
+        with open(REF_INTERP_CU) as f:
+            L = f.readlines()
+        body = "".join(L[8:56]) + "".join(L[79:102]) + "".join(L[123:146])     # the three kernels, no launchers
+        tu = _INTERP_PRELUDE + body + _INTERP_WRAP
+        subprocess.run(["g++", "-x", "c++", "-O2", "-fno-fast-math", "-ffp-contract=off", "-shared", "-fPIC", "-w",
+                        "-o", dst, "-"], input=tu.encode(), check=True)
+    return dst
 
 
 def _newer(dst, srcs):
@@ -68,3 +119,4 @@ def build_ref(force=False):
 if __name__ == "__main__":
     print(build_oracle(True))
     print(build_ref(True))
+    print(build_ref_interp(True))

@@ -123,3 +123,18 @@ def test_pts_in_boxes3d_vs_reference_golden(dev):
     flag, reg = K.pts_in_boxes3d(torch.from_numpy(G["pts"]).to(dev), torch.from_numpy(G["boxes"]).to(dev))
     assert np.array_equal(flag.cpu().numpy(), G["flag"])
     assert np.array_equal(reg.cpu().numpy(), G["reg"])
+
+
+def test_interpolation_vs_reference_golden(dev):
+    """HIP three_nn (brute force and binned) / three_interpolate against outputs of the reference's own kernels
+    (tests/golden/interp_ref.npz); the gradient up to fp32 summation order."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "interp_ref.npz"))
+    u, k = torch.from_numpy(G["unknown"]).to(dev), torch.from_numpy(G["known"]).to(dev)
+    for d, i in (K.three_nn(u, k), K.three_nn_binned(u, k, (0., -40., 70., 40.), 1.6, 3)):
+        assert np.array_equal(i.cpu().numpy(), G["idx"]) and np.array_equal(d.cpu().numpy(), G["dist2"])
+    idx, w = torch.from_numpy(G["idx"]).to(dev), torch.from_numpy(G["weight"]).to(dev)
+    out = K.three_interpolate(torch.from_numpy(G["feat"]).to(dev), idx, w)
+    assert np.abs(out.cpu().numpy() - G["out"]).max() < 1e-6          # fused multiply-adds on the device: last ulp
+    gp = K.three_interpolate_grad(torch.from_numpy(G["grad_out"]).to(dev), idx, w, len(G["known"]))
+    assert np.abs(gp.cpu().numpy() - G["grad_points"]).max() < 1e-5

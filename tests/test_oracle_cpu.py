@@ -159,3 +159,15 @@ def test_pts_in_boxes3d_oracle_vs_reference_cpp():
     flag, reg = clib.pts_in_boxes3d(G["pts"], G["boxes"])
     assert np.array_equal(flag, G["flag"]) and np.array_equal(reg, G["reg"])
     assert int(G["flag"].max(0).sum()) > 300
+
+
+def test_interpolation_oracle_vs_reference_kernels():
+    """oracle three_nn / three_interpolate / grad vs the reference's own CUDA kernels compiled for the host
+    (oracle/build.py::build_ref_interp -> tests/golden/interp_ref.npz): bit-exact."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "interp_ref.npz"))
+    d, i = clib.three_nn(G["unknown"], G["known"])
+    assert np.array_equal(i, G["idx"]) and np.array_equal(d, G["dist2"])
+    assert np.array_equal(clib.three_interpolate(G["feat"], G["idx"], G["weight"]), G["out"])
+    assert np.array_equal(clib.three_interpolate_grad(G["grad_out"], G["idx"], G["weight"], len(G["known"])),
+                          G["grad_points"])

@@ -171,3 +171,21 @@ def test_interpolation_oracle_vs_reference_kernels():
     assert np.array_equal(clib.three_interpolate(G["feat"], G["idx"], G["weight"]), G["out"])
     assert np.array_equal(clib.three_interpolate_grad(G["grad_out"], G["idx"], G["weight"], len(G["known"])),
                           G["grad_points"])
+
+
+def test_anchor_mask_and_near_bbox_vs_reference_functions():
+    """oracle anchors_mask (+ sassd.anchors.rbbox2d_to_near_bbox) vs the reference's own numba functions run as plain
+    Python (tests/golden/make_golden_anchor_mask.py): masks bit-exact for two frames and both thresholds."""
+    import os
+    from oracle import nets as onets
+    from sassd import anchors as A, synth
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "anchor_mask_ref.npz"))
+    an = A.AnchorGeneratorStride(sizes=[1.6, 3.9, 1.56], anchor_strides=[.4, .4, 1.], anchor_offsets=[.2, -39.8, -1.78],
+                                 rotations=[0, 1.57])([1, 200, 176]).reshape(-1, 7)
+    bv = A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]]).astype(np.float32)
+    assert np.array_equal(bv, G["anchors_bv"])
+    for name in ("small", "k17"):
+        for thr in (1, 0):
+            m = onets.anchors_mask(G["coors_" + name], bv, synth.KITTI_VOXEL, synth.KITTI_RANGE, (1408, 1600, 40), thr)
+            ref = np.unpackbits(G["mask_%s_thr%d" % (name, thr)])[:len(bv)].astype(bool)
+            assert np.array_equal(m, ref), (name, thr, int((m != ref).sum()))

@@ -178,6 +178,19 @@ def main():
     guided, glabels = rpn.get_guided_anchors(box.detach(), cls.detach(), dr.detach(), anc, msk, gtb, gtl, thr=0.1)
     for i in range(2):
         out["guided%d" % i], out["guided_labels%d" % i] = guided[i], glabels[i]
+    # the inference call of the same method (single_stage.py:122: no ground truth, thr 0.1) -- pins oracle/nets.py
+    tguided, tlabels = rpn.get_guided_anchors(box.detach(), cls.detach(), dr.detach(), anc, msk, None, None, thr=0.1)
+    for i in range(2):
+        out["test_guided%d" % i], out["test_guided_labels%d" % i] = tguided[i], tlabels[i]
+    # three-class variant (multi_cfg): max over classes picks the label
+    rpn3 = head.SSDRotateHead(num_class=3, num_output_filters=8, num_anchor_per_loc=2, box_code_size=7)
+    box3 = torch.randn(1, 3, 20, 22, 14, generator=g) * 0.2
+    cls3 = torch.randn(1, 3, 20, 22, 6, generator=g) - 1.5
+    dr3 = torch.randn(1, 3, 20, 22, 4, generator=g)
+    anc3 = torch.stack([anchors[:20 * 22 * 2], a2[:20 * 22 * 2], anchors[100:100 + 20 * 22 * 2]], 0).view(1, -1, 7)
+    msk3 = (torch.rand(1, 3 * 20 * 22 * 2, generator=g) > 0.3)
+    g3, l3 = rpn3.get_guided_anchors(box3, cls3, dr3, anc3, msk3, None, None, thr=0.1)
+    out.update(mc_box=box3, mc_cls=cls3, mc_dir=dr3, mc_anchors=anc3, mc_mask=msk3, mc_guided=g3[0], mc_labels=l3[0])
 
     # ---- PSWarpHead.loss (rotated 3-D IoU assignment) -------------------------------------------------------------
     ext = head.PSWarpHead(grid_offsets=(0., 40.), featmap_stride=.4, in_channels=8, num_class=1, num_parts=28)

@@ -189,3 +189,22 @@ def test_anchor_mask_and_near_bbox_vs_reference_functions():
             m = onets.anchors_mask(G["coors_" + name], bv, synth.KITTI_VOXEL, synth.KITTI_RANGE, (1408, 1600, 40), thr)
             ref = np.unpackbits(G["mask_%s_thr%d" % (name, thr)])[:len(bv)].astype(bool)
             assert np.array_equal(m, ref), (name, thr, int((m != ref).sum()))
+
+
+def test_guided_anchors_inference_vs_reference_method():
+    """oracle guided_anchors (inference path) vs the reference's own SSDRotateHead.get_guided_anchors called without
+    ground truth (tests/golden/make_golden_train.py), one class and the three-class variant."""
+    import os
+    from oracle import nets as onets
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_fns.npz"))
+    t = lambda k: torch.from_numpy(G[k])                                  # noqa: E731
+    anc = torch.stack([t("anchors"), t("a2")])
+    msk = torch.stack([t("anchor_mask"), t("m2")])
+    got = onets.guided_anchors(t("rpn_box"), t("rpn_cls"), t("rpn_dir"), anc, msk, 1, 0.1)
+    for i in range(2):
+        assert got[i][0].shape == G["test_guided%d" % i].shape
+        assert np.abs(got[i][0].numpy() - G["test_guided%d" % i]).max() < 1e-6
+        assert np.array_equal(got[i][1].numpy(), G["test_guided_labels%d" % i])
+    got3 = onets.guided_anchors(t("mc_box"), t("mc_cls"), t("mc_dir"), t("mc_anchors"), t("mc_mask"), 3, 0.1)
+    assert np.abs(got3[0][0].numpy() - G["mc_guided"]).max() < 1e-6
+    assert np.array_equal(got3[0][1].numpy(), G["mc_labels"]) and set(np.unique(G["mc_labels"])) == {0, 1, 2}

@@ -82,9 +82,28 @@ def import_reference():
     bc.GroundBox3dCoder = type("GroundBox3dCoder", (), {})
     sys.modules["mmdet.core.bbox3d.box_coders"] = bc
     sys.modules["mmdet.core.bbox3d"].box_coders = bc
-    nms = types.ModuleType("mmdet.core.post_processing.bbox_nms")
-    nms.rotate_nms_torch = None
-    sys.modules["mmdet.core.post_processing.bbox_nms"] = nms
+    # nms: the reference's rotate_nms_torch / iou3d_utils.nms_gpu Python run unchanged; only the compiled
+    # iou3d_cuda.nms_gpu(boxes_sorted, keep, thresh) -> count is served here: greedy pass in score order
+    # (iou3d.cpp:100-116) over the reference's own iou_bev device function (oracle/_ref)
+    import ctypes as C
+
+    def nms_gpu_ext(boxes, keep, thresh):
+        b = np.ascontiguousarray(boxes.detach().numpy(), np.float32)
+        ref = clib.ref()
+        n, kept, dead = len(b), [], np.zeros(len(b), bool)
+        for i in range(n):
+            if dead[i]:
+                continue
+            kept.append(i)
+            pi = b[i:i + 1].ctypes.data_as(C.c_void_p)
+            for jj in range(i + 1, n):
+                if not dead[jj] and ref.ref_iou_bev(pi, b[jj:jj + 1].ctypes.data_as(C.c_void_p)) > thresh:
+                    dead[jj] = True
+        keep[:len(kept)] = torch.tensor(kept, dtype=torch.int64)
+        return len(kept)
+    cu.nms_gpu = nms_gpu_ext
+    torch.Tensor.cuda = lambda self, *a, **k: self              # the reference moves `keep` to the GPU
+    _load("mmdet.core.post_processing.bbox_nms", "mmdet/core/post_processing/bbox_nms.py")
     return _load("mmdet.models.single_stage_heads_ssd_rotate_head",
                  "mmdet/models/single_stage_heads/ssd_rotate_head.py")
 
@@ -191,6 +210,16 @@ def main():
     msk3 = (torch.rand(1, 3 * 20 * 22 * 2, generator=g) > 0.3)
     g3, l3 = rpn3.get_guided_anchors(box3, cls3, dr3, anc3, msk3, None, None, thr=0.1)
     out.update(mc_box=box3, mc_cls=cls3, mc_dir=dr3, mc_anchors=anc3, mc_mask=msk3, mc_guided=g3[0], mc_labels=l3[0])
+    # PSWarpHead.get_rescore_bboxes (ssd_rotate_head.py:487-533): sigmoid, score threshold, BEV boxes, rotated NMS
+    ext0 = head.PSWarpHead(grid_offsets=(0., 40.), featmap_stride=.4, in_channels=8, num_class=1, num_parts=28)
+    rs_boxes = [tguided[0][:900].contiguous(), tguided[1][:700].contiguous(), tguided[0][:0]]
+    rs_logits = [torch.randn(900, generator=g) * 1.5, torch.randn(700, generator=g) * 1.5 - 6.0, torch.randn(0)]
+    rs_labels = [tlabels[0][:900], tlabels[1][:700], tlabels[0][:0]]
+    db, ds, dl = ext0.get_rescore_bboxes(rs_boxes, rs_logits, rs_labels, [None] * 3,
+                                         AttrDict(score_thr=0.3, nms=AttrDict(iou_thr=0.1)))
+    assert db[1] is None and db[2] is None and db[0] is not None       # sample 1: nothing passes 0.3; sample 2: empty
+    out.update(rs_boxes0=rs_boxes[0], rs_logits0=rs_logits[0], rs_labels0=rs_labels[0], rs_logits1=rs_logits[1],
+               rs_det_boxes=db[0], rs_det_scores=ds[0], rs_det_labels=dl[0])
 
     # ---- PSWarpHead.loss (rotated 3-D IoU assignment) -------------------------------------------------------------
     ext = head.PSWarpHead(grid_offsets=(0., 40.), featmap_stride=.4, in_channels=8, num_class=1, num_parts=28)

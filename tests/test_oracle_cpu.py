@@ -208,3 +208,19 @@ def test_guided_anchors_inference_vs_reference_method():
     got3 = onets.guided_anchors(t("mc_box"), t("mc_cls"), t("mc_dir"), t("mc_anchors"), t("mc_mask"), 3, 0.1)
     assert np.abs(got3[0][0].numpy() - G["mc_guided"]).max() < 1e-6
     assert np.array_equal(got3[0][1].numpy(), G["mc_labels"]) and set(np.unique(G["mc_labels"])) == {0, 1, 2}
+
+
+def test_rescore_vs_reference_method():
+    """oracle rescore (sigmoid, 0.3 score threshold, BEV boxes, rotated NMS at 0.1, gather) vs the reference's own
+    PSWarpHead.get_rescore_bboxes -> rotate_nms_torch -> iou3d_utils.nms_gpu Python, with the compiled nms step served
+    by a greedy pass over the reference's own iou_bev device function (tests/golden/make_golden_train.py)."""
+    import os
+    from oracle import nets as onets
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_fns.npz"))
+    t = lambda k: torch.from_numpy(G[k])                                  # noqa: E731
+    d = onets.rescore(t("rs_boxes0"), t("rs_logits0"), t("rs_labels0"), 0.3, 0.1)
+    assert d is not None and len(d[0]) == len(G["rs_det_boxes"]) > 10
+    assert np.abs(d[0] - G["rs_det_boxes"]).max() < 1e-6 and np.abs(d[1] - G["rs_det_scores"]).max() < 1e-6
+    assert np.array_equal(d[2], G["rs_det_labels"])
+    assert onets.rescore(t("rs_boxes0")[:700], t("rs_logits1"), t("rs_labels0")[:700], 0.3, 0.1) is None
+    assert onets.rescore(t("rs_boxes0")[:0], t("rs_logits0")[:0], t("rs_labels0")[:0], 0.3, 0.1) is None

@@ -224,3 +224,14 @@ def test_rescore_vs_reference_method():
     assert np.array_equal(d[2], G["rs_det_labels"])
     assert onets.rescore(t("rs_boxes0")[:700], t("rs_logits1"), t("rs_labels0")[:700], 0.3, 0.1) is None
     assert onets.rescore(t("rs_boxes0")[:0], t("rs_logits0")[:0], t("rs_labels0")[:0], 0.3, 0.1) is None
+
+
+def test_voxel_mean_vs_reference_simplevoxel():
+    """oracle voxel_mean vs the reference's own SimpleVoxel.forward (tests/golden/make_golden_voxel_mean.py): bit-exact
+    for max_points 3 / 5 / 8."""
+    import os
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    R = np.load(os.path.join(here, "voxel_mean_ref.npz"))
+    for case in ("small", "oob", "dense_t3", "t8"):
+        G = np.load(os.path.join(here, "voxelizer_%s.npz" % case))
+        assert np.array_equal(clib.voxel_mean(G["voxels"], G["num_points"]), R[case]), case

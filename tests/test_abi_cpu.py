@@ -1,0 +1,49 @@
+"""C-ABI error convention without a GPU (include/sassd.h: every entry point returns 0 or a negative code and validates
+its arguments BEFORE touching the device): NULL pointers / unsupported shapes -> SASSD_EINVAL (-1), undersized
+workspaces -> SASSD_ENOSPC (-2); workspace / packing queries are pure host arithmetic."""
+import ctypes as C
+
+import sassd  # noqa: F401
+from sassd import _C
+
+EINVAL, ENOSPC = -1, -2
+
+
+def test_argument_validation_returns_error_codes():
+    L = _C.lib()
+    null = None
+    assert L.sassd_voxelize(null, 10, 4, null, null, 5, 100, 0, null, null, 3, null, null, 4, null, null, 100, null,
+                            null, 0, null) == EINVAL
+    assert L.sassd_spconv_fwd(null, null, null, 0, null, 27, 16, 16, null, null, 0, null, null) == EINVAL
+    assert L.sassd_conv2d_fwd(null, null, null, null, 0, null, 1, 16, 16, 8, 8, 3, null) == EINVAL
+    assert L.sassd_conv2d_fwd(C.c_void_p(16), C.c_void_p(16), null, null, 0, C.c_void_p(16), 1, 16, 16, 8, 8, 5,
+                              null) == EINVAL                       # kernel size 5 does not exist on the path
+    assert L.sassd_conv2d_wino_fwd(C.c_void_p(16), C.c_void_p(16), null, null, 0, C.c_void_p(16), 1, 28, 28, 200, 176,
+                                   null) == EINVAL                  # channel counts the Winograd kernel rejects
+    assert L.sassd_conv2d_bwd_weight(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 1, 16, 16, 8, 8, 3, 0,
+                                     C.c_void_p(16), 4, null) == ENOSPC
+    assert L.sassd_three_nn(-1, 5, null, null, null, null, null) == EINVAL
+    assert L.sassd_three_nn_binned(4, 4, C.c_void_p(16), C.c_void_p(16), 0.0, 0.0, 1.6, 44, 50, 2, C.c_void_p(16),
+                                   C.c_void_p(16), C.c_void_p(16), 8, null) == ENOSPC
+    assert L.sassd_rotate_iou_eval(null, 3, null, 3, -1, null, null) == EINVAL
+    assert L.sassd_adam_step(null, null, null, null, 10, null, 1e-3, 0.9, 0.99, 1e-8, 0.01, 1, 10.0, 1.0,
+                             null) == EINVAL
+    assert L.sassd_adam_step(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 10, null, 1e-3, 0.9, 0.99,
+                             1e-8, 0.01, 0, 10.0, 1.0, null) == EINVAL      # step counts from 1
+    assert L.sassd_nms_gpu(null, 4, 0.1, null, null, null, 0, null) == EINVAL
+    # empty problems are not errors
+    assert L.sassd_three_nn(0, 0, null, null, C.c_void_p(16), C.c_void_p(16), null) == 0
+    assert L.sassd_rotate_iou_eval(null, 0, null, 0, -1, C.c_void_p(16), null) == 0
+
+
+def test_host_side_queries():
+    L = _C.lib()
+    assert L.sassd_conv2d_wino_supported(256, 256, 200, 176) == 1 and L.sassd_conv2d_wino_supported(320, 256, 200, 176) == 1
+    assert L.sassd_conv2d_wino_supported(256, 28, 200, 176) == 0 and L.sassd_conv2d_wino_supported(256, 256, 200, 44) == 0
+    assert L.sassd_conv2d_wino_packed_floats(256, 256) == 16 * 256 * 256
+    assert L.sassd_conv2d_wgrad_workspace_bytes(2, 256, 256, 200, 176, 3) % (9 * 256 * 256 * 4) == 0
+    assert L.sassd_conv2d_wgrad_workspace_bytes(2, 256, 256, 200, 176, 5) == 0
+    assert L.sassd_three_nn_binned_workspace_bytes(1000, 44, 50, 2) > 1000 * 20
+    assert L.sassd_three_nn_binned_workspace_bytes(1000, 4096, 4096, 2) == 0          # grid too large
+    assert L.sassd_spconv_bwd_weight_workspace_bytes(16111, 27, 64, 64) >= 126 * 27 * 64 * 64 * 4
+    assert L.sassd_hash_bytes(20000) >= 2 * 20000 * 8

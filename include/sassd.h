@@ -266,6 +266,26 @@ int sassd_pts_in_boxes3d(const float *pts, int n, const float *boxes3d, int m, i
 int sassd_rotate_iou_eval(const float *boxes, int n, const float *query_boxes, int k, int criterion, float *iou,
                           void *stream);
 
+/* (f-2) KITTI-evaluation matching statistics -- HOST function (no device memory, no stream): the greedy
+ * ground-truth <-> detection assignment is sequential per image and negligible next to the overlap matrices above.
+ * Replaces `compute_statistics_jit` (mmdet/core/evaluation/kitti_eval.py:165-283, numba CPU) and the loop over images x
+ * score thresholds `fused_compute_statistics` (:296-343) for ONE part of the image list (eval_class_v3 :598-648).
+ *   overlaps [sum dt, ld] f64 host, row-major: overlap of detection j with ground truth i; image p owns the block
+ *            rows [sum_{q<p} dt_nums[q], +dt_nums[p]) x columns [sum_{q<p} gt_nums[q], +gt_nums[p]);  ld >= sum gt
+ *   gt_datas [sum gt,5] (bbox x1 y1 x2 y2, alpha)   dt_datas [sum dt,6] (bbox, alpha, score)   dontcares [sum dc,4]
+ *   ignored_gts [sum gt] / ignored_dets [sum dt] int64: 0 counted, 1 neutral, -1 other class (clean_data :39-93)
+ *   metric 0 image bbox (detections inside DontCare boxes are not false positives), 1 BEV, 2 3-D
+ *   n_thr == 0: first pass (compute_fp=False, thresh 0): tp_scores[<= sum gt] receives the score of every matched
+ *               detection in image order, *n_tp_scores their count;  pr (optional, [4]) += (tp, 0, fn, 0)
+ *   n_thr  > 0: pr [n_thr,4] f64 += (tp, fp, fn, sum over true positives of (1+cos(alpha_gt-alpha_dt))/2 when
+ *               compute_aos) per threshold; detections scoring under thresholds[t] are left out
+ * Returns SASSD_EINVAL for negative counts, metric outside 0..2, ld < sum gt or a missing output array. */
+int sassd_kitti_eval_statistics(const double *overlaps, int64_t ld, int n_img, const int64_t *gt_nums,
+                                const int64_t *dt_nums, const int64_t *dc_nums, const double *gt_datas,
+                                const double *dt_datas, const double *dontcares, const int64_t *ignored_gts,
+                                const int64_t *ignored_dets, int metric, double min_overlap, const double *thresholds,
+                                int n_thr, int compute_aos, double *pr, double *tp_scores, int64_t *n_tp_scores);
+
 /* ---- training: parameter update ------------------------------------------------------------------------------------
  * Replaces tools/train_utils/__init__.py:57-61 (clip_grad_norm_ + optimizer.step) for optimizer type 'adam_onecycle'
  * (tools/train_utils/optimization/__init__.py:17-30, fastai_optim.py:132-148): decoupled weight decay on every

@@ -82,6 +82,8 @@ _SIGS = {
     "sassd_conv2d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "sassd_conv2d_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_rotate_iou_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "sassd_kitti_eval_statistics": (_I, [_P, C.c_int64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, C.c_double, _P, _I, _I, _P,
+                                         _P, _P]),
     "sassd_grad_sumsq": (_I, [_P, C.c_long, _P, _P]),
     "sassd_adam_step": (_I, [_P, _P, _P, _P, C.c_long, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P]),
     "sassd_mfma_probe": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),

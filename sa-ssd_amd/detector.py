@@ -26,6 +26,7 @@ from . import spconv
 from . import train_ops as T
 from .autograd import Conv2dFn, PSWarpFn
 from .config import _wrap, obj_from_dict
+from .kitti_common import kitti_bbox2results
 from .pipeline import InferencePlan
 from .pointnet2_utils import nearest_neighbor_interpolate
 
@@ -543,8 +544,10 @@ class SingleStageDetector(nn.Module):
         return losses
 
     def forward_test(self, img, img_meta, **kwargs):
-        """single_stage.py:110-131 on the fused pipeline.  Returns per-sample dicts
-        {boxes_lidar [k,7], scores [k], labels [k]} (numpy); KITTI camera-frame annos need calib files."""
+        """single_stage.py:110-131 on the fused pipeline.  A sample whose img_meta carries 'calib' (and 'img_shape')
+        comes back as the reference's KITTI result annotation (kitti_bbox2results, camera frame, ready for
+        sassd.kitti_eval.get_official_eval_result); without calibration the lidar-frame detections are returned as
+        {boxes_lidar [k,7], scores [k], labels [k]} (numpy)."""
         batch_size = len(img_meta)
         ret = self.merge_second_batch(kwargs)
         dev = ret['voxels'].device
@@ -553,8 +556,11 @@ class SingleStageDetector(nn.Module):
         vx = self.backbone(ret['voxels'], ret['num_points'])
         plan.run_from_voxels(vx, ret['coordinates'], ret['anchors_mask'])
         out = []
-        for boxes, scores, labels in plan.results():
-            out.append(dict(boxes_lidar=boxes, scores=scores, labels=labels))
+        for (boxes, scores, labels), meta in zip(plan.results(), img_meta):
+            if isinstance(meta, dict) and meta.get('calib') is not None:
+                out.append(kitti_bbox2results(boxes, scores, labels, meta, class_names=self.class_names))
+            else:
+                out.append(dict(boxes_lidar=boxes, scores=scores, labels=labels))
         return out
 
     def forward(self, img, img_meta, return_loss=True, **kwargs):

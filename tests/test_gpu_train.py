@@ -217,3 +217,64 @@ def test_training_step_waymo_scale(dev):
         assert bool(torch.isfinite(opt.flat.grad).all()) and float(opt.flat.grad.abs().sum()) > 0
     assert float((opt.flat.data - w0).abs().max()) > 0
     torch.cuda.synchronize()
+
+
+# ---- evaluation with the overlap matrices on the GPU (kept last in the last -m gpu file) --------------
+
+def test_kitti_eval_on_gpu(dev):
+    """get_official_eval_result with the rotated BEV / 3-D overlaps computed by sassd_rotate_iou_eval (HIP): the report
+    text equals the one the reference's own kitti_eval.py produced for the same annotations (tests/golden/
+    make_golden_kitti_eval.py; its device call was served by the CPU oracle).  Index-level work: the text is compared
+    exactly -- it could only differ if an overlap fell within fp32 rounding of a 0.7 / 0.5 / 0.25 cut-off."""
+    import os
+    import kitti_synth
+    from sassd import kitti_eval as ke
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_eval_ref.npz"))
+    gts, dts = kitti_synth.unpack(G, "gt_"), kitti_synth.unpack(G, "dt_")
+    for metric in (1, 2):
+        part = ke.calculate_iou_partly(dts, gts, metric, 50)[1][-1]
+        assert np.abs(part - G["ov%d_last_part" % metric]).max() < 1e-5
+    assert ke.get_official_eval_result(gts, dts, ["Car", "Pedestrian", "Cyclist"]) == str(G["official_text"])
+
+
+def test_forward_test_returns_kitti_annos(dev):
+    """With calibration in img_meta, model(return_loss=False) returns the reference's result annotations
+    (single_stage.py:129 -> kitti_bbox2results), which the evaluation accepts as `dt_annos`."""
+    import test_gpu_pipeline as P
+    from sassd import kitti_common as kc, kitti_eval as ke
+    from sassd.voxel_generator import VoxelGenerator
+    from oracle import nets as onets
+    model, c = P._model()
+    model = model.to(dev)
+    model.class_names = c.data.val.class_names
+    an, bv = P._anchors()
+    gen = VoxelGenerator(**{k: v for k, v in c.data.val.generator.items() if k != "type"})
+    calib = kc.Calibration(matrices={
+        "P2": [721.5377, 0, 609.5593, 44.85728, 0, 721.5377, 172.854, 0.2163791, 0, 0, 1, 0.002745884],
+        "R0_rect": [0.9999239, 0.00983776, -0.007445048, -0.009869795, 0.9999421, -0.004278459, 0.007402527,
+                    0.004351614, 0.9999631],
+        "Tr_velo_to_cam": [0.007533745, -0.9999714, -0.000616602, -0.004069766, 0.01480249, 0.0007280733, -0.9998902,
+                           -0.07631618, 0.9998621, 0.00752379, 0.01480755, -0.2717806]})
+    metas, kw = [], dict(voxels=[], coordinates=[], num_points=[], anchors=[], anchors_mask=[])
+    for i, p in enumerate([H.frame("small", 5), H.frame("k17", 1)]):
+        v, co, n = gen.generate(p)
+        m = onets.anchors_mask(co, bv, gen.voxel_size, gen.point_cloud_range, gen.grid_size, 1)
+        kw["voxels"].append(torch.from_numpy(v).to(dev)); kw["coordinates"].append(torch.from_numpy(co).to(dev))
+        kw["num_points"].append(torch.from_numpy(n).to(dev)); kw["anchors"].append(torch.from_numpy(an).to(dev))
+        kw["anchors_mask"].append(torch.from_numpy(m).to(dev))
+        metas.append(dict(sample_idx=i, img_shape=(375, 1242, 3), calib=calib))
+    raw = model(None, [dict(sample_idx=0), dict(sample_idx=1)], return_loss=False, **kw)
+    annos = model(None, metas, return_loss=False, **kw)
+    total = 0
+    for r, a in zip(raw, annos):
+        want = kc.kitti_bbox2results(None if r["boxes_lidar"] is None else r["boxes_lidar"].copy(), r["scores"],
+                                     r["labels"], metas[0], class_names=model.class_names)
+        assert sorted(a.keys()) == sorted(kc.empty_result_anno().keys()) or "image_idx" in a
+        assert len(a["name"]) == len(want["name"])
+        for k in ("bbox", "location", "dimensions", "rotation_y", "score", "alpha"):
+            assert np.allclose(a[k], want[k], atol=1e-4), k
+        total += len(a["name"])
+    assert total > 0, "test vector produced no detections inside the image"
+    # the annotations are valid evaluation input (scored against themselves as labels)
+    text = ke.get_official_eval_result([dict(a, occluded=np.zeros(len(a["name"]), int)) for a in annos], annos, "Car")
+    assert text.startswith("Car AP@0.70, 0.70, 0.70:")

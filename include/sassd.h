@@ -286,6 +286,53 @@ int sassd_kitti_eval_statistics(const double *overlaps, int64_t ld, int n_img, c
                                 const int64_t *ignored_dets, int metric, double min_overlap, const double *thresholds,
                                 int n_thr, int compute_aos, double *pr, double *tp_scores, int64_t *n_tp_scores);
 
+/* ------------------------------------------------------------------------------------------------
+ * (f-4) Training-side augmentation and offline data preparation.  The reference runs these as numba CPU loops inside
+ * DataLoader workers (mmdet/core/point_cloud/point_augmentor.py, mmdet/core/bbox3d/geometry.py, tools/create_data.py).
+ * Device entry points work in place on a point cloud that is already in HBM ([n, stride] f32 rows, xyz first).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* `points_in_convex_polygon_3d_jit(points, surfaces)` geometry.py:189-227, the core of `points_in_rbbox` (:63-74, called
+ * from kitti.py:222, create_data.py:43,221) and of `remove_outside_points` (:50-61, camera-frustum reduction).
+ *   planes [m,6,4] f64 device: (nx, ny, nz, d) of each polytope's 6 surfaces, as `surface_equ_3d_jit` (:176-186) gives
+ *   them -- the caller builds them from the box / frustum corners with the reference's own numpy arithmetic;
+ *   f32_math != 0: the plane values are float32 numbers (float32 boxes) and the sign is evaluated in float32, as the
+ *   reference's dtype rules make it;  mask [n,m] u8 device: 1 when no surface gives n.p + d >= 0. */
+int sassd_points_in_polytopes(const float *points, int n, int stride, const double *planes, int m, int f32_math,
+                              uint8_t *mask, void *stream);
+
+/* `points_transform_(points, centers, point_masks, loc_transform, rot_transform, valid_mask)` point_augmentor.py:44-62:
+ * every point inside a valid box is rotated about that box's centre and shifted with it (first such box wins).
+ *   mask [n,m] u8, valid [m] u8, centers [m,3] f32, rot_sin / rot_cos [m] f32 (float64 sine / cosine of the accepted yaw
+ *   noise rounded to float32, the entries of the reference's float32 rotation matrix), loc [m,3] f64 -- all device. */
+int sassd_points_transform(float *points, int n, int stride, const uint8_t *mask, int m, const uint8_t *valid,
+                           const float *centers, const float *rot_sin, const float *rot_cos, const double *loc,
+                           void *stream);
+
+/* `random_flip` + `global_rotation` + `global_scaling` on the points, one pass (point_augmentor.py:279-303):
+ * y -> -y if flip; [x y z] @ [[c,-s,0],[s,c,0],[0,0,1]]; xyz *= scale. */
+int sassd_points_global_transform(float *points, int n, int stride, int flip, float rot_sin, float rot_cos, float scale,
+                                  void *stream);
+
+/* The points of the sampled ground-truth objects (`PointAugmentor.sample_all` point_augmentor.py:232-242: np.fromfile
+ * per object, += box centre, -= road-plane correction) gathered from a database that is RESIDENT IN HBM.
+ *   db_points [P,4] f32;  src_start [n_obj] i64 first database row of object k;  out_start [n_obj+1] i64 prefix sums of
+ *   the objects' point counts (out_start[n_obj] == n_out);  shift [n_obj,3] f64;  lower [n_obj] f64 or NULL;
+ *   out [n_out,4] f32 -- all device. */
+int sassd_paste_objects(const float *db_points, const int64_t *src_start, const int64_t *out_start, int n_obj,
+                        int64_t n_out, const double *shift, const double *lower, float *out, void *stream);
+
+/* HOST functions (no device memory, no stream): the sequential O(boxes^2 x tries) decisions.
+ * `box_collision_test(boxes, qboxes)` geometry.py:593-672: boxes [n,4,2], qboxes [k,4,2] corner arrays (float64 when
+ * is_f64, else float32) -> out [n,k] u8; edge crossings and full containment both count (numba evaluates the
+ * reference's `ret[i, j] is False` as an equality test).
+ * `noise_per_box(boxes, valid_mask, loc_noises, rot_noises)` point_augmentor.py:73-105: boxes [n,5] f32 (x, y, w, l, yaw),
+ * valid [n] u8, loc_noises [n,num_try,3] f64, rot_noises [n,num_try] f64 -> success [n] i64: index of the first draw
+ * that keeps box i clear of all others (accepted draws move the box for the later tests), -1 if none / not valid. */
+int sassd_box_collision_test(const void *boxes, int n, const void *qboxes, int k, int is_f64, uint8_t *out);
+int sassd_noise_per_box(const float *boxes, const uint8_t *valid, const double *loc_noises, const double *rot_noises,
+                        int n, int num_try, int64_t *success);
+
 /* ---- training: parameter update ------------------------------------------------------------------------------------
  * Replaces tools/train_utils/__init__.py:57-61 (clip_grad_norm_ + optimizer.step) for optimizer type 'adam_onecycle'
  * (tools/train_utils/optimization/__init__.py:17-30, fastai_optim.py:132-148): decoupled weight decay on every

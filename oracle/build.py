@@ -1,6 +1,8 @@
 """Build recipe for the CPU oracle (TEST INFRASTRUCTURE, never imported by the product path).
 
   oracle/_build/liboracle.so   <- oracle/sassd_oracle.c         (our restatement, always buildable)
+  oracle/_build/libharness.so  <- oracle/harness/augment_harness.hip: the product's own __host__ __device__ per-point
+                                  functions (sa-ssd_amd/csrc/augment_core.h) looped on the CPU, hipcc --cuda-host-only
   oracle/_ref/libref_iou3d.so  <- /root/reference/mmdet/ops/iou3d/src/iou3d_kernel.cu lines 1-221
                                   (the reference's own __device__ functions compiled for the HOST;
                                   only when /root/reference exists; source is piped to g++, never copied)
@@ -116,7 +118,20 @@ def build_ref(force=False):
     return dst
 
 
+def build_harness(force=False):
+    """oracle/harness/augment_harness.hip: the product's __host__ __device__ per-point functions looped on the CPU."""
+    os.makedirs(BUILD, exist_ok=True)
+    src = os.path.join(HERE, "harness", "augment_harness.hip")
+    core = os.path.join(os.path.dirname(HERE), "sa-ssd_amd", "csrc", "augment_core.h")
+    dst = os.path.join(BUILD, "libharness.so")
+    if force or not _newer(dst, [src, core]):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "--cuda-host-only", "-O2", "-fno-fast-math",
+                               "-ffp-contract=on", "-shared", "-fPIC", "-o", dst, src])
+    return dst
+
+
 if __name__ == "__main__":
     print(build_oracle(True))
+    print(build_harness(True))
     print(build_ref(True))
     print(build_ref_interp(True))

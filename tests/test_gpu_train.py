@@ -278,3 +278,62 @@ def test_forward_test_returns_kitti_annos(dev):
     # the annotations are valid evaluation input (scored against themselves as labels)
     text = ke.get_official_eval_result([dict(a, occluded=np.zeros(len(a["name"]), int)) for a in annos], annos, "Car")
     assert text.startswith("Car AP@0.70, 0.70, 0.70:")
+
+
+# ---- augmentation kernels on the reference-generated vectors -----------------------------------------------
+
+def test_augmentation_kernels(dev, tmp_path):
+    """sassd_points_in_polytopes / sassd_points_transform / sassd_points_global_transform / sassd_paste_objects against
+    tests/golden/augment_ref.npz (made by the reference's own PointAugmentor / geometry code): masks bit-exact, points
+    within float32 rounding, three whole training frames with the reference's random seed."""
+    import os
+    import augment_synth as S
+    from sassd import geometry as G, kitti_common as kc, point_augmentor as PA
+    R = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment_ref.npz"))
+    unpack = lambda bits, n, m: np.unpackbits(bits)[:n * m].reshape(n, m).astype(bool)
+    pts = R["pts"]
+    for tag in ("32", "64"):
+        boxes = R["pib_boxes" + tag]
+        assert np.array_equal(G.points_in_rbbox(pts, boxes), unpack(R["pib_mask" + tag], len(pts), len(boxes))), tag
+    on_gpu = G.points_in_rbbox(torch.from_numpy(pts).to(dev), R["pib_boxes32"])
+    assert on_gpu.is_cuda and np.array_equal(on_gpu.cpu().numpy(), unpack(R["pib_mask32"], len(pts), 14))
+    many = np.tile(R["pib_boxes32"], (30, 1))                                  # 420 polytopes: two LDS passes
+    assert np.array_equal(G.points_in_rbbox(pts, many), np.tile(unpack(R["pib_mask32"], len(pts), 14), (1, 30)))
+    c = S.calib_matrices()
+    rect, trv2c, p2 = (S.extend(c[k]) for k in ("R0_rect", "Tr_velo_to_cam", "P2"))
+    full = R["fov_points"]
+    assert np.array_equal(G.remove_outside_points(full, rect, trv2c, p2, (375, 1242)),
+                          full[unpack(R["fov_mask"], len(full), 1)[:, 0]])
+
+    S.write_database(S.unpack_database(R), str(tmp_path))
+    calib = kc.Calibration(matrices=S.calib_matrices())
+    info = str(tmp_path / "kitti_dbinfos_train.pkl")
+    for cfg_name in ("car", "multi"):
+        cfg = S.AUGMENTOR_CONFIGS[cfg_name]
+        np.random.seed(1234)
+        aug = PA.PointAugmentor(root_path=str(tmp_path), info_path=info, device=dev, **cfg)       # fused recipe
+        np.random.seed(1234)
+        step = PA.PointAugmentor(root_path=str(tmp_path), info_path=info, device=dev, **cfg)      # method by method
+        state = np.random.get_state()
+        for f in range(3):
+            points, gt_boxes, gt_types = S.frame(f)
+            plane = S.PLANE if cfg_name == "multi" else None
+            tag = "aug_%s_%d_" % (cfg_name, f)
+            np.random.set_state(state)
+            s_boxes, s_types, s_points = step.sample_all(gt_boxes, gt_types, plane, calib)        # numpy convention
+            assert np.array_equal(s_boxes, R[tag + "s_boxes"]) and np.array_equal(s_points, R[tag + "s_points"])
+            boxes, p = R[tag + "pre_boxes"].copy(), R[tag + "pre_points"].copy()
+            step.noise_per_object_(boxes, p, num_try=100)
+            assert np.abs(p - R[tag + "noise_points"]).max() < 4e-6
+            boxes, p = step.random_flip(boxes, p)
+            boxes, p = step.global_rotation(boxes, p)
+            boxes, p = step.global_scaling(boxes, p)
+            assert np.abs(boxes - R[tag + "out_boxes"]).max() < 2e-5 and np.abs(p - R[tag + "out_points"]).max() < 2e-5
+            after = np.random.get_state()
+            np.random.set_state(state)
+            out_pts, out_boxes, out_types, _ = aug.augment_frame(torch.from_numpy(points).to(dev), gt_boxes.copy(), gt_types,
+                                                                 cfg["sample_classes"], plane, calib)
+            assert out_pts.is_cuda and "\n".join(out_types) == str(R[tag + "out_types"])
+            assert np.abs(out_boxes - R[tag + "out_boxes"]).max() < 2e-5
+            assert np.abs(out_pts.cpu().numpy() - R[tag + "out_points"]).max() < 2e-5
+            state = after

@@ -199,3 +199,99 @@ def kitti_bbox2results(boxes_lidar, scores, labels, meta, class_names=None):
                 truncated=np.zeros(k), occluded=np.zeros(k, dtype=np.int64), alpha=alphas[keep], bbox=box2d,
                 dimensions=cam[:, 3:6], location=cam[:, :3], rotation_y=cam[:, 6],
                 score=np.asarray(scores)[keep], image_idx=np.full(k, int(sample_id), dtype=np.int64))
+
+
+# ---- per-frame info records (tools/kitti_common.py:77-213,476-518; consumed by sassd.create_data) ----------------------
+
+def png_shape(path):
+    """(height, width) from a PNG file's IHDR chunk -- all the image the lidar path ever needs (the reference decodes the
+    whole picture with imageio / mmcv just to read its shape, kitti_common.py:152-153, kitti.py:140-142)."""
+    with open(path, "rb") as f:
+        head = f.read(24)
+    if len(head) < 24 or head[:8] != b"\x89PNG\r\n\x1a\n" or head[12:16] != b"IHDR":
+        raise ValueError("not a PNG file: %s" % path)
+    return int.from_bytes(head[20:24], "big"), int.from_bytes(head[16:20], "big")
+
+
+def get_kitti_info_path(idx, prefix, info_type='image_2', file_tail='.png', training=True, relative_path=True,
+                        exist_check=True):
+    rel = pathlib.Path('training' if training else 'testing') / info_type / (get_image_index_str(idx) + file_tail)
+    if exist_check and not (pathlib.Path(prefix) / rel).exists():
+        raise ValueError("file not exist: {}".format(rel))
+    return str(rel) if relative_path else str(pathlib.Path(prefix) / rel)
+
+
+def get_image_path(idx, prefix, training=True, relative_path=True, exist_check=True):
+    return get_kitti_info_path(idx, prefix, 'image_2', '.png', training, relative_path, exist_check)
+
+
+def get_label_path(idx, prefix, training=True, relative_path=True, exist_check=True):
+    return get_kitti_info_path(idx, prefix, 'label_2', '.txt', training, relative_path, exist_check)
+
+
+def get_velodyne_path(idx, prefix, training=True, relative_path=True, exist_check=True):
+    return get_kitti_info_path(idx, prefix, 'velodyne', '.bin', training, relative_path, exist_check)
+
+
+def get_calib_path(idx, prefix, training=True, relative_path=True, exist_check=True):
+    return get_kitti_info_path(idx, prefix, 'calib', '.txt', training, relative_path, exist_check)
+
+
+def add_difficulty_to_annos(info):
+    """annos['difficulty'] [n] int32: 0 easy / 1 moderate / 2 hard / -1 none, from image-box height, occlusion, truncation."""
+    annos = info['annos']
+    height = annos['bbox'][:, 3] - annos['bbox'][:, 1]
+    occ, trunc = np.asarray(annos['occluded']), np.asarray(annos['truncated'])
+    ok = [~((occ > o) | (height <= h) | (trunc > t)) for h, o, t in zip((40, 25, 25), (0, 1, 2), (0.15, 0.3, 0.5))]
+    diff = np.full(len(height), -1, dtype=np.int32)
+    diff[ok[2] ^ ok[1]] = 2
+    diff[ok[0] ^ ok[1]] = 1
+    diff[ok[0]] = 0
+    annos["difficulty"] = diff
+    return diff.tolist()
+
+
+def _calib_rows(path):
+    with open(path, 'r') as f:
+        lines = f.readlines()
+    return lambda i, n: np.array([float(v) for v in lines[i].split(' ')[1:n + 1]])
+
+
+def get_kitti_image_info(path, training=True, label_info=True, velodyne=False, calib=False, image_ids=7481,
+                         extend_matrix=True, num_worker=8, relative_path=True, with_imageshape=True):
+    """One dict per frame: image_idx, pointcloud_num_features, velodyne_path, img_path, img_shape, calib/P0..P3,
+    calib/R0_rect, calib/Tr_velo_to_cam, calib/Tr_imu_to_velo (4x4 when extend_matrix), annos (+ difficulty)."""
+    root = pathlib.Path(path)
+    if not isinstance(image_ids, list):
+        image_ids = list(range(image_ids))
+    infos = []
+    for idx in image_ids:
+        info = {'image_idx': idx, 'pointcloud_num_features': 4}
+        if velodyne:
+            info['velodyne_path'] = get_velodyne_path(idx, path, training, relative_path)
+        info['img_path'] = get_image_path(idx, path, training, relative_path)
+        if with_imageshape:
+            img = info['img_path']
+            info['img_shape'] = np.array(png_shape(str(root / img) if relative_path else img), dtype=np.int32)
+        annotations = None
+        if label_info:
+            label = get_label_path(idx, path, training, relative_path)
+            annotations = get_label_anno(str(root / label) if relative_path else label)
+        if calib:
+            row = _calib_rows(get_calib_path(idx, path, training, relative_path=False))
+            pad = lambda m: np.concatenate([m, np.array([[0., 0., 0., 1.]])], axis=0) if extend_matrix else m
+            for k in range(4):
+                info['calib/P%d' % k] = pad(row(k, 12).reshape([3, 4]))
+            r0 = row(4, 9).reshape([3, 3])
+            if extend_matrix:
+                r4 = np.zeros([4, 4], dtype=r0.dtype)
+                r4[3, 3], r4[:3, :3] = 1., r0
+                r0 = r4
+            info['calib/R0_rect'] = r0
+            info['calib/Tr_velo_to_cam'] = pad(row(5, 12).reshape([3, 4]))
+            info['calib/Tr_imu_to_velo'] = pad(row(6, 12).reshape([3, 4]))
+        if annotations is not None:
+            info['annos'] = annotations
+            add_difficulty_to_annos(info)
+        infos.append(info)
+    return infos

@@ -174,6 +174,8 @@ class PointAugmentor:
     def sample(self, gt_boxes, num, i):
         """`num` database objects of class i that collide neither with gt_boxes nor with each other (earlier wins)."""
         sampled = copy.deepcopy(self._samplers[i].sample(num))
+        if not sampled:                                          # (an empty class list makes the reference's np.stack fail)
+            return []
         num_gt = gt_boxes.shape[0]
         sp_boxes = np.stack([s["box3d_lidar"] for s in sampled], axis=0)
         boxes = np.concatenate([gt_boxes, sp_boxes], axis=0).copy()

@@ -158,3 +158,91 @@ def unpack_database(npz, names=("Car", "Pedestrian", "Cyclist")):
             at += k
         db[name] = infos
     return db
+
+
+# ---- a tiny raw KITTI tree (tools/create_data.py input layout) -----------------------------------------------------------
+
+CALIB_TXT = """P0: 7.215377e+02 0.000000e+00 6.095593e+02 0.000000e+00 0.000000e+00 7.215377e+02 1.728540e+02 0.000000e+00 0.000000e+00 0.000000e+00 1.000000e+00 0.000000e+00
+P1: 7.215377e+02 0.000000e+00 6.095593e+02 -3.875744e+02 0.000000e+00 7.215377e+02 1.728540e+02 0.000000e+00 0.000000e+00 0.000000e+00 1.000000e+00 0.000000e+00
+P2: 7.215377e+02 0.000000e+00 6.095593e+02 4.485728e+01 0.000000e+00 7.215377e+02 1.728540e+02 2.163791e-01 0.000000e+00 0.000000e+00 1.000000e+00 2.745884e-03
+P3: 7.215377e+02 0.000000e+00 6.095593e+02 -3.395242e+02 0.000000e+00 7.215377e+02 1.728540e+02 2.199936e+00 0.000000e+00 0.000000e+00 1.000000e+00 2.729905e-03
+R0_rect: 9.999239e-01 9.837760e-03 -7.445048e-03 -9.869795e-03 9.999421e-01 -4.278459e-03 7.402527e-03 4.351614e-03 9.999631e-01
+Tr_velo_to_cam: 7.533745e-03 -9.999714e-01 -6.166020e-04 -4.069766e-03 1.480249e-02 7.280733e-04 -9.998902e-01 -7.631618e-02 9.998621e-01 7.523790e-03 1.480755e-02 -2.717806e-01
+Tr_imu_to_velo: 9.999976e-01 7.553071e-04 -2.035826e-03 -8.086759e-01 -7.854027e-04 9.998898e-01 -1.482298e-02 3.195559e-01 2.024406e-03 1.482454e-02 9.998881e-01 -7.997231e-01
+"""
+TREE_SETS = {"train": [0, 1, 3], "val": [2, 5], "trainval": [0, 1, 3, 2, 5], "test": [0, 1]}
+TREE_IMG_HW = {0: (375, 1242), 1: (370, 1224), 2: (374, 1238), 3: (376, 1241), 5: (375, 1242)}
+
+
+def write_png(path, h, w):
+    """a valid all-black 8-bit grayscale PNG of the given size (the data path only ever reads its header)."""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xffffffff)
+    raw = b"".join(b"\x00" + b"\x00" * w for _ in range(h))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 1)) + chunk(b"IEND", b""))
+
+
+def _camera_objects(r, n):
+    """n labelled objects in the camera frame: (name, truncated, occluded, dims l h w, location, ry)."""
+    names = ["Car", "Car", "Pedestrian", "Cyclist", "Van", "Truck", "Car", "Person_sitting"]
+    out = []
+    for _ in range(n):
+        name = names[int(r.integers(0, len(names)))]
+        w, l, h = np.array(SIZES.get(name, SIZES["Pedestrian"])) * r.uniform(0.9, 1.1, 3)
+        out.append((name, float(r.choice([0.0, 0.0, 0.1, 0.4])), int(r.choice([0, 0, 1, 2, 3])), (l, h, w),
+                    np.array([r.uniform(-12, 12), r.uniform(1.5, 1.8), r.uniform(7, 48)]), r.uniform(-np.pi, np.pi)))
+    return out
+
+
+def write_kitti_tree(root):
+    """training/{image_2,label_2,calib,velodyne} for frames 0,1,2,3,5, testing/{image_2,calib,velodyne} for 0,1, ImageSets."""
+    c = calib_matrices()
+    rect4, v2c4, p2 = extend(c["R0_rect"]), extend(c["Tr_velo_to_cam"]), c["P2"].reshape(3, 4)
+    to_lidar = np.linalg.inv((rect4 @ v2c4).T)
+    os.makedirs(os.path.join(root, "ImageSets"), exist_ok=True)
+    for k, ids in TREE_SETS.items():
+        with open(os.path.join(root, "ImageSets", k + ".txt"), "w") as f:
+            f.write("\n".join("%06d" % i for i in ids) + "\n")
+    for split, ids in (("training", sorted(TREE_IMG_HW)), ("testing", TREE_SETS["test"])):
+        for sub in ("image_2", "calib", "velodyne") + (("label_2",) if split == "training" else ()):
+            os.makedirs(os.path.join(root, split, sub), exist_ok=True)
+        for idx in ids:
+            r = np.random.default_rng(700 + idx + (50 if split == "testing" else 0))
+            h, w = TREE_IMG_HW[idx]
+            write_png(os.path.join(root, split, "image_2", "%06d.png" % idx), h, w)
+            with open(os.path.join(root, split, "calib", "%06d.txt" % idx), "w") as f:
+                f.write(CALIB_TXT)
+            objs = _camera_objects(r, int(r.integers(5, 10)) if idx != 3 else 0)
+            lines, boxes = [], []
+            for name, trunc, occ, (l, hh, ww), loc, ry in objs:
+                lidar_c = (np.append(loc, 1.0) @ to_lidar)[:3]
+                box = np.array([lidar_c[0], lidar_c[1], lidar_c[2], ww, l, hh, ry])   # same yaw number as box_camera_to_lidar
+                boxes.append(box)
+                corners = np.array([[sx * l / 2, -sy * hh, sz * ww / 2] for sx in (-1, 1) for sy in (0, 1) for sz in (-1, 1)])
+                cs, sn = np.cos(ry), np.sin(ry)
+                cam = np.stack([cs * corners[:, 0] + sn * corners[:, 2], corners[:, 1],
+                                -sn * corners[:, 0] + cs * corners[:, 2]], 1) + loc
+                uvw = np.concatenate([cam, np.ones((8, 1))], 1) @ p2.T
+                uv = uvw[:, :2] / uvw[:, 2:3]
+                bb = [max(uv[:, 0].min(), 0), max(uv[:, 1].min(), 0), min(uv[:, 0].max(), w - 1), min(uv[:, 1].max(), h - 1)]
+                alpha = ry - np.arctan2(loc[0], loc[2])
+                lines.append("%s %.2f %d %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f" % (
+                    name, trunc, occ, alpha, bb[0], bb[1], bb[2], bb[3], hh, ww, l, loc[0], loc[1], loc[2], ry))
+            for _ in range(int(r.integers(0, 3))):
+                x1, y1 = r.uniform(0, 1000), r.uniform(100, 250)
+                lines.append("DontCare -1 -1 -10 %.2f %.2f %.2f %.2f -1 -1 -1 -1000 -1000 -1000 -10" % (
+                    x1, y1, x1 + r.uniform(40, 200), y1 + r.uniform(30, 90)))
+            if split == "training":
+                with open(os.path.join(root, split, "label_2", "%06d.txt" % idx), "w") as f:
+                    f.write("\n".join(lines) + ("\n" if lines else ""))
+            sweep = full_sweep(idx, n=3500)
+            parts = [sweep]
+            for b in boxes:                                   # the labelled objects return some points
+                parts.append(_cluster(r, b, int(r.integers(3, 50))).astype(np.float32))
+            np.concatenate(parts).astype(np.float32).tofile(os.path.join(root, split, "velodyne", "%06d.bin" % idx))

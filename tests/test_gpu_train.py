@@ -337,3 +337,52 @@ def test_augmentation_kernels(dev, tmp_path):
             assert np.abs(out_boxes - R[tag + "out_boxes"]).max() < 2e-5
             assert np.abs(out_pts.cpu().numpy() - R[tag + "out_points"]).max() < 2e-5
             state = after
+
+
+def test_disk_to_ap_end_to_end(dev, tmp_path):
+    """Raw KITTI tree on disk -> data preparation on the GPU (byte-identical to the reference's artefacts) -> KittiLiDAR
+    (augmentor with the database in HBM) -> collate -> one optimisation step; then the val split -> forward_test ->
+    KITTI result files -> get_official_eval_result.  Everything between the files and the report runs on the device."""
+    import os
+    import augment_synth as S
+    import test_create_data_cpu as TC
+    from sassd import create_data as CD, kitti_common as kc, kitti_eval as ke, train
+    from sassd.kitti_dataset import get_dataset
+    root = str(tmp_path)
+    TC.run_preparation(root, dev)
+    TC.check_tree(root, np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "create_data_ref.npz")))
+
+    c = Config.fromfile("configs/car_cfg.py")
+    tr = dict(c.data.train, root=root + '/training/', ann_file=root + '/ImageSets/train.txt')
+    tr['augmentor'] = dict(tr['augmentor'], root_path=root + '/', info_path=root + '/kitti_dbinfos_train.pkl',
+                           sample_classes=['Van'], min_num_points=[2], sample_max_num=[4])
+    np.random.seed(3)
+    ds = get_dataset(tr, device=dev)
+    assert ds.augmentor.database_on_device().is_cuda
+    model = H.randomize_detector(build_detector(c.model, c.train_cfg, c.test_cfg), 3, cls_bias=-3.0).to(dev)
+    opt = train.build_optimizer(model, c.optimizer, 1)
+    sched = train.build_scheduler(opt, 10, 1, c.optimizer, c.lr_config)
+    sync = train.GradSync(opt.flat)
+    w0 = opt.flat.data.clone()
+    samples = [ds[0], ds[1]]
+    assert all(s['points'].is_cuda and s['gt_bboxes'].is_cuda for s in samples)
+    batch = ds.collate(samples, model=model)
+    assert len(batch['voxels']) == 2 and batch['anchors_mask']['Car'][0].dtype == torch.bool
+    loss, terms = train.train_one_iter(model, opt, sched, sync, batch, 0)
+    assert np.isfinite(float(loss)) and len(terms) == 6 and float((opt.flat.data - w0).abs().max()) > 0
+
+    va = dict(c.data.val, root=root + '/training/', ann_file=root + '/ImageSets/val.txt')
+    dv = get_dataset(va, device=dev)
+    model.eval()
+    model.class_names = c.data.val.class_names
+    with torch.no_grad():
+        annos = [a for i in range(len(dv)) for a in model(**dv.collate([dv[i]]))]
+    assert len(annos) == 2 and all(a['bbox'].shape[1:] == (4,) for a in annos)
+    gt = kc.get_label_annos(dv.label_prefix, dv.sample_ids)
+    text = ke.get_official_eval_result(gt, annos, c.data.val.class_names)
+    assert text.startswith("Car AP@0.70, 0.70, 0.70:") and "3d   AP:" in text
+    found = [a for a in annos if len(a['name'])]
+    if found:                                                    # result files round-trip (random weights may detect nothing)
+        kc.write_label_annos(found, root + '/results')
+        back = kc.get_label_annos(root + '/results', [int(a['image_idx'][0]) for a in found])
+        assert [len(b['name']) for b in back] == [len(a['name']) for a in found]

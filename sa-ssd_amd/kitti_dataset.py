@@ -124,8 +124,8 @@ class KittiLiDAR:
         return out
 
     # ---- one frame -> device tensors -------------------------------------------------------------------------------------
-    def prepare_train_img(self, idx):
-        fr = self.load_frame(idx)
+    def prepare_train_img(self, idx, frame=None):
+        fr = self.load_frame(idx) if frame is None else frame
         dev = self._dev()
         points = torch.from_numpy(fr['points']).to(dev)
         gt_bboxes, gt_types = fr['gt_bboxes'], fr['gt_types']
@@ -146,8 +146,8 @@ class KittiLiDAR:
                     points=points, gt_bboxes=torch.from_numpy(np.ascontiguousarray(gt_bboxes, dtype=np.float32)).to(dev),
                     gt_labels=torch.from_numpy(gt_labels).to(dev), gt_types=gt_types)
 
-    def prepare_test_img(self, idx):
-        fr = self.load_frame(idx, with_label=self.with_label)
+    def prepare_test_img(self, idx, frame=None):
+        fr = self.load_frame(idx, with_label=self.with_label) if frame is None else frame
         dev = self._dev()
         out = dict(img=None, img_meta=dict(img_shape=fr['img_shape'], sample_idx=fr['sample_idx'], calib=fr['calib']),
                    points=torch.from_numpy(fr['points']).to(dev), gt_bboxes=None, gt_labels=None, gt_types=None)

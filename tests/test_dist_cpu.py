@@ -30,7 +30,13 @@ def _worker(rank, world, port, q):
     tmax = D.allreduce_max(1.0 + rank)             # rank 1 is "slower"
     total = D.allreduce_sum(len(mine))
     allres = D.gather_results([(i, "frame%d" % i) for i in mine])
-    q.put((rank, mine, tmax, total, allres))
+    import types
+    from sassd import loader as L
+    ds = types.SimpleNamespace(flag=np.ones(13, dtype=np.uint8), test_mode=False)
+    ld = L.build_dataloader(ds, 2, 1, dist=True)                   # rank / world come from the process group
+    assert (ld.sampler.rank, ld.sampler.num_replicas, ld.batch_size) == (rank, world, 2)
+    ld.sampler.set_epoch(3)
+    q.put((rank, mine, tmax, total, allres, list(ld.sampler)))
     D.barrier()
     torch.distributed.destroy_process_group()
 
@@ -54,6 +60,8 @@ def test_two_rank_frame_sharding_and_timing_reduction():
         assert o[3] == 11.0           # all frames accounted for
         gathered = sorted(x for part in o[4] for x in part)
         assert [g[0] for g in gathered] == list(range(11))
+    a, b = outs[0][5], outs[1][5]                                  # the training loader's per-rank epoch shares
+    assert len(a) == len(b) == 8 and set(a + b) == set(range(13))
 
 
 def _grad_sync_worker(rank, world, port, q):

@@ -36,7 +36,11 @@ def _worker(rank, world, port, q):
     ld = L.build_dataloader(ds, 2, 1, dist=True)                   # rank / world come from the process group
     assert (ld.sampler.rank, ld.sampler.num_replicas, ld.batch_size) == (rank, world, 2)
     ld.sampler.set_epoch(3)
-    q.put((rank, mine, tmax, total, allres, list(ld.sampler)))
+    import test_runner_cpu as TR
+    from sassd import runner
+    annos = runner.single_test(TR._Model(), TR._DS(5))             # this rank's frames + the other rank's, dataset order
+    order = [int(a['image_idx'][0]) if len(a['name']) else -1 for a in annos]
+    q.put((rank, mine, tmax, total, allres, list(ld.sampler), order))
     D.barrier()
     torch.distributed.destroy_process_group()
 
@@ -62,6 +66,7 @@ def test_two_rank_frame_sharding_and_timing_reduction():
         assert [g[0] for g in gathered] == list(range(11))
     a, b = outs[0][5], outs[1][5]                                  # the training loader's per-rank epoch shares
     assert len(a) == len(b) == 8 and set(a + b) == set(range(13))
+    assert outs[0][6] == outs[1][6] == [0, 1, -1, 3, 4]            # single_test: every rank holds the merged result list
 
 
 def _grad_sync_worker(rank, world, port, q):

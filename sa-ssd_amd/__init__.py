@@ -13,6 +13,13 @@ Layout:
   config.py        mmcv-free Config.fromfile / obj_from_dict
   pipeline.py      device-resident whole-frame inference plan (raw points -> detections, no host syncs inside)
   synth.py         synthetic KITTI-range / Waymo-scale clouds (measurement contract)
+  autograd.py, train_ops.py, train.py, pointnet2_utils.py   the training step
+  kitti_common.py  label / result / calibration formats, kitti_bbox2results, per-frame info records (tools/kitti_common.py)
+  kitti_eval.py, eval_ops.py   KITTI AP evaluation: GPU overlap matrices + native host matching (core/evaluation)
+  geometry.py      box geometry: numpy for boxes, HIP for points, native host collision test (core/bbox3d/geometry.py)
+  point_augmentor.py  GT sampling / per-object noise / global transforms, database resident in HBM (core/point_cloud)
+  create_data.py   infos / velodyne_reduced / gt_database preparation in the reference's formats (tools/create_data.py)
+  kitti_dataset.py, loader.py, runner.py   KittiLiDAR + get_dataset, samplers + prefetching loader, epoch / test loops
 """
 from . import synth  # noqa: F401
 

@@ -173,6 +173,26 @@ def load_checkpoint(model, optimizer, filename, map_location="cpu"):
     return ck.get("epoch", 0), ck.get("it", 0)
 
 
+def load_params_from_file(model, filename, to_cpu=False):
+    """tools/train_utils/__init__.py:152-173: copy every tensor of the checkpoint's 'model_state' whose name and shape match
+    into the model (in place, so FlatParams views stay valid).  Checkpoints written by the reference's (MM)DataParallel
+    wrappers carry a 'module.' prefix on every key; it is accepted with or without.  -> (loaded, skipped) key lists."""
+    import os
+    if not os.path.isfile(filename):
+        raise FileNotFoundError(filename)
+    ck = torch.load(filename, map_location=torch.device('cpu') if to_cpu or not torch.cuda.is_available() else None,
+                    weights_only=False)
+    sd, loaded, skipped = model.state_dict(), [], []
+    for key, val in ck['model_state'].items():
+        k = key[len('module.'):] if key.startswith('module.') and key not in sd else key
+        if k in sd and sd[k].shape == val.shape:
+            sd[k].copy_(val)
+            loaded.append(k)
+        else:
+            skipped.append(key)
+    return loaded, skipped
+
+
 def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, voxel_size, pc_range,
                  max_points=5, max_voxels=20000, area_threshold=1, model=None):
     """What KittiLiDAR.prepare_train_img + collate produce (kitti.py:212-262,333-343), built on the device from raw

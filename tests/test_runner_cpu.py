@@ -110,3 +110,21 @@ def test_single_test_order_and_files(tmp_path):
     back = kc.get_label_annos(str(tmp_path / "res"), [3])[0]
     assert back["name"][0] == "Car" and abs(back["location"][0, 2] - 13.0) < 1e-4 and abs(back["score"][0] - 0.5) < 1e-4
     assert model.class_names == ['Car'] and not model.training
+
+
+def test_load_params_from_file(tmp_path):
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    flat = T.FlatParams(m)
+    ref = {k: torch.randn_like(v.float()).to(v.dtype) for k, v in m.state_dict().items()}
+    state = {'module.' + k: v for k, v in ref.items()}
+    state['module.0.bias'] = torch.zeros(5)                       # wrong shape -> skipped
+    state['module.extra'] = torch.zeros(1)                        # unknown -> skipped
+    torch.save(dict(epoch=3, it=9, model_state=state, optimizer_state=None, version='none'), str(tmp_path / "c.pth"))
+    before = m[0].bias.detach().clone()
+    loaded, skipped = T.load_params_from_file(m, str(tmp_path / "c.pth"), to_cpu=True)
+    assert sorted(skipped) == ['module.0.bias', 'module.extra'] and '0.weight' in loaded and '1.running_var' in loaded
+    assert torch.equal(m[0].weight, ref['0.weight']) and torch.equal(m[0].bias, before)
+    assert m[0].weight.data_ptr() == flat.data.data_ptr() + 4 * flat.offsets[0]      # still a view of the flat buffer
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        T.load_params_from_file(m, str(tmp_path / "missing.pth"))

@@ -486,7 +486,8 @@ class SingleStageDetector(nn.Module):
                          grid_offsets=extra_head['grid_offsets'] if extra_head else (0., 40.),
                          featmap_stride=extra_head['featmap_stride'] if extra_head else .4)
         if isinstance(pretrained, str):
-            self.load_state_dict(torch.load(pretrained, map_location='cpu').get('model_state', {}), strict=False)
+            from .train import load_params_from_file      # accepts the reference's 'module.'-prefixed checkpoints
+            load_params_from_file(self, pretrained, to_cpu=True)
 
     @property
     def with_rpn(self):

@@ -37,6 +37,36 @@ class AnchorGeneratorStride:
                                         self._rotations, self._dtype)
 
 
+def create_anchors_3d_range(feature_size, anchor_range, sizes=(1.6, 3.9, 1.56), rotations=(0, np.pi / 2),
+                            dtype=np.float32):
+    """feature_size [D,H,W], anchor_range (x0, y0, z0, x1, y1, z1): centres on np.linspace between the range ends
+    -> anchors [D,H,W,num_sizes,num_rots,7] (anchor3d_generator.py:44-79; unused by the shipped configs)."""
+    d, h, w = [int(v) for v in feature_size]
+    rg = np.array(anchor_range, dtype)
+    xs, ys, zs = (np.linspace(rg[a], rg[a + 3], n, dtype=dtype) for a, n in ((0, w), (1, h), (2, d)))
+    sz = np.asarray(sizes, dtype=dtype).reshape(-1, 3)
+    rot = np.asarray(rotations, dtype=dtype)
+    out = np.empty((d, h, w, sz.shape[0], rot.shape[0], 7), dtype=dtype)
+    out[..., 0] = xs[None, None, :, None, None]
+    out[..., 1] = ys[None, :, None, None, None]
+    out[..., 2] = zs[:, None, None, None, None]
+    out[..., 3:6] = sz[None, None, None, :, None, :]
+    out[..., 6] = rot[None, None, None, None, :]
+    return out
+
+
+class AnchorGeneratorRange:
+    def __init__(self, anchor_ranges, sizes=(1.6, 3.9, 1.56), rotations=(0, np.pi / 2), dtype=np.float32):
+        self._anchor_ranges, self._sizes, self._rotations, self._dtype = anchor_ranges, sizes, rotations, dtype
+
+    @property
+    def num_anchors_per_localization(self):
+        return len(self._rotations) * np.array(self._sizes).reshape([-1, 3]).shape[0]
+
+    def __call__(self, feature_map_size):
+        return create_anchors_3d_range(feature_map_size, self._anchor_ranges, self._sizes, self._rotations, self._dtype)
+
+
 def limit_period(val, offset=0.5, period=np.pi):
     return val - np.floor(val / period + offset) * period
 

@@ -12,8 +12,8 @@ def test_range_anchors():
                                rotations=[0, 1.57])
     an = g([1, 200, 176])
     assert an.shape == (1, 200, 176, 2, 2, 7) and an.dtype == np.float32 and g.num_anchors_per_localization == 4
-    assert np.array_equal(an[0, 0, :, 0, 0, 0], np.linspace(0, 70.4, 176, dtype=np.float32))
-    assert np.array_equal(an[0, :, 0, 0, 0, 1], np.linspace(-40.0, 40.0, 200, dtype=np.float32))
+    assert np.array_equal(an[0, 0, :, 0, 0, 0], np.linspace(np.float32(0), np.float32(70.4), 176, dtype=np.float32))
+    assert np.array_equal(an[0, :, 0, 0, 0, 1], np.linspace(np.float32(-40.0), np.float32(40.0), 200, dtype=np.float32))
     assert np.all(an[..., 2] == np.float32(-1.78))
     assert np.array_equal(an[0, 5, 7, 1, :, 3:6], np.float32([[0.6, 0.8, 1.73]] * 2))
     assert np.array_equal(an[0, 5, 7, 0, :, 6], np.float32([0, 1.57]))

@@ -13,9 +13,7 @@
 
     python tests/golden/make_golden_augment.py
 """
-import importlib.util
 import os
-import pickle
 import sys
 import tempfile
 import types

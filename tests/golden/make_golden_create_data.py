@@ -12,7 +12,6 @@ import os
 import pickle
 import sys
 import tempfile
-import types
 
 import numpy as np
 

@@ -10,7 +10,6 @@ import torch
 import sassd  # noqa: F401
 from sassd import loader as L
 
-import augment_synth as S
 import harness
 import test_create_data_cpu as TC
 

@@ -135,8 +135,8 @@ class _HipConv2d(nn.Conv2d):
     """nn.Conv2d parameters, HIP fp32-MFMA forward (sassd_conv2d_fwd) with an optional fused affine + ReLU."""
 
     def packed_weight(self):
-        v = self.weight._version
-        if getattr(self, "_pk", None) is None or self._pkv != v or self._pk.device != self.weight.device:
+        v = K.weight_key(self.weight)
+        if getattr(self, "_pk", None) is None or self._pkv != v:
             self._pk, self._pkv = K.conv2d_pack_weight(self.weight.detach().float().contiguous()), v
         return self._pk
 
@@ -144,8 +144,8 @@ class _HipConv2d(nn.Conv2d):
         """Winograd-packed weights when this layer / feature-map shape supports the F(2x2,3x3) kernel, else None."""
         if self.kernel_size[0] != 3 or not K.conv2d_wino_supported(self.in_channels, self.out_channels, h, w):
             return None
-        v = self.weight._version
-        if getattr(self, "_pkw", None) is None or self._pkwv != v or self._pkw.device != self.weight.device:
+        v = K.weight_key(self.weight)
+        if getattr(self, "_pkw", None) is None or self._pkwv != v:
             self._pkw, self._pkwv = K.conv2d_wino_pack_weight(self.weight.detach().float().contiguous()), v
         return self._pkw
 
@@ -489,6 +489,11 @@ class SingleStageDetector(nn.Module):
             from .train import load_params_from_file      # accepts the reference's 'module.'-prefixed checkpoints
             load_params_from_file(self, pretrained, to_cpu=True)
 
+    def train(self, mode=True):
+        if mode:
+            self._plan, self._plan_key = None, None      # weights are about to change: the folded plan is stale
+        return super().train(mode)
+
     @property
     def with_rpn(self):
         return hasattr(self, 'rpn_head') and self.rpn_head is not None
@@ -512,10 +517,17 @@ class SingleStageDetector(nn.Module):
 
     def plan(self, batch_size, anchors, device, **kw):
         """Build (and cache) the fused inference plan for this batch size / anchor set."""
-        key = (batch_size, anchors.data_ptr() if torch.is_tensor(anchors) else id(anchors), str(device))
-        if self._plan is None or self._plan_key != key:
+        # keyed on the weights (autograd versions + the raw-write generation of sassd.kernels) and on the anchor
+        # CONTENT: merge_second_batch stacks a fresh anchor tensor per call, so its address says nothing
+        key = (batch_size, str(device), K.weights_generation(),
+               sum(t._version for t in list(self.parameters()) + list(self.buffers())))
+        an_t = anchors if torch.is_tensor(anchors) else torch.as_tensor(np.asarray(anchors))
+        same = (self._plan is not None and self._plan_key == key and
+                self._plan.anchors.shape == an_t.reshape(-1, 7).shape and
+                torch.equal(self._plan.anchors, an_t.reshape(-1, 7).to(self._plan.anchors)))
+        if not same:
             tc = self.test_cfg.get('extra', self.test_cfg) if self.test_cfg else {}
-            an = anchors.detach().cpu().numpy() if torch.is_tensor(anchors) else np.asarray(anchors)
+            an = an_t.detach().cpu().numpy()
             self._plan = InferencePlan(self.state_dict(), batch_size=batch_size, anchors=an.reshape(-1, 7),
                                        score_thr=tc.get('score_thr', 0.3),
                                        iou_thr=tc.get('nms', {}).get('iou_thr', 0.1), device=device, **self._cfg, **kw)

@@ -8,6 +8,23 @@ from . import _C
 
 _ws_cache = {}
 
+# Packed-weight caches (SparseConvolution.packed_weight, _HipConv2d.packed_*, SingleStageDetector.plan) are keyed on
+# the parameter's autograd version AND on this generation: the fused optimizer and the checkpoint loaders write the
+# flat parameter buffer through raw pointers / views, which never bumps `Tensor._version`.
+_weights_gen = [0]
+
+
+def weights_generation():
+    return _weights_gen[0]
+
+
+def bump_weights_generation():
+    _weights_gen[0] += 1
+
+
+def weight_key(w):
+    return (w._version, w.data_ptr(), str(w.device), _weights_gen[0])
+
 
 def workspace(name, nbytes, device):
     """Grow-only cached scratch buffer (uint8) per (name, device)."""

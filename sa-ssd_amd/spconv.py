@@ -80,8 +80,8 @@ class SparseConvolution(nn.Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def packed_weight(self):
-        v = self.weight._version
-        if self._packed is None or self._packed_version != v or self._packed.device != self.weight.device:
+        v = K.weight_key(self.weight)
+        if self._packed is None or self._packed_version != v:
             k = int(np.prod(self.kernel_size))
             w = self.weight.detach().reshape(k, self.in_channels, self.out_channels).contiguous().float()
             self._packed = K.spconv_pack_weight(w)

@@ -71,6 +71,18 @@ class OneCycle:
         self.optimizer.lr, self.optimizer.mom = self.values(step)
 
 
+class CosineWarmupLR:
+    """tools/train_utils/optimization/learning_schedules_fastai.py:78-87: lr = eta_min + (base_lr - eta_min) *
+    (1 - cos(pi * it / T_max)) / 2 for the first T_max iterations (the runner switches to the main schedule after)."""
+
+    def __init__(self, optimizer, T_max, eta_min=0.0):
+        self.optimizer, self.T_max, self.eta_min = optimizer, int(T_max), float(eta_min)
+        self.base_lr = optimizer.lr
+
+    def step(self, step):
+        self.optimizer.lr = self.eta_min + (self.base_lr - self.eta_min) * (1 - math.cos(math.pi * step / self.T_max)) / 2
+
+
 class AdamOneCycle:
     def __init__(self, model, lr, weight_decay, beta2=0.99, eps=1e-8, grad_clip=None, world_size=1):
         self.flat = model if isinstance(model, FlatParams) else FlatParams(model)
@@ -92,6 +104,7 @@ class AdamOneCycle:
         sumsq = K.grad_sumsq(self.flat.grad, self.sumsq) if self.max_norm > 0 else None
         K.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, sumsq, self.lr, self.mom,
                     self.beta2, self.eps, self.wd, self.steps, self.max_norm, 1.0 / self.world_size)
+        K.bump_weights_generation()          # raw-pointer update: parameter `_version`s did not move
 
     def state_dict(self):
         return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), steps=self.steps, lr=self.lr,
@@ -101,6 +114,7 @@ class AdamOneCycle:
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.steps, self.lr, self.mom = sd["steps"], sd["lr"], sd["mom"]
+        K.bump_weights_generation()
 
 
 def build_optimizer(model, optim_cfg, world_size=1):
@@ -115,6 +129,13 @@ def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, optim_cfg, 
         raise NotImplementedError("the SA-SSD configs use the 'onecycle' policy")
     return OneCycle(optimizer, total_iters_each_epoch * total_epochs, optim_cfg["lr"], list(lr_cfg["moms"]),
                     lr_cfg["div_factor"], lr_cfg["pct_start"])
+
+
+def build_warmup_scheduler(optimizer, optim_cfg, lr_cfg):
+    """optimization/__init__.py:57-62: a CosineWarmupLR when the lr config carries 'warmup', else None."""
+    if "warmup" not in lr_cfg:
+        return None
+    return CosineWarmupLR(optimizer, T_max=lr_cfg["warmup_iters"], eta_min=optim_cfg["lr"] * lr_cfg["warmup_ratio"])
 
 
 class GradSync:
@@ -155,7 +176,7 @@ def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None):
 
 
 def checkpoint_state(model, optimizer, epoch, it):
-    return dict(epoch=epoch, it=it, model_state={k: v.detach().cpu() for k, v in model.state_dict().items()},
+    return dict(epoch=epoch, it=it, version="sassd", model_state={k: v.detach().cpu() for k, v in model.state_dict().items()},
                 optimizer_state={k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()})
 
 
@@ -163,13 +184,38 @@ def save_checkpoint(state, filename):
     torch.save(state, filename if filename.endswith(".pth") else filename + ".pth")
 
 
+def _copy_model_state(model, model_state):
+    """In-place copy (parameters stay views of the flat buffer) of every tensor whose name -- with or without the
+    (MM)DataParallel 'module.' prefix of the reference's checkpoints -- and shape match.  -> (loaded, skipped)."""
+    sd, loaded, skipped = model.state_dict(), [], []
+    with torch.no_grad():
+        for key, val in model_state.items():
+            k = key[len('module.'):] if key.startswith('module.') and key not in sd else key
+            if k in sd and sd[k].shape == val.shape:
+                sd[k].copy_(val)
+                loaded.append(k)
+            else:
+                skipped.append(key)
+    K.bump_weights_generation()
+    return loaded, skipped
+
+
 def load_checkpoint(model, optimizer, filename, map_location="cpu"):
-    ck = torch.load(filename, map_location=map_location)
-    sd = model.state_dict()
-    for k, v in ck["model_state"].items():                  # copy in place: parameters are views of the flat buffer
-        sd[k].copy_(v)
-    if optimizer is not None and ck.get("optimizer_state"):
-        optimizer.load_state_dict(ck["optimizer_state"])
+    """tools/train_utils/__init__.py:120-150 (resume): model + optimizer state.  A reference checkpoint carries a torch
+    Adam / OptimWrapper state dict, which has no meaning for the flat fused optimizer: it is skipped with a warning."""
+    import warnings
+    ck = torch.load(filename, map_location=map_location, weights_only=False)
+    _, skipped = _copy_model_state(model, ck["model_state"])
+    if skipped:
+        warnings.warn("load_checkpoint: %d tensors of %s do not match the model: %s" % (len(skipped), filename,
+                                                                                        skipped[:4]))
+    ost = ck.get("optimizer_state")
+    if optimizer is not None and ost:
+        if isinstance(ost, dict) and "exp_avg" in ost and "exp_avg_sq" in ost:
+            optimizer.load_state_dict(ost)
+        else:
+            warnings.warn("load_checkpoint: optimizer state of %s is not in the flat exp_avg / exp_avg_sq format "
+                          "(a reference torch optimizer state?) -- optimizer starts fresh" % filename)
     return ck.get("epoch", 0), ck.get("it", 0)
 
 
@@ -182,15 +228,7 @@ def load_params_from_file(model, filename, to_cpu=False):
         raise FileNotFoundError(filename)
     ck = torch.load(filename, map_location=torch.device('cpu') if to_cpu or not torch.cuda.is_available() else None,
                     weights_only=False)
-    sd, loaded, skipped = model.state_dict(), [], []
-    for key, val in ck['model_state'].items():
-        k = key[len('module.'):] if key.startswith('module.') and key not in sd else key
-        if k in sd and sd[k].shape == val.shape:
-            sd[k].copy_(val)
-            loaded.append(k)
-        else:
-            skipped.append(key)
-    return loaded, skipped
+    return _copy_model_state(model, ck['model_state'])
 
 
 def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, voxel_size, pc_range,

@@ -1,24 +1,33 @@
 #!/usr/bin/env python
 """bench.py -- SA-SSD hot path throughput on MI355X (BASELINE.json metric: KITTI-Car inference frames/s).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, 1 rank / GPU)
+  python bench.py --gpus N --steps K --warmup W      N > 1 without a torchrun environment: bench.py re-executes itself
+                                                     under torch.distributed.run with N ranks (one per GPU, RCCL)
 
-A "step" = one whole pass of the hot path over one synthetic KITTI-range frame (configs[1]: car_cfg inference,
-batch 1, fp32): raw points resident in HBM -> voxelize -> 7 rulebooks -> 14 sparse convs -> densify -> BEVNet
--> heads -> anchors mask -> decode/filter -> PSWarp -> rescore + rotated NMS -> detections in HBM.  Frames shard
+A "step" = one whole pass of the hot path over one batch of synthetic frames, raw points resident in HBM ->
+voxelize -> 7 rulebooks -> 14 sparse convs -> densify -> BEVNet -> heads -> anchors mask -> decode/filter -> PSWarp
+-> rescore + rotated NMS -> detections in HBM.  The whole frame is ONE hipGraph launch (sassd_graph_*).  Frames shard
 across ranks with no data-path collective (weak scaling); value = frames of all ranks / max-over-ranks time.
-By default three frames are in flight per GPU (--inflight): independent plans on separate HIP streams, so that one
-frame's latency-bound sparse / post stages overlap another frame's MFMA-bound BEV stage (each frame is still a
-batch-1 pass; --inflight 1 gives the strictly sequential number, also reported as per-stage `stage_ms`).
+
+  --config car    BASELINE configs[1] (HEADLINE, default): car_cfg inference, batch 1, fp32, K21 frames
+  --config multi  configs[3]: multi_cfg (Car+Ped+Cyclist) inference, batch 8
+  --config waymo  configs[4] shape, inference side: 180k-point frames, 0.1 m voxels, batch 4 per GPU
+  --mode train    configs[2] shape: car_cfg training step, batch 2 per GPU, DDP (extra measurement)
+
+By default three frames are in flight per GPU (--inflight): independent plans / graphs on separate HIP streams, so one
+frame's latency-bound sparse / post stages overlap another frame's MFMA-bound BEV stage; each frame is still a batch-1
+pass.  `fps_sequential` (one graph after the other on one stream, no host sync) and `latency_ms_sync_per_frame` (host
+sync + result read-back per frame) are printed next to it.
 
 The JSON line also carries:
-  roofline      dominant kernel (BEV 3x3 conv, Winograd on the fp32 MFMA): algorithmic FLOPs per launch / mean launch
-                duration measured live with HIP events on the launch stream, one frame at a time (pass right after the
-                timed region), vs the 157.3 TF fp32-MFMA peak; `timed_region` = the same launches while three frames
-                share the GPU.
-  roofline_sparse  the sparse path (7 rulebooks + 14 sparse convs) against the HBM roofline, from B_gs bytes.
-  cpu_baseline  the CPU oracle (a faithful port: C voxelizer/NMS + torch-CPU sparse/dense convs) timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline         dominant kernel (BEV 3x3 conv, Winograd F(2x2,3x3) on the fp32 MFMA): `achieved` / `frac` = the
+                   flops the kernel EXECUTES on the MFMA pipe (16/36 of the direct convolution) over the mean launch
+                   duration (HIP events on the launch stream, one frame at a time) vs the 157.3 TF fp32-MFMA peak;
+                   `effective` = the direct-convolution flops of SURVEY 8(d) over the same time.
+  roofline_sparse  7 rulebooks + 14 sparse convs against the HBM roofline (B_gs bytes of SURVEY 8d), timed as a
+                   hipGraph of exactly that segment.
+  cpu_baseline     the CPU oracle (a faithful port: C voxelizer / NMS + torch-CPU sparse and dense convs) on this box's
+                   host cores, 3 warm-ups + >= 20 timed frames, median + per-stage ms (rank 0, N = 1, car only).
 """
 import argparse
 import json
@@ -31,12 +40,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import sassd  # noqa: E402
-from sassd import synth, anchors as A  # noqa: E402
-from sassd.config import Config  # noqa: E402
-from sassd.detector import build_detector  # noqa: E402
+from sassd import synth  # noqa: E402
 from sassd.pipeline import InferencePlan  # noqa: E402
 
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -45,84 +51,95 @@ MEASURED_HBM_GBS = 6290.0
 PUBLISHED_FPS = 25.0              # /root/reference/readme.md:2 "can run at 25 FPS" 
 
 
-def build_model(seed=0, dev=None):
-    """Seeded random-init SA-SSD (car_cfg) + anchors.  With `dev`, the classification head is rescaled ON THE DEVICE
-    PATH (one pipeline run on a calibration frame) so that a few hundred anchors pass the 0.1 guided-anchor threshold
-     instead of tens of thousands with raw random weights; without `dev` (CPU-only callers: smoke /
-    tests) the same rescaling is done with the CPU oracle."""
-    import helpers as H           # tests/helpers.py: seeded weights, randomised BN stats
-    cfg = Config.fromfile(os.path.join(ROOT, "configs", "car_cfg.py"))
-    model = H.randomize_detector(build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg).eval(), seed)
-    an = A.AnchorGeneratorStride(sizes=[1.6, 3.9, 1.56], anchor_strides=[.4, .4, 1.], anchor_offsets=[.2, -39.8, -1.78],
-                                 rotations=[0, 1.57])([1, 200, 176]).reshape(-1, 7)
-    bv = A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]]).astype(np.float32)
-    cal = dict(voxel_size=synth.KITTI_VOXEL, pc_range=synth.KITTI_RANGE, max_points=5, max_voxels=20000,
-               sparse_shape=(40, 1600, 1408), grid_xyz=(1408, 1600, 40))
-    if dev is None:
-        H.calibrate_cls_head(model, synth.lidar64(11)[:3000], bv, cal, target_count=100)
-        return model, an, bv, cal
-    plan = InferencePlan(model.state_dict(), batch_size=1, anchors=an, anchors_bv=bv, device=dev)
-    plan.run_from_points([torch.from_numpy(synth.lidar64(11)[:3000]).to(dev)])
-    torch.cuda.synchronize()
-    hw = plan.H * plan.W
-    cls = plan.head_out.view(-1)[plan.n_box * hw:(plan.n_box + plan.n_cls) * hw].view(plan.n_cls, hw)   # [A, HW]
-    lg = cls.t().reshape(-1)[plan.mask[0].bool()].double().cpu()          # anchor index = pixel * A + a
-    b_old = model.rpn_head.conv_cls.bias.detach().double()
-    sc = 0.45 / max(float(lg.std()), 1e-6)
-    q = float(torch.quantile((lg - b_old.mean()) * sc, 1.0 - min(0.5, 100.0 / max(lg.numel(), 1))))
-    with torch.no_grad():
-        model.rpn_head.conv_cls.weight.mul_(sc)
-        model.rpn_head.conv_cls.bias.copy_(((b_old - b_old.mean()) * sc + (float(np.log(0.1 / 0.9)) - q)).float())
-    return model, an, bv, cal
+def build_model(seed=0, dev=None, config="car"):
+    """Seeded random-init SA-SSD for the workload + anchors; with `dev` the classification head is rescaled on the HIP
+    pipeline so that ~10^2 anchors pass the guided-anchor threshold.  No CPU oracle involved."""
+    w = synth.workload(config)
+    model, cfg = synth.build_detector_for(w, seed)
+    if dev is not None:
+        cal_cloud = synth.lidar64(11)[:3000] if config != "waymo" else synth.waymo_synth(11)[:30000]
+        synth.calibrate_cls_head_on_device(model, w, dev, cal_cloud, target_count=100 if config != "waymo" else 600)
+    return model, w
 
 
-def cpu_baseline(model, an, bv, cal, budget_s=20.0):
+def cpu_baseline(model, w, warm=3, runs=20, budget_s=60.0):
+    """BASELINE.md section 4 protocol on the CPU oracle (imported HERE only: the checker, timed as the baseline)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
+    from oracle import clib, nets as onets
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     torch.set_num_threads(min(torch.get_num_threads(), 16))      # oneDNN / index_add scale poorly past ~16 threads here
-    frames, t0 = 0, time.time()
-    while frames < 2 or (time.time() - t0 < budget_s and frames < 8):
-        H.oracle_forward(sd, [synth.k21(100 + frames)], an, bv, cal)
-        frames += 1
-    dt = time.time() - t0
-    return dict(value=round(frames / dt, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d K21 frames (21.5k pts), whole path on the CPU oracle: C voxelizer + rotated NMS on 1 "
-                       "thread, torch-CPU gather/mm/index_add sparse convs and oneDNN conv2d on %d threads"
-                       % (frames, torch.get_num_threads()))
+    cal, an, bv = w["cal"], w["anchors"], w["anchors_bv"]
+    vx, bev, head, ps = H.oracle_params(sd)
+    stages = {k: [] for k in ("voxelize", "sparse", "bev_heads", "post")}
+    total = []
+    t_start = time.time()
+    i = 0
+    while i < warm + runs and (i < warm + 5 or time.time() - t_start < budget_s):
+        pts = synth.k21(100 + i)
+        t0 = time.perf_counter()
+        v, c, n = clib.points_to_voxel(pts, cal["voxel_size"], cal["pc_range"], cal["max_points"], True, cal["max_voxels"])
+        feats = clib.voxel_mean(v, n)
+        coors = np.concatenate([np.zeros((len(c), 1), np.int32), c], 1)
+        t1 = time.perf_counter()
+        x3, idx3, shape3, *_ = onets.vxnet_forward(feats, coors, cal["sparse_shape"], 1, vx)
+        t2 = time.perf_counter()
+        x, conv6 = onets.bevnet_forward(onets.densify(x3, idx3, shape3, 1), bev)
+        box, cls, dirp = onets.ssd_head_forward(x, head, 1)
+        t3 = time.perf_counter()
+        mask = onets.anchors_mask(c, bv, cal["voxel_size"], cal["pc_range"], cal["grid_xyz"], 1)[None]
+        guided = onets.guided_anchors(box, cls, dirp, torch.from_numpy(an).view(1, -1, 7), torch.from_numpy(mask), 1, 0.1)
+        logits, _ = onets.pswarp_forward(conv6, ps, [g[0] for g in guided])
+        [onets.rescore(g[0], lg, g[1], 0.3, 0.1) for g, lg in zip(guided, logits)]
+        t4 = time.perf_counter()
+        if i >= warm:
+            for k, dt in zip(("voxelize", "sparse", "bev_heads", "post"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                stages[k].append(dt * 1e3)
+            total.append((t4 - t0) * 1e3)
+        i += 1
+    med = float(np.median(total))
+    return dict(value=round(1e3 / med, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+                ms_per_frame_median=round(med, 1), ms_p10=round(float(np.percentile(total, 10)), 1),
+                ms_p90=round(float(np.percentile(total, 90)), 1),
+                stage_ms_median={k: round(float(np.median(v)), 2) for k, v in stages.items()},
+                sample="%d warm-ups + %d timed K21 frames (21.5k pts), whole path on the CPU oracle: C voxelizer + "
+                       "rotated NMS on 1 thread, torch-CPU gather/mm/index_add sparse convs and oneDNN conv2d on %d "
+                       "threads; value = 1000 / median ms" % (warm, len(total), torch.get_num_threads()))
 
 
-def synth_gt(seed, n=8):
-    """Car-sized ground-truth boxes inside the KITTI crop (x,y,z bottom centre, w,l,h,ry)."""
+def synth_gt_on_points(cloud, seed, n=8):
+    """Car-sized ground-truth boxes centred on occupied voxels of the frame (so anchors get positive matches and the
+    localisation / direction losses are exercised): x,y,z bottom centre, w,l,h,ry."""
     r = np.random.default_rng(seed)
+    c = cloud[r.choice(len(cloud), n, replace=False), :3]
     b = np.zeros((n, 7), np.float32)
-    b[:, 0], b[:, 1], b[:, 2] = r.uniform(5, 65, n), r.uniform(-35, 35, n), r.uniform(-1.9, -1.5, n)
+    b[:, 0], b[:, 1] = np.clip(c[:, 0], 3, 67), np.clip(c[:, 1], -37, 37)
+    b[:, 2] = r.uniform(-1.9, -1.5, n)
     b[:, 3], b[:, 4], b[:, 5] = r.uniform(1.5, 1.8, n), r.uniform(3.5, 4.4, n), r.uniform(1.4, 1.7, n)
-    b[:, 6] = r.uniform(-3.1, 3.1, n)
+    b[:, 6] = r.choice([0.0, 1.57, -1.57, 3.1], n) + r.uniform(-0.2, 0.2, n)
     return b
 
 
 def main_train(args):
-    """--mode train: BASELINE configs[2] shape (car_cfg training, batch 2 / GPU, DDP) in fp32.  A step = device
-    voxelize + anchor masks + forward_train + backward + flat-gradient all-reduce (RCCL) + fused clip/AdamW update."""
-    from sassd import dist as D, train
+    """--mode train: BASELINE configs[2] shape (car_cfg training, batch 2 / GPU, DDP).  A step = device voxelize +
+    anchor masks + forward_train + backward + flat-gradient all-reduce (RCCL) + fused clip/AdamW update."""
+    from sassd import dist as D, train, anchors as A
     rank, local_rank, world = D.init("nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import helpers as H
-    cfg = Config.fromfile(os.path.join(ROOT, "configs", "car_cfg.py"))
-    model = H.randomize_detector(build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg), 0, cls_bias=-3.0).to(dev)
+    w = synth.workload("car")
+    model, cfg = synth.build_detector_for(w, 0, train=True, cls_bias=-3.0)
+    model = model.to(dev)
     B = args.batch if args.batch > 1 else 2
-    an = A.AnchorGeneratorStride(sizes=[1.6, 3.9, 1.56], anchor_strides=[.4, .4, 1.], anchor_offsets=[.2, -39.8, -1.78],
-                                 rotations=[0, 1.57])([1, 200, 176]).reshape(-1, 7)
-    bv = A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]]).astype(np.float32)
-    anchors = dict(Car=torch.from_numpy(an).to(dev))
-    anchors_bv = dict(Car=torch.from_numpy(bv).to(dev))
+    anchors = dict(Car=torch.from_numpy(w["anchors"]).to(dev))
+    anchors_bv = dict(Car=torch.from_numpy(w["anchors_bv"]).to(dev))
     opt = train.build_optimizer(model, cfg.optimizer, world)
     sched = train.build_scheduler(opt, args.steps + args.warmup, 1, cfg.optimizer, cfg.lr_config)
     sync = train.GradSync(opt.flat)
     nf = max(args.frames, B)
-    clouds = [torch.from_numpy(synth.k21(rank * 1000 + i)).to(dev) for i in range(nf)]
-    gts = [torch.from_numpy(synth_gt(rank * 1000 + i)).to(dev) for i in range(nf)]
+    host = [synth.k21(rank * 1000 + i) for i in range(nf)]
+    clouds = [torch.from_numpy(p).to(dev) for p in host]
+    gts = [torch.from_numpy(synth_gt_on_points(p, rank * 1000 + i)).to(dev) for i, p in enumerate(host)]
     types = [np.array(["Car"] * 8) for _ in range(nf)]
 
     def make_batch(i):
@@ -160,15 +177,43 @@ def main_train(args):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs/car_cfg.py training, batch=%d/GPU, fp32, synthetic lidar64 K21 frames + 8 "
-                               "synthetic car boxes/frame, adam_onecycle, grad clip 10" % B,
+                               "synthetic car boxes/frame on occupied voxels, adam_onecycle, grad clip 10" % B,
                    "global_batch": B * world, "parallelism": "ddp x%d (one flat-gradient RCCL all-reduce/step)" % world},
         "final_loss": round(float(loss), 4), "loss_terms": {k: round(float(v), 4) for k, v in terms.items()}}))
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with no torchrun environment: become N ranks (one per GPU) of one node."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.execvpe(cmd[0], cmd, env)
+
+
+def timed_graph_ms(plan, batch, reps=30):
+    """Mean replay time of plan.graph on the current stream (events around `reps` back-to-back replays)."""
+    plan.stage_inputs(batch)
+    for _ in range(3):
+        plan.graph.launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        plan.graph.launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="infer = BASELINE configs[1] (headline); train = configs[2] shape, extra measurement")
+    ap.add_argument("--config", choices=("car", "multi", "waymo"), default="car",
+                    help="car = configs[1] (headline); multi = configs[3] (batch 8); waymo = configs[4] shape (batch 4)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -176,9 +221,16 @@ def main():
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic frames cycled through")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight: independent plans on separate HIP "
                     "streams, so one frame's latency-bound sparse stage overlaps another frame's MFMA-bound BEV stage")
-    ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU (default 1 = BASELINE configs[1]); "
-                    "larger batches are an extra measurement, not the headline metric")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: the config's own -- car 1, "
+                    "multi 8, waymo 4)")
+    ap.add_argument("--eager", action="store_true", help="issue the ~80 launches per frame from the host instead of "
+                    "replaying the captured hipGraph (A/B)")
     args = ap.parse_args()
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and env_world == 0:
+        respawn_under_torchrun(args)                     # does not return
+    if env_world and env_world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, env_world))
     if args.mode == "train":
         return main_train(args)
 
@@ -187,13 +239,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    model, an, bv, cal = build_model(0, dev)
-    B = args.batch
+    model, w = build_model(0, dev, args.config)
+    B = args.batch if args.batch > 0 else w["batch"]
     S = max(1, args.inflight)
-    plans = [InferencePlan(model.state_dict(), batch_size=B, anchors=an, anchors_bv=bv, device=dev) for _ in range(S)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(S - 1)]
+    sd = model.state_dict()
+
+    def new_plan():
+        return InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["anchors_bv"], device=dev, **w["plan"])
+
+    plans = [new_plan() for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     plan = plans[0]
-    clouds = [torch.from_numpy(synth.k21(rank * 1000 + i)).to(dev) for i in range(max(args.frames, B))]
+    nfr = max(args.frames if args.config != "waymo" else min(args.frames, 8), B)
+    clouds = [torch.from_numpy(w["frame"](rank * 1000 + i)).to(dev) for i in range(nfr)]
 
     def batch_of(i):
         return [clouds[(i * B + j) % len(clouds)] for j in range(B)]
@@ -203,9 +261,18 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
 
+    if not args.eager:
+        for pl, st in zip(plans, streams):
+            with torch.cuda.stream(st):
+                pl.capture(w["points_cap"])
+        torch.cuda.synchronize()
+
     def step(i):
         with torch.cuda.stream(streams[i % S]):
-            plans[i % S].run_from_points(batch_of(i))
+            if args.eager:
+                plans[i % S].run_from_points(batch_of(i))
+            else:
+                plans[i % S].run_graph(batch_of(i))
 
     for i in range(max(args.warmup, S)):
         step(i)
@@ -214,97 +281,116 @@ def main():
         st = int(pl.status.item())
         assert st == 0, "pipeline status 0x%x" % st
 
-    plan.prof = {}
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     barrier()
     dt = time.perf_counter() - t0
-    prof, plan.prof = plan.prof, None
     dt = D.allreduce_max(dt, dev)
     ndet = int(plan.det["counts"].sum().item())
+    fps = args.steps * B * world / dt
 
-    # isolated pass: one frame at a time on one stream -> per-stage / per-kernel durations without inter-frame overlap
-    plan.prof = {}
-    torch.cuda.synchronize()
-    for i in range(40):
-        plan.run_from_points(batch_of(i))
-    torch.cuda.synchronize()
-    prof_iso, plan.prof = plan.prof, None
+    # ---- everything below is measurement detail on top of the timed region -----------------------------------
+    # sequential: one graph after the other on ONE stream, no host sync in between
+    seq_steps = max(20, min(args.steps, 100))
+    with torch.cuda.stream(streams[0]):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(seq_steps):
+            plan.run_from_points(batch_of(i)) if args.eager else plan.run_graph(batch_of(i))
+        torch.cuda.synchronize()
+        seq_ms = (time.perf_counter() - t1) / seq_steps * 1e3
+        # latency mode: host sync + result read-back per frame
+        nlat = max(10, min(50, args.steps))
+        t1 = time.perf_counter()
+        for i in range(nlat):
+            plan.run_from_points(batch_of(i)) if args.eager else plan.run_graph(batch_of(i))
+            plan.results()
+        lat_ms = (time.perf_counter() - t1) / nlat * 1e3
 
-    # latency mode (host sync + result read-back per frame), reported as an extra
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    nlat = max(10, min(50, args.steps))
-    for i in range(nlat):
-        plan.run_from_points(batch_of(i))
-        plan.results()
-    lat_ms = (time.perf_counter() - t1) / nlat * 1e3
+    # isolated eager pass with HIP events on the launch stream: per-stage / per-kernel durations of one frame at a time
+    iso_plan = new_plan()
+    iso_plan.prof = {}
+    with torch.cuda.stream(streams[0]):
+        for i in range(30):
+            iso_plan.run_from_points(batch_of(i))
+        torch.cuda.synchronize()
+    prof_iso, iso_plan.prof = iso_plan.prof, None
+    work = iso_plan.sparse_work()                              # of the last frame processed
 
+    # the sparse segment (7 rulebooks + 14 sparse convs) as its own hipGraph
+    sp_ms = None
+    if not args.eager:
+        with torch.cuda.stream(streams[0]):
+            iso_plan.capture(w["points_cap"], stages=("sparse",))
+            iso_plan.stage_inputs(batch_of(29))
+            sp_ms = timed_graph_ms(iso_plan, None)
+            iso_plan.capture(w["points_cap"], stages=("voxelize", "backbone", "tail"))
+            frame_ms = timed_graph_ms(iso_plan, batch_of(29))
     if rank != 0:
         return
-    seg_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items()}
-    iso_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof_iso.items()}
+    iso_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v][5:])) for k, v in prof_iso.items()}
+    if sp_ms is None:
+        sp_ms, frame_ms = iso_ms["sparse"], None
     H, W = plan.H, plan.W
-    conv_ms = float(np.mean([seg_ms["bev_conv%d" % i] for i in range(1, 7)]))      # six identical 256->256 3x3 launches
-    conv_iso = float(np.mean([iso_ms["bev_conv%d" % i] for i in range(1, 7)]))
+    wino_layers = [i for i in range(1, 7) if plan.bev[i][5]]
+    conv_iso = float(np.mean([iso_ms["bev_conv%d" % i] for i in range(1, 7)]))      # six identical 256->256 3x3 launches
     conv_flops = 2.0 * 256 * 256 * 9 * H * W * B               # direct-convolution flops of the layer
-    wino_flops = conv_flops * 16.0 / 36.0                      # what the Winograd F(2x2,3x3) kernel executes on the MFMA
-    achieved_tf = conv_flops / (conv_ms * 1e-3) / 1e12
-    iso_tf = conv_flops / (conv_iso * 1e-3) / 1e12
+    exec_flops = conv_flops * (16.0 / 36.0 if wino_layers else 1.0)     # Winograd F(2x2,3x3) executes 16/36 of them
+    exec_tf = exec_flops / (conv_iso * 1e-3) / 1e12
+    eff_tf = conv_flops / (conv_iso * 1e-3) / 1e12
     bev_total_ms = sum(iso_ms["bev_conv%d" % i] for i in range(8))
-    work = plan.sparse_work()                                  # of the last frame processed
-    sp_ms = iso_ms["sparse"]
     sp_gbs = (work["bytes_gs"] + work["rulebook_bytes"]) / (sp_ms * 1e-3) / 1e9
-    fps = args.steps * B * world / dt
     traffic = None                       # PMC passes cannot run inside this process: read the committed measurement
-    tj = os.path.join(ROOT, "profiles", "r01_conv2d_hbm_traffic.json")
-    if os.path.exists(tj) and B == 1:
-        traffic = json.load(open(tj))["traffic_bytes_per_launch"]
+    for tj in ("r02_conv2d_hbm_traffic.json", "r01_conv2d_hbm_traffic.json"):
+        tj = os.path.join(ROOT, "profiles", tj)
+        if os.path.exists(tj) and B == 1 and args.config == "car":
+            traffic = json.load(open(tj))["traffic_bytes_per_launch"]
+            break
+    headline = args.config == "car" and B == 1
     out = {
-        "metric": "KITTI-Car inference frames/sec (whole job)", "value": round(fps, 3), "unit": "frames/s",
+        "metric": "KITTI-Car inference frames/sec (whole job)" if args.config == "car" else
+                  "%s inference frames/sec (whole job)" % args.config,
+        "value": round(fps, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": round(fps / world / PUBLISHED_FPS, 3), "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs/car_cfg.py inference, batch=%d, fp32, synthetic lidar64 K21 "
-                               "frames (21500 pts -> ~16k voxels), random-init SA-SSD weights, points resident in HBM" % B,
+        "vs_baseline": round(fps / world / PUBLISHED_FPS, 3) if headline else None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s, batch=%d, random-init SA-SSD weights, points resident in HBM" % (w["desc"], B),
                    "frames_per_step_per_gpu": B, "frames_in_flight": S,
+                   "launch": "eager host launches" if args.eager else "one hipGraph replay per frame",
                    "parallelism": "frame-sharded x%d, no collective" % world,
                    "vs_baseline_ref": "reference readme.md:2 '25 FPS' (hardware unstated), per-GPU fps / 25"},
+        "fps_in_flight": round(fps, 3), "fps_sequential": round(B * 1e3 / seq_ms, 3),
+        "latency_ms_sync_per_frame": round(lat_ms, 3), "frame_graph_ms": None if frame_ms is None else round(frame_ms, 4),
         "roofline": {"bound": "mfma", "kernel": "conv2d_wino_kernel (BEV 256->256 3x3, Winograd F(2x2,3x3) on fp32 MFMA "
                                                 "32x32x2)",
-                     "achieved": round(iso_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                     "frac": round(iso_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
+                     "achieved": round(exec_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                     "frac": round(exec_tf / PEAK_F32_MFMA_TF, 4),
+                     "effective": round(eff_tf, 2), "effective_frac": round(eff_tf / PEAK_F32_MFMA_TF, 4),
+                     "traffic": traffic,
                      "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "
-                                     "passes, profiles/r01_conv2d_hbm_traffic.json)",
-                     "flops_per_launch": conv_flops, "ms_per_launch": round(conv_iso, 4),
-                     "executed_flops_per_launch": wino_flops,
-                     "mfma_pipe_frac": round(wino_flops / (conv_iso * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4),
-                     "note": "achieved = algorithmic (direct-convolution) flops of SURVEY 8(d) / mean launch duration, HIP "
-                             "events on the launch stream, one frame at a time (the pass right after the timed region; "
-                             "this is the duration rocprofv3 --kernel-trace reports, profiles/); the kernel EXECUTES "
-                             "16/36 of those flops on the MFMA (mfma_pipe_frac), which is how frac can exceed 1",
-                     "timed_region": {"frames_in_flight": S, "ms_per_launch": round(conv_ms, 4),
-                                      "achieved": round(achieved_tf, 2),
-                                      "frac": round(achieved_tf / PEAK_F32_MFMA_TF, 4),
-                                      "note": "same launches inside the timed region, where frames on separate streams "
-                                              "share the GPU"}},
-        "roofline_sparse": {"bound": "hbm", "kernels": "7 rulebooks + 14 spconv_fwd_kernel launches (isolated pass)",
+                                     "passes, profiles/)",
+                     "executed_flops_per_launch": exec_flops, "direct_conv_flops_per_launch": conv_flops,
+                     "ms_per_launch": round(conv_iso, 4),
+                     "note": "achieved/frac = flops EXECUTED on the MFMA pipe (Winograd: 16/36 of the direct "
+                             "convolution) / mean launch duration (HIP events on the launch stream, one frame at a time "
+                             "= what rocprofv3 --kernel-trace reports, profiles/); effective = the layer's direct-"
+                             "convolution flops of SURVEY 8(d) over the same time"},
+        "roofline_sparse": {"bound": "hbm", "kernels": "7 rulebooks (fused pyramid) + 14 sparse-conv launches, timed as "
+                                                       "one hipGraph" if not args.eager else "eager, isolated pass",
                             "achieved": round(sp_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": round(sp_gbs / PEAK_HBM_GBS, 4),
                             "frac_of_measured_copy_peak": round(sp_gbs / MEASURED_HBM_GBS, 4),
                             "bytes_gs": work["bytes_gs"], "bytes_min": work["bytes_min"],
                             "rulebook_bytes": work["rulebook_bytes"], "flops": work["flops"],
-                            "ms": round(sp_ms, 4), "rows": work["n"]},
+                            "ms": round(sp_ms, 4), "ms_eager_isolated": round(iso_ms["sparse"], 4), "rows": work["n"]},
         "stage_ms": {k: round(v, 4) for k, v in sorted(iso_ms.items())},
-        "stage_ms_timed_region_overlapped": {k: round(v, 4) for k, v in sorted(seg_ms.items())},
-        "frames_in_flight": S,
-        "bev_total_ms": round(bev_total_ms, 4), "latency_ms_sync_per_frame": round(lat_ms, 3),
+        "bev_total_ms": round(bev_total_ms, 4),
         "detections_last_frame": ndet,
     }
-    if world == 1 and B == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model, an, bv, cal)
+    if world == 1 and headline and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, w)
     print(json.dumps(out))
 
 

@@ -41,6 +41,19 @@ const char *sassd_version(void);
 int sassd_last_hip_error(void);
 const char *sassd_last_hip_error_string(void);
 
+/* Debug / ablation switches of the sparse-conv forward kernel (tools/ablate_spconv.py); 0 in production:
+ * bit0 no gather loads, bit1 no LDS scatter-add, bit2 no MFMA, bit3 no weight loads, bit8 legacy register-stationary
+ * kernel, bits 16+ force the row-slice size (64 / 128). */
+void sassd_debug_set_spconv(int flags);
+
+/* hipGraph capture of a launch sequence issued through this ABI (the reference has no counterpart: its frame is
+ * ~10^2 host-issued launches with >= 6 host syncs).  begin -> any sassd_* calls on `stream` (streams
+ * joined to it through events are captured too) -> end returns an executable graph; launch replays it. */
+int sassd_graph_begin(void *stream);
+int sassd_graph_end(void *stream, void **graph_exec);
+int sassd_graph_launch(void *graph_exec, void *stream);
+int sassd_graph_destroy(void *graph_exec);
+
 /* ------------------------------------------------------------------------------------------------
  * (a1+a2) Hard voxelisation + per-voxel mean.
  * Replaces mmdet/ops/points_op/points_ops.py:104-164 `points_to_voxel` (numba kernel :5-50, zyx order) and
@@ -63,6 +76,15 @@ int sassd_voxelize(const float *points, int n_points, int ndim, const float *vox
                    float *voxels, int32_t *coors, int coors_cols, int32_t *num_points, float *mean,
                    int nfeat, int32_t *row_offset, int32_t *voxel_num, int cap, int32_t *status,
                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same with the point count in DEVICE memory: `points` has room for points_cap rows, min(*n_points_dev, points_cap)
+ * of them are valid.  The launch sequence depends on points_cap only, so a frame that starts at the raw point cloud
+ * can be captured in a hipGraph and replayed for clouds of any size (workspace: sassd_voxelize_workspace_bytes(points_cap, ..)). */
+int sassd_voxelize_dev(const float *points, int points_cap, const int32_t *n_points_dev, int ndim,
+                       const float *voxel_size, const float *coors_range, int max_points, int max_voxels,
+                       int batch_idx, float *voxels, int32_t *coors, int coors_cols, int32_t *num_points,
+                       float *mean, int nfeat, int32_t *row_offset, int32_t *voxel_num, int cap, int32_t *status,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* SimpleVoxel.forward alone (vxnet.py:110-116): mean[v,f] = sum_t voxels[v,t,f] / num_points[v]. */
 int sassd_voxel_mean(const float *voxels, const int32_t *num_points, int m, int max_points, int ndim,
@@ -90,6 +112,22 @@ int sassd_rulebook_conv(const int32_t *in_indices, const int32_t *n_in_ptr, int 
                         int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 int sassd_rulebook_pairs(const int32_t *nbr, const int32_t *n_out_ptr, int cap_out, int K,
                          int32_t *pairs /*[K,2,cap_out]*/, int32_t *pair_num /*[K]*/, void *stream);
+
+/* Fused rulebook PYRAMID: all gather tables of a stack of `levels` resolutions (level l: SubMConv3d k=3 rulebook,
+ * indice_key "subm<l>"; l-1 -> l: SparseConv3d(k=3,s=2,p=1) rulebook + output coordinates) -- the seven
+ * get_indice_pairs calls of VxNet (cmn.py:147-173, 197-206) in 9 launches instead of 30.
+ *   indices[l]  [caps[l],4] i32 (b,z,y,x): level 0 is the input, levels >= 1 are written (ascending linear order)
+ *   n_ptrs[l]   device int32 row counts: level 0 is the input, levels >= 1 are written
+ *   D,H,W       spatial shape of level 0; level l+1 = (dim-1)/2+1 per axis
+ *   nbr_subm[l] [caps[l],27] or NULL;  nbr_down[l] (l >= 1) [caps[l],27]: strided table from level l-1 into level l
+ *   level_begin/level_end   build levels [begin, end) only (a caller that overlaps the tables with the convolutions
+ *               issues one call per level and records an event after each); begin = 0 also resets the workspace.
+ * All pointer arrays are HOST arrays of device pointers. */
+size_t sassd_rulebook_pyramid_workspace_bytes(int levels, const int *caps, int D, int H, int W, int batch_size);
+int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32_t *const *n_ptrs, const int *caps,
+                           int D, int H, int W, int batch_size, int32_t *const *nbr_subm,
+                           int32_t *const *nbr_down, int level_begin, int level_end, int32_t *status,
+                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a6+a7) Sparse convolution forward with fused per-channel affine (folded eval BatchNorm1d) + ReLU.

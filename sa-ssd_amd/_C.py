@@ -38,6 +38,7 @@ _SIGS = {
     "sassd_last_hip_error_string": (C.c_char_p, []),
     "sassd_voxelize_workspace_bytes": (_SZ, [_I, _I]),
     "sassd_voxelize": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _SZ, _P]),
+    "sassd_voxelize_dev": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _SZ, _P]),
     "sassd_voxel_mean": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "sassd_hash_bytes": (_SZ, [_I]),
     "sassd_hash_build": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P]),
@@ -45,6 +46,13 @@ _SIGS = {
     "sassd_rulebook_conv_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sassd_rulebook_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "sassd_rulebook_pairs": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "sassd_rulebook_pyramid_workspace_bytes": (_SZ, [_I, _P, _I, _I, _I, _I]),
+    "sassd_rulebook_pyramid": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "sassd_graph_begin": (_I, [_P]),
+    "sassd_graph_end": (_I, [_P, _P]),
+    "sassd_graph_launch": (_I, [_P, _P]),
+    "sassd_graph_destroy": (_I, [_P]),
+    "sassd_debug_set_spconv": (None, [_I]),
     "sassd_spconv_packed_floats": (_SZ, [_I, _I, _I]),
     "sassd_spconv_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
     "sassd_spconv_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P]),

@@ -48,3 +48,40 @@ extern "C" int sassd_mfma_probe(const float *a32, const float *b32, float *d32, 
                        ksteps);
     return sassd_launch_status();
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// hipGraph helpers.  Every entry point of this library is a fixed launch sequence on the caller's stream with all
+// data-dependent counts in device memory, so a whole frame (side streams joined through events included) can be
+// captured once and replayed: ~80 launches issued through a language binding become one hipGraphLaunch.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int sassd_graph_begin(void *stream)
+{
+    return sassd_hip(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+}
+
+extern "C" int sassd_graph_end(void *stream, void **graph_exec)
+{
+    if (!graph_exec) return SASSD_EINVAL;
+    hipGraph_t g = nullptr;
+    int rc = sassd_hip(hipStreamEndCapture((hipStream_t)stream, &g));
+    if (rc) return rc;
+    hipGraphExec_t ex = nullptr;
+    rc = sassd_hip(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    if (rc) return rc;
+    *graph_exec = (void *)ex;
+    return SASSD_OK;
+}
+
+extern "C" int sassd_graph_launch(void *graph_exec, void *stream)
+{
+    if (!graph_exec) return SASSD_EINVAL;
+    return sassd_hip(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+}
+
+extern "C" int sassd_graph_destroy(void *graph_exec)
+{
+    if (!graph_exec) return SASSD_OK;
+    return sassd_hip(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+}

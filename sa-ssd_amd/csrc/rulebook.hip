@@ -189,6 +189,162 @@ __global__ void __launch_bounds__(1024) pairs_kernel(const int32_t *__restrict__
 
 inline bool lin_fits(int D, int H, int W, int B) { return (double)D * H * W * B < 4294967294.0; }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused rulebook pyramid: every gather table of a submanifold / strided-conv stack (level l: SubMConv3d rulebook;
+// l -> l+1: SparseConv3d(k3,s2,p1) rulebook + the output coordinates) in 2 + 2*(L-1) + 1 launches and two memsets,
+// instead of the per-op chain above (30 launches for the four VxNet levels of cmn.py:147-173).
+//   rb_level_kernel   one thread per (row of level l, offset k): the subm table of level l (hash of level l), the
+//                     strided table INTO level l (hash of level l-1), and -- threads k < 8 -- the marks of the
+//                     row's <= 8 strided outputs in the bitmap of level l+1.  All three only read finished tables.
+//   rb_emit_kernel    single-pass ordered compaction of the bitmap: workgroups take a ticket (start order), publish
+//                     their popcount in a tagged 64-bit word and sum their predecessors' words (chained scan; a
+//                     ticket only waits for tickets that are already running, so any grid size makes progress),
+//                     then emit the coordinates in ascending linear order AND insert them into the next level's hash.
+// ------------------------------------------------------------------------------------------------------------------
+struct LevelArgs {
+    const int32_t *idx; const int32_t *n_ptr; int cap; int D, H, W;
+    HashView hv;               // this level's table (complete)
+    int32_t *nbr_subm;         // [cap,27] or nullptr
+    HashView hv_prev;          // previous (finer) level's table
+    int pD, pH, pW;            // previous level's dims
+    int32_t *nbr_down;         // [cap,27] strided table into this level, or nullptr
+    unsigned *bitmap_next;     // marks of level l+1's outputs, or nullptr
+    int OD, OH, OW;
+};
+
+__global__ void __launch_bounds__(256) rb_level_kernel(LevelArgs A)
+{
+    const int n = min(*A.n_ptr, A.cap);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 27) return;
+    const int row = t / 27, k = t - row * 27;
+    const int4 c = ((const int4 *)A.idx)[row];
+    const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+    if (A.nbr_subm) {
+        const int z = c.y + kz - 1, y = c.z + ky - 1, x = c.w + kx - 1;
+        int r = -1;
+        if (k == 13) r = row;
+        else if (z >= 0 && z < A.D && y >= 0 && y < A.H && x >= 0 && x < A.W) {
+            const unsigned key = (((unsigned)c.x * A.D + z) * A.H + y) * A.W + x;
+            const int e = hash_find(A.hv.keys, A.hv.mask, key);
+            if (e >= 0) r = A.hv.vals[e];
+        }
+        A.nbr_subm[t] = r;
+    }
+    if (A.nbr_down) {
+        const int z = 2 * c.y - 1 + kz, y = 2 * c.z - 1 + ky, x = 2 * c.w - 1 + kx;
+        int r = -1;
+        if (z >= 0 && z < A.pD && y >= 0 && y < A.pH && x >= 0 && x < A.pW) {
+            const unsigned key = (((unsigned)c.x * A.pD + z) * A.pH + y) * A.pW + x;
+            const int e = hash_find(A.hv_prev.keys, A.hv_prev.mask, key);
+            if (e >= 0) r = A.hv_prev.vals[e];
+        }
+        A.nbr_down[t] = r;
+    }
+    if (A.bitmap_next && k < 8) {
+        int oz[2], oy[2], ox[2];
+        const int nz = axis_outs(c.y, A.OD, oz), ny = axis_outs(c.z, A.OH, oy), nx = axis_outs(c.w, A.OW, ox);
+        const int a = k & 1, b = (k >> 1) & 1, e = k >> 2;
+        if (a < nz && b < ny && e < nx) {
+            const unsigned lin = (((unsigned)c.x * A.OD + oz[a]) * A.OH + oy[b]) * A.OW + ox[e];
+            atomicOr(&A.bitmap_next[lin >> 5], 1u << (lin & 31));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) rb_emit_kernel(const unsigned *__restrict__ bitmap, int nwords, int nblk,
+                                                      unsigned long long *state, unsigned *ticket, int OD, int OH,
+                                                      int OW, int cap_out, int32_t *__restrict__ out_idx,
+                                                      int32_t *n_out_ptr, HashView hv_next, int32_t *status)
+{
+    __shared__ int wsum[17];
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tk = s_ticket;                         // logical block index = start order
+    const int base = tk * kWordsPerBlock + threadIdx.x * 4;
+    unsigned w[4];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { w[k] = (base + k < nwords) ? bitmap[base + k] : 0u; s += __popc(w[k]); }
+    int tot;
+    const int ex = block_exclusive_scan(s, wsum, &tot);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&state[tk], (1ull << 32) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int part = 0;
+    for (int j = threadIdx.x; j < tk; j += 256) {
+        unsigned long long v;
+        for (;;) {
+            v = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v >> 32) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        part += (int)(unsigned)v;
+    }
+    int before;
+    block_exclusive_scan(part, wsum, &before);       // block total of the predecessors' counts
+    int row = before + ex;
+    if (tk == nblk - 1 && threadIdx.x == 0) {
+        int total = before + tot;
+        if (total > cap_out) { if (status) atomicOr(status, SASSD_ST_VOXEL_OVERFLOW); total = cap_out; }
+        *n_out_ptr = total;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned m = w[k];
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            if (row < cap_out) {
+                const unsigned key = (unsigned)(base + k) * 32u + bit;
+                unsigned lin = key;
+                const int x = lin % OW; lin /= OW;
+                const int y = lin % OH; lin /= OH;
+                const int z = lin % OD; lin /= OD;
+                ((int4 *)out_idx)[row] = make_int4((int)lin, z, y, x);
+                const int e = hash_insert(hv_next.keys, hv_next.mask, key);
+                if (e < 0) { if (status) atomicOr(status, SASSD_ST_HASH_FULL); }
+                else hv_next.vals[e] = row;
+            }
+            ++row;
+        }
+    }
+}
+
+constexpr int kMaxLevels = 8;
+
+struct PyramidLayout {
+    size_t keys[kMaxLevels], vals[kMaxLevels], bitmap[kMaxLevels], state[kMaxLevels], ticket;
+    size_t keys_end, zero_begin, zero_end, total;
+    int nwords[kMaxLevels], nblk[kMaxLevels];
+    int dims[kMaxLevels][3];
+};
+
+bool pyramid_layout(int levels, const int *caps, int D, int H, int W, int B, PyramidLayout &L)
+{
+    if (levels < 1 || levels > kMaxLevels) return false;
+    size_t o = 0;
+    for (int l = 0; l < levels; ++l) { L.keys[l] = o; o += align_up((size_t)hash_cap(caps[l]) * 4, 256); }
+    L.keys_end = o;
+    for (int l = 0; l < levels; ++l) { L.vals[l] = o; o += align_up((size_t)hash_cap(caps[l]) * 4, 256); }
+    L.zero_begin = o;
+    L.dims[0][0] = D; L.dims[0][1] = H; L.dims[0][2] = W;
+    for (int l = 0; l + 1 < levels; ++l) {
+        for (int a = 0; a < 3; ++a) L.dims[l + 1][a] = (L.dims[l][a] - 1) / 2 + 1;
+        if (!lin_fits(L.dims[l][0], L.dims[l][1], L.dims[l][2], B)) return false;
+        const size_t cells = (size_t)B * L.dims[l + 1][0] * L.dims[l + 1][1] * L.dims[l + 1][2];
+        L.nwords[l] = (int)((cells + 31) / 32);
+        L.nblk[l] = cdiv(L.nwords[l], kWordsPerBlock);
+        L.bitmap[l] = o; o += align_up((size_t)L.nwords[l] * 4, 256);
+        L.state[l] = o;  o += align_up((size_t)L.nblk[l] * 8, 256);
+    }
+    L.ticket = o; o += 256;
+    L.zero_end = o;
+    L.total = o;
+    return true;
+}
+
 }  // namespace
 
 extern "C" size_t sassd_hash_bytes(int cap_rows) { return (size_t)hash_cap(cap_rows) * 8; }
@@ -280,5 +436,68 @@ extern "C" int sassd_rulebook_pairs(const int32_t *nbr, const int32_t *n_out_ptr
     if (!nbr || !n_out_ptr || !pairs || !pair_num || cap_out <= 0 || K <= 0) return SASSD_EINVAL;
     hipLaunchKernelGGL(pairs_kernel, dim3(K), dim3(1024), 0, (hipStream_t)stream_, nbr, n_out_ptr, cap_out, K, pairs,
                        pair_num);
+    return sassd_launch_status();
+}
+
+
+extern "C" size_t sassd_rulebook_pyramid_workspace_bytes(int levels, const int *caps, int D, int H, int W,
+                                                         int batch_size)
+{
+    PyramidLayout L;
+    if (!caps || !pyramid_layout(levels, caps, D, H, W, batch_size, L)) return 0;
+    return L.total;
+}
+
+extern "C" int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32_t *const *n_ptrs, const int *caps,
+                                      int D, int H, int W, int batch_size, int32_t *const *nbr_subm,
+                                      int32_t *const *nbr_down, int level_begin, int level_end, int32_t *status,
+                                      void *workspace, size_t workspace_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!indices || !n_ptrs || !caps || !nbr_subm || !nbr_down || !workspace) return SASSD_EINVAL;
+    PyramidLayout L;
+    if (!pyramid_layout(levels, caps, D, H, W, batch_size, L)) return SASSD_EINVAL;
+    if (workspace_bytes < L.total) return SASSD_ENOSPC;
+    if (level_begin < 0 || level_end > levels || level_begin >= level_end) return SASSD_EINVAL;
+    for (int l = 0; l < levels; ++l) {
+        if (!indices[l] || !n_ptrs[l] || caps[l] <= 0) return SASSD_EINVAL;
+        if (l > 0 && !nbr_down[l]) return SASSD_EINVAL;
+    }
+    char *w = (char *)workspace;
+    int rc;
+    HashView hv[kMaxLevels];
+    for (int l = 0; l < levels; ++l) {
+        hv[l].keys = (unsigned *)(w + L.keys[l]);
+        hv[l].vals = (int *)(w + L.vals[l]);
+        hv[l].mask = hash_cap(caps[l]) - 1;
+    }
+    for (int l = level_begin; l < level_end; ++l) {
+        if (l == 0) {
+            if ((rc = sassd_hip(hipMemsetAsync(w, 0xFF, L.keys_end, stream)))) return rc;
+            if ((rc = sassd_hip(hipMemsetAsync(w + L.zero_begin, 0, L.zero_end - L.zero_begin, stream)))) return rc;
+            hipLaunchKernelGGL(hash_build_kernel, dim3(cdiv(caps[0], 256)), dim3(256), 0, stream, indices[0],
+                               n_ptrs[0], caps[0], L.dims[0][0], L.dims[0][1], L.dims[0][2], hv[0], status);
+        } else {
+            const int p = l - 1;
+            hipLaunchKernelGGL(rb_emit_kernel, dim3(L.nblk[p]), dim3(256), 0, stream,
+                               (const unsigned *)(w + L.bitmap[p]), L.nwords[p], L.nblk[p],
+                               (unsigned long long *)(w + L.state[p]), (unsigned *)(w + L.ticket) + p, L.dims[l][0],
+                               L.dims[l][1], L.dims[l][2], caps[l], indices[l], n_ptrs[l], hv[l], status);
+        }
+        LevelArgs A;
+        A.idx = indices[l]; A.n_ptr = n_ptrs[l]; A.cap = caps[l];
+        A.D = L.dims[l][0]; A.H = L.dims[l][1]; A.W = L.dims[l][2];
+        A.hv = hv[l];
+        A.nbr_subm = nbr_subm[l];
+        const int pl = l > 0 ? l - 1 : 0;
+        A.hv_prev = hv[pl];
+        A.pD = L.dims[pl][0]; A.pH = L.dims[pl][1]; A.pW = L.dims[pl][2];
+        A.nbr_down = l > 0 ? nbr_down[l] : nullptr;
+        const bool last = (l + 1 == levels);
+        A.bitmap_next = last ? nullptr : (unsigned *)(w + L.bitmap[l]);
+        A.OD = last ? 1 : L.dims[l + 1][0]; A.OH = last ? 1 : L.dims[l + 1][1]; A.OW = last ? 1 : L.dims[l + 1][2];
+        if (A.nbr_subm || A.nbr_down || A.bitmap_next)
+            hipLaunchKernelGGL(rb_level_kernel, dim3(cdiv(caps[l] * 27, 256)), dim3(256), 0, stream, A);
+    }
     return sassd_launch_status();
 }

@@ -247,6 +247,194 @@ int launch_pack(const float *w, int K, float *packed, int transposed, hipStream_
     return sassd_launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gather - GEMM - scatter sparse conv (the production forward / data-gradient kernel for Cin >= 16).
+//
+// The register-stationary kernel above pads every (16-row tile, offset) to 16 rows: at KITTI sparsity only 40-60 %
+// of its MFMA rows carry a rulebook pair (21-24 % on the strided layers) and it pays one workgroup barrier per three
+// offsets.  Here a workgroup owns RW consecutive output rows and its waves pull whole kernel OFFSETS from an LDS
+// ticket counter (heaviest offsets first: centre, faces, edges, corners):
+//   compaction   the wave scans the offset's column of the workgroup's rulebook slice (staged once in LDS), ballots
+//                the rows that have a pair and writes the (input row, local output row) list -- the M dimension of
+//                the MFMA is filled with PAIRS, ceil(n_k/16) tiles instead of RW/16 (75-85 % full at RW = 64,
+//                85-95 % at RW = 128)
+//   B operand    W[k] (Cin x Cout, pre-packed fragment order) lives in REGISTERS for the whole offset: loaded once
+//                per (workgroup, offset) straight from L2, reused by every tile of that offset
+//   A operand    pair rows gathered from HBM/L2 in fragment order, double buffered across tiles
+//   scatter      D tiles are added into the workgroup's fp32 accumulator slab in LDS with ds_add_f32 (each output
+//                row occurs at most once per offset, different offsets = different waves: LDS atomics, no barrier)
+//   epilogue     ONE barrier, then scale / shift / ReLU and coalesced 16-B row stores.
+// No barrier inside the main loop; waves of one workgroup never wait for each other until the epilogue.  fp32 adds
+// of the <= 27 offset contributions of a row arrive in a timing-dependent order (last-ulp run-to-run variation; the
+// rulebooks and voxels stay bit-exact, the parity bar on features is 1e-4).
+// Workgroup -> rows: blocks that land on the same XCD (blockIdx % 8) take one contiguous range of row slices, so
+// the gathers of neighbouring voxels hit that XCD's L2.
+// ------------------------------------------------------------------------------------------------------------------
+__constant__ int c_offset_order[kK] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25,
+                                       0, 2, 6, 8, 18, 20, 24, 26};
+
+template <int CIN, int COUT, int RW, int NW>
+__global__ void __launch_bounds__(NW * 64)
+spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_ptr,
+                 int cap, const float *__restrict__ wp, const float *__restrict__ scale,
+                 const float *__restrict__ shift, int relu, float *__restrict__ y, int dbg)
+{
+    constexpr int KS = CIN / 4, NT = COUT / 16;
+    constexpr int LDA = COUT + 4;
+    constexpr int NH = RW / 64;
+    __shared__ __attribute__((aligned(16))) float acc[RW * LDA];
+    __shared__ int nbr_s[RW * kK];
+    __shared__ __attribute__((aligned(16))) int lst_in[NW][RW];
+    __shared__ __attribute__((aligned(16))) int lst_out[NW][RW];
+    __shared__ int next_slot;
+
+    const int n = min(*n_ptr, cap);
+    const int nslice = (n + RW - 1) / RW;
+    const int per_xcd = (nslice + 7) >> 3;
+    const int slice = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || slice >= nslice) return;      // workgroup-uniform
+    const int r0 = slice * RW;
+    const int rows = min(RW, n - r0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, m16 = lane & 15;
+
+    for (int i = tid; i < RW * kK; i += NW * 64) nbr_s[i] = (i < rows * kK) ? nbr[(size_t)r0 * kK + i] : -1;
+    for (int i = tid; i < RW * LDA; i += NW * 64) acc[i] = 0.f;
+    if (tid == 0) next_slot = 0;
+    __syncthreads();
+
+    int *lin = lst_in[wave], *lout = lst_out[wave];
+    float b[NT][KS];
+    float a0[KS], a1[KS];
+
+    auto fetch_a = [&](int t, float (&af)[KS]) {
+        const int in = lin[t * 16 + m16];
+        if (in >= 0 && !(dbg & 1)) load_vec<KS>(x + (size_t)in * CIN + q * KS, af);
+        else {
+#pragma unroll
+            for (int i = 0; i < KS; ++i) af[i] = 0.f;
+        }
+    };
+    auto tile = [&](int t, int nk, const float (&af)[KS]) {
+        f32x4 d[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) d[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 4)) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], b[u][kk], d[u], 0, 0, 0);
+        }
+        const int4 ol = *(const int4 *)(lout + t * 16 + q * 4);            // D[row = q*4 + reg][col = m16]
+        const int pbase = t * 16 + q * 4;
+        if (!(dbg & 2)) {
+            const int olr[4] = {ol.x, ol.y, ol.z, ol.w};
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (pbase + reg < nk) {
+                    float *dst = acc + olr[reg] * LDA + m16;
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) atomicAdd(dst + u * 16, d[u][reg]);
+                }
+        }
+    };
+
+    for (;;) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&next_slot, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= kK) break;
+        const int k = c_offset_order[slot];
+        // ---- compaction of offset k over the workgroup's rows ----------------------------------------
+        int nk = 0;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int r = h * 64 + lane;
+            const int v = nbr_s[r * kK + k];
+            const unsigned long long mk = __ballot(v >= 0);
+            const int pos = nk + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+            if (v >= 0) { lin[pos] = v; lout[pos] = r; }
+            nk += __popcll(mk);
+        }
+        nk = __builtin_amdgcn_readfirstlane(nk);
+        if (nk == 0) continue;
+        const int ntile = (nk + 15) >> 4;
+        if (lane < ntile * 16 - nk) { lin[nk + lane] = -1; lout[nk + lane] = 0; }     // pad the last tile
+        // ---- W[k] -> registers (fragment order, 16-B pieces, coalesced) ------------------------------
+        if (!(dbg & 8)) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u) load_vec<KS>(wp + (((size_t)k * NT + u) * 64 + lane) * KS, b[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int i = 0; i < KS; ++i) b[u][i] = 1.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own list writes precede its list reads
+        fetch_a(0, a0);
+        for (int t = 0; t < ntile; t += 2) {
+            if (t + 1 < ntile) fetch_a(t + 1, a1);
+            tile(t, nk, a0);
+            if (t + 1 < ntile) {
+                if (t + 2 < ntile) fetch_a(t + 2, a0);
+                tile(t + 1, nk, a1);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // list reads done before the next offset rewrites it
+    }
+    __syncthreads();
+
+    // ---- epilogue: folded BatchNorm / bias / ReLU, one 16-B piece per thread and step ----------------------
+    constexpr int C4 = COUT / 4;
+    for (int i = tid; i < rows * C4; i += NW * 64) {
+        const int r = i / C4, c4 = i - r * C4;
+        float4 v = *(const float4 *)(acc + r * LDA + c4 * 4);
+        const float4 sc = scale ? *(const float4 *)(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 sh = shift ? *(const float4 *)(shift + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(float4 *)(y + (size_t)(r0 + r) * COUT + c4 * 4) = v;
+    }
+}
+
+int g_spconv_rw = 0;            // 0 = choose by capacity; 64 / 128 forced (tools/, tests)
+
+template <int CIN, int COUT>
+int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp, int K,
+              const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
+{
+    // capacity is the only size the host knows (row counts live on the device): KITTI-scale single frames take 64-row
+    // slices (>= 200 workgroups for 13-18 k rows), batches / Waymo-scale frames 128-row slices (denser MFMA tiles,
+    // half the weight traffic)
+    const int rw = g_spconv_rw ? g_spconv_rw : (cap <= 65536 ? 64 : 128);
+    const int dbg = g_spconv_dbg & 15;
+    if (rw == 64) {
+        const int grid = 8 * cdiv(cdiv(cap, 64), 8);
+        hipLaunchKernelGGL((spconv_gs_kernel<CIN, COUT, 64, 8>), dim3(grid), dim3(512), 0, stream, x, nbr, n_ptr, cap,
+                           wp, scale, shift, relu, y, dbg);
+    } else {
+        const int grid = 8 * cdiv(cdiv(cap, 128), 8);
+        hipLaunchKernelGGL((spconv_gs_kernel<CIN, COUT, 128, 8>), dim3(grid), dim3(512), 0, stream, x, nbr, n_ptr, cap,
+                           wp, scale, shift, relu, y, dbg);
+    }
+    (void)K;
+    return sassd_launch_status();
+}
+
+// forward / data-gradient dispatch: gather-GEMM-scatter for 27-offset layers with Cin >= 16, the register-stationary
+// kernel for the 4-channel input layer, the 1x1x1 layer and when the legacy switch (debug bit 8) is set
+template <int CIN, int COUT>
+int launch_conv(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp, int K,
+                const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
+{
+    if constexpr (CIN >= 16) {
+        if (nbr && !(g_spconv_dbg & 256)) return launch_gs<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, stream);
+    }
+    return launch_fwd<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, stream);
+}
+
 #define SP_DISPATCH(FN, ...)                                                     \
     if (Cin == 4 && Cout == 16) return FN<4, 16>(__VA_ARGS__);                   \
     if (Cin == 16 && Cout == 16) return FN<16, 16>(__VA_ARGS__);                 \
@@ -420,7 +608,7 @@ extern "C" int sassd_spconv_bwd_data(const float *dy, const int32_t *nbrT, const
     if (nbrT ? (K != kK) : (K != 1)) return SASSD_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     { const int t = Cin; Cin = Cout; Cout = t; }
-    SP_DISPATCH(launch_fwd, dy, nbrT, n_in_ptr, cap_in, wT_packed, K, nullptr, nullptr, 0, dx, stream)
+    SP_DISPATCH(launch_conv, dy, nbrT, n_in_ptr, cap_in, wT_packed, K, nullptr, nullptr, 0, dx, stream)
 }
 
 extern "C" size_t sassd_spconv_bwd_weight_workspace_bytes(int cap_out, int K, int Cin, int Cout)
@@ -442,7 +630,9 @@ extern "C" int sassd_spconv_bwd_weight(const float *x, const float *dy, const in
 namespace {
 }  // namespace
 
-extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags; }
+// debug / ablation switches (tools/ablate_spconv.py): bit0 no gather loads, bit1 no LDS scatter-add, bit2 no MFMA,
+// bit3 no weight loads, bit8 legacy register-stationary kernel; bits 16.. force the row-slice size (64 / 128)
+extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags & 0xFFFF; g_spconv_rw = flags >> 16; }
 
 extern "C" size_t sassd_spconv_packed_floats(int K, int Cin, int Cout) { return (size_t)K * Cin * Cout; }
 
@@ -460,7 +650,7 @@ extern "C" int sassd_spconv_fwd(const float *x, const int32_t *nbr, const int32_
     if (!x || !n_out_ptr || !w_packed || !y || cap_out <= 0) return SASSD_EINVAL;
     if (nbr ? (K != kK) : (K != 1)) return SASSD_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    SP_DISPATCH(launch_fwd, x, nbr, n_out_ptr, cap_out, w_packed, K, scale, shift, relu, y, stream)
+    SP_DISPATCH(launch_conv, x, nbr, n_out_ptr, cap_out, w_packed, K, scale, shift, relu, y, stream)
 }
 
 extern "C" int sassd_densify(const float *feats, const int32_t *indices, const int32_t *n_ptr, int cap, int C,

@@ -23,7 +23,10 @@ struct VoxParams {
     int grid[3];               // x,y,z cells
     int n, ndim, T, max_voxels, batch_idx, coors_cols, nfeat, cap;
     unsigned hmask;
+    const int32_t *n_dev;      // device point count (<= n, the capacity) or nullptr: the count is n
 };
+
+__device__ __forceinline__ int vox_n(const VoxParams &P) { return P.n_dev ? min(max(*P.n_dev, 0), P.n) : P.n; }
 
 struct VoxWs {
     unsigned *keys;            // [hcap]
@@ -38,7 +41,7 @@ __global__ void __launch_bounds__(256) vox_insert_kernel(const float *__restrict
                                                          int32_t *status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
+    if (i >= vox_n(P)) return;
     const float *p = pts + (size_t)i * P.ndim;
     int c[3];
     bool ok = true;
@@ -82,8 +85,9 @@ __global__ void __launch_bounds__(kScanThreads) vox_count_kernel(VoxParams P, Vo
     __shared__ int wsum[17];
     const int base = blockIdx.x * kPtsPerBlock + threadIdx.x * kPtsPerThread;
     int s = 0;
+    const int n = vox_n(P);
 #pragma unroll
-    for (int k = 0; k < kPtsPerThread; ++k) s += is_first(ws, P.T, P.n, base + k);
+    for (int k = 0; k < kPtsPerThread; ++k) s += is_first(ws, P.T, n, base + k);
     int tot;
     block_exclusive_scan(s, wsum, &tot);
     if (threadIdx.x == 0) ws.bsum[blockIdx.x] = tot;
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(1024) vox_scan_kernel(VoxParams P, VoxWs ws, i
     if (F > P.max_voxels) {           // uniform branch
         const int blk = s_blk, bb = s_base;
         const int i = blk * kPtsPerBlock + threadIdx.x;     // kPtsPerBlock == 1024 == blockDim
-        int f = is_first(ws, P.T, P.n, i);
+        int f = is_first(ws, P.T, vox_n(P), i);
         int tot;
         int ex = block_exclusive_scan(f, wsum, &tot);
         if (f && bb + ex == P.max_voxels) ws.scal[1] = i;
@@ -140,8 +144,9 @@ __global__ void __launch_bounds__(kScanThreads) vox_emit_kernel(const float *__r
     const int base = blockIdx.x * kPtsPerBlock + threadIdx.x * kPtsPerThread;
     int f[kPtsPerThread];
     int s = 0;
+    const int n = vox_n(P);
 #pragma unroll
-    for (int k = 0; k < kPtsPerThread; ++k) { f[k] = is_first(ws, P.T, P.n, base + k); s += f[k]; }
+    for (int k = 0; k < kPtsPerThread; ++k) { f[k] = is_first(ws, P.T, n, base + k); s += f[k]; }
     int tot;
     int ex = block_exclusive_scan(s, wsum, &tot);
     int r = ws.bbase[blockIdx.x] + ex;
@@ -228,11 +233,11 @@ extern "C" size_t sassd_voxelize_workspace_bytes(int n_points, int max_points)
     return vox_layout(n_points, max_points, nullptr, off);
 }
 
-extern "C" int sassd_voxelize(const float *points, int n_points, int ndim, const float *voxel_size,
-                              const float *coors_range, int max_points, int max_voxels, int batch_idx,
-                              float *voxels, int32_t *coors, int coors_cols, int32_t *num_points, float *mean,
-                              int nfeat, int32_t *row_offset, int32_t *voxel_num, int cap, int32_t *status,
-                              void *workspace, size_t workspace_bytes, void *stream_)
+static int voxelize_impl(const float *points, int n_points, const int32_t *n_points_dev, int ndim,
+                         const float *voxel_size, const float *coors_range, int max_points, int max_voxels,
+                         int batch_idx, float *voxels, int32_t *coors, int coors_cols, int32_t *num_points,
+                         float *mean, int nfeat, int32_t *row_offset, int32_t *voxel_num, int cap, int32_t *status,
+                         void *workspace, size_t workspace_bytes, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_points < 0 || ndim < 3 || !voxel_size || !coors_range || !coors || !workspace) return SASSD_EINVAL;
@@ -258,6 +263,7 @@ extern "C" int sassd_voxelize(const float *points, int n_points, int ndim, const
     if (vol >= 4294967294.0) return SASSD_EINVAL;
     P.n = n_points; P.ndim = ndim; P.T = max_points; P.max_voxels = max_voxels; P.batch_idx = batch_idx;
     P.coors_cols = coors_cols; P.nfeat = mean ? nfeat : 0; P.cap = cap; P.hmask = hcap - 1;
+    P.n_dev = n_points_dev;
 
     char *w = (char *)workspace;
     VoxWs ws;
@@ -279,6 +285,29 @@ extern "C" int sassd_voxelize(const float *points, int n_points, int ndim, const
     hipLaunchKernelGGL(vox_emit_kernel, dim3(nblk), dim3(kScanThreads), 0, stream, points, P, ws,
                        (const int32_t *)row_offset, voxels, coors, num_points, mean, status);
     return sassd_launch_status();
+}
+
+extern "C" int sassd_voxelize(const float *points, int n_points, int ndim, const float *voxel_size,
+                              const float *coors_range, int max_points, int max_voxels, int batch_idx,
+                              float *voxels, int32_t *coors, int coors_cols, int32_t *num_points, float *mean,
+                              int nfeat, int32_t *row_offset, int32_t *voxel_num, int cap, int32_t *status,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    return voxelize_impl(points, n_points, nullptr, ndim, voxel_size, coors_range, max_points, max_voxels, batch_idx,
+                         voxels, coors, coors_cols, num_points, mean, nfeat, row_offset, voxel_num, cap, status,
+                         workspace, workspace_bytes, stream);
+}
+
+extern "C" int sassd_voxelize_dev(const float *points, int points_cap, const int32_t *n_points_dev, int ndim,
+                                  const float *voxel_size, const float *coors_range, int max_points, int max_voxels,
+                                  int batch_idx, float *voxels, int32_t *coors, int coors_cols, int32_t *num_points,
+                                  float *mean, int nfeat, int32_t *row_offset, int32_t *voxel_num, int cap,
+                                  int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!n_points_dev || points_cap <= 0) return SASSD_EINVAL;
+    return voxelize_impl(points, points_cap, n_points_dev, ndim, voxel_size, coors_range, max_points, max_voxels,
+                         batch_idx, voxels, coors, coors_cols, num_points, mean, nfeat, row_offset, voxel_num, cap,
+                         status, workspace, workspace_bytes, stream);
 }
 
 extern "C" int sassd_voxel_mean(const float *voxels, const int32_t *num_points, int m, int max_points, int ndim,

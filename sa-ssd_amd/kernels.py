@@ -26,9 +26,26 @@ def weight_key(w):
     return (w._version, w.data_ptr(), str(w.device), _weights_gen[0])
 
 
+_ws_scope = [None]
+
+
+class ws_scope:
+    """Scratch buffers handed out inside `with ws_scope(owner)` belong to `owner`: plans that run concurrently on
+    different HIP streams must not share kernel workspaces."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __enter__(self):
+        self.prev, _ws_scope[0] = _ws_scope[0], self.owner
+
+    def __exit__(self, *exc):
+        _ws_scope[0] = self.prev
+
+
 def workspace(name, nbytes, device):
-    """Grow-only cached scratch buffer (uint8) per (name, device)."""
-    key = (name, str(device))
+    """Grow-only cached scratch buffer (uint8) per (name, device, workspace scope)."""
+    key = (name, str(device), _ws_scope[0])
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -52,9 +69,11 @@ def new_status(device):
 
 # --------------------------------------------------------------------------------------------------
 def voxelize(points, voxel_size, coors_range, max_points, max_voxels, batch_idx=0, coors_cols=3,
-             want_voxels=True, want_mean=True, nfeat=4, out=None, row_offset=None, status=None, cap=None):
+             want_voxels=True, want_mean=True, nfeat=4, out=None, row_offset=None, status=None, cap=None,
+             n_dev=None):
     """points [N,ndim] f32 cuda.  Returns dict(voxels, coors, num_points, mean, voxel_num) of capacity-sized
-    tensors (rows [0, voxel_num) valid; voxel_num is a device int32 scalar)."""
+    tensors (rows [0, voxel_num) valid; voxel_num is a device int32 scalar).  With `n_dev` (device int32 scalar) the
+    first min(n_dev, N) rows of `points` are the cloud (graph-capturable: the launches depend on N only)."""
     _chk_cuda(points)
     L = _C.lib()
     n, ndim = points.shape
@@ -80,10 +99,14 @@ def voxelize(points, voxel_size, coors_range, max_points, max_voxels, batch_idx=
         vnum = torch.zeros(1, dtype=torch.int32, device=dev)
     wsb = L.sassd_voxelize_workspace_bytes(n, max_points)
     ws = workspace("voxelize", wsb, dev)
-    rc = L.sassd_voxelize(_C.ptr(points), n, ndim, vs.ctypes.data, cr.ctypes.data, int(max_points), int(max_voxels),
-                          int(batch_idx), _C.ptr(voxels) if want_voxels else None, _C.ptr(coors), coors_cols,
-                          _C.ptr(num), _C.ptr(mean) if want_mean else None, nfeat, _C.ptr(row_offset), _C.ptr(vnum),
-                          cap, _C.ptr(status), _C.ptr(ws), wsb, _C.stream())
+    tail = (ndim, vs.ctypes.data, cr.ctypes.data, int(max_points), int(max_voxels), int(batch_idx),
+            _C.ptr(voxels) if want_voxels else None, _C.ptr(coors), coors_cols, _C.ptr(num),
+            _C.ptr(mean) if want_mean else None, nfeat, _C.ptr(row_offset), _C.ptr(vnum), cap, _C.ptr(status),
+            _C.ptr(ws), wsb, _C.stream())
+    if n_dev is None:
+        rc = L.sassd_voxelize(_C.ptr(points), n, *tail)
+    else:
+        rc = L.sassd_voxelize_dev(_C.ptr(points), n, _C.ptr(n_dev), *tail)
     _C.check(rc, "sassd_voxelize")
     return dict(voxels=voxels, coors=coors, num_points=num, mean=mean, voxel_num=vnum)
 
@@ -147,6 +170,72 @@ def rulebook_conv(indices, n_in_ptr, cap_in, shape, batch_size, table, cap_out, 
                                _C.ptr(status), _C.ptr(ws), wsb, _C.stream())
     _C.check(rc, "sassd_rulebook_conv")
     return out_indices, n_out_ptr, nbr
+
+
+class RulebookPyramid:
+    """Pre-resolved argument block of sassd_rulebook_pyramid for fixed buffers (a plan builds it once; a frame is then
+    `build(level_begin, level_end)` calls with no per-call marshalling)."""
+
+    def __init__(self, indices, n_ptrs, caps, shape0, batch_size, nbr_subm, nbr_down, status=None):
+        import ctypes as C
+        L = _C.lib()
+        self.levels = len(indices)
+        dev = indices[0].device
+        arr = lambda ts: (C.c_void_p * self.levels)(*[(t.data_ptr() if t is not None else None) for t in ts])  # noqa: E731
+        self._keep = (list(indices), list(n_ptrs), list(nbr_subm), list(nbr_down), status)
+        self.indices, self.n_ptrs = arr(indices), arr(n_ptrs)
+        self.nbr_subm, self.nbr_down = arr(nbr_subm), arr(nbr_down)
+        self.caps = (C.c_int * self.levels)(*[int(c) for c in caps])
+        self.shape0, self.B = tuple(int(v) for v in shape0), int(batch_size)
+        self.status = status
+        self.wsb = L.sassd_rulebook_pyramid_workspace_bytes(self.levels, self.caps, *self.shape0, self.B)
+        if self.wsb == 0:
+            raise ValueError("rulebook pyramid: unsupported level count / grid too large")
+        self.ws = torch.empty(self.wsb, dtype=torch.uint8, device=dev)
+
+    def build(self, level_begin=0, level_end=None):
+        level_end = self.levels if level_end is None else level_end
+        d, h, w = self.shape0
+        rc = _C.lib().sassd_rulebook_pyramid(self.levels, self.indices, self.n_ptrs, self.caps, d, h, w, self.B,
+                                             self.nbr_subm, self.nbr_down, level_begin, level_end,
+                                             _C.ptr(self.status), _C.ptr(self.ws), self.wsb, _C.stream())
+        _C.check(rc, "sassd_rulebook_pyramid")
+
+
+class Graph:
+    """hipGraph of a launch sequence issued through this module on the current stream (sassd_graph_*)."""
+
+    def __init__(self):
+        self.exe = None
+
+    def capture(self, fn):
+        import ctypes as C
+        st = _C.stream()
+        _C.check(_C.lib().sassd_graph_begin(st), "sassd_graph_begin")
+        try:
+            fn()
+        except BaseException:
+            junk = C.c_void_p()
+            _C.lib().sassd_graph_end(st, C.byref(junk))
+            raise
+        exe = C.c_void_p()
+        _C.check(_C.lib().sassd_graph_end(st, C.byref(exe)), "sassd_graph_end")
+        self.exe = exe
+        return self
+
+    def launch(self):
+        _C.check(_C.lib().sassd_graph_launch(self.exe, _C.stream()), "sassd_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exe is not None:
+                _C.lib().sassd_graph_destroy(self.exe)
+        except Exception:
+            pass
+
+
+def debug_set_spconv(flags):
+    _C.lib().sassd_debug_set_spconv(int(flags))
 
 
 def rulebook_pairs(nbr, n_out_ptr, cap_out):

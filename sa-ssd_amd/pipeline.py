@@ -54,7 +54,8 @@ class InferencePlan:
                  point_cloud_range=(0, -40., -3., 70.4, 40., 1.), max_num_points=5, max_voxels=20000,
                  sparse_shape=(40, 1600, 1408), anchors=None, anchors_bv=None, anchor_area_threshold=1,
                  anchors_per_loc=2, grid_offsets=(0., 40.), featmap_stride=0.4, rpn_thr=0.1, score_thr=0.3,
-                 iou_thr=0.1, cap_k=4096, cap_d=512, device=None, level_cap_factor=2, overlap=True, winograd=True):
+                 iou_thr=0.1, cap_k=4096, cap_d=512, device=None, level_cap_factor=2, overlap=True, winograd=True,
+                 fused_rulebooks=True):
         dev = torch.device(device if device is not None else "cuda:0")
         self.dev, self.B, self.ncls, self.A = dev, int(batch_size), int(num_class), int(anchors_per_loc)
         self.voxel_size = np.asarray(voxel_size, np.float32)
@@ -150,6 +151,14 @@ class InferencePlan:
         self.det = dict(boxes=z(B, self.capD, 7), scores=z(B, self.capD), labels=z(B, self.capD, dt=i32),
                         counts=z(B, dt=i32))
         self.middle = {}
+        # all seven rulebooks through the fused pyramid (9 launches); the per-op chain (30) stays selectable for A/B
+        self.pyr = None
+        if fused_rulebooks:
+            self.pyr = K.RulebookPyramid(self.idx, self.n, self.caps, self.shape0, B,
+                                         [self.nbr["subm%d" % l] for l in range(4)],
+                                         [None] + [self.nbr["down%d" % l] for l in range(3)], self.status)
+        self.graph = None
+        self._wsid = id(self)
         # coordinate-only work (rulebooks, anchors_mask) runs on a side stream, overlapping the feature path
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(device=dev) if self.overlap else None
@@ -167,8 +176,9 @@ class InferencePlan:
             self.prof.setdefault(name, []).append((e0, self._ev()))
 
     # ------------------------------------------------------------------------------------------------
-    def voxelize(self, clouds):
-        """clouds: list of B device tensors [Ni, ndim] f32.  Fills idx[0] (b,z,y,x), mean, row_off."""
+    def voxelize(self, clouds, n_dev=None):
+        """clouds: list of B device tensors [Ni, ndim] f32.  Fills idx[0] (b,z,y,x), mean, row_off.  With `n_dev`
+        (device int32 [B]) the clouds are capacity-sized staging buffers holding n_dev[b] points each."""
         assert len(clouds) == self.B
         e0 = self._ev() if self.prof is not None else None
         self.row_off.zero_()
@@ -177,7 +187,8 @@ class InferencePlan:
                        want_voxels=False, want_mean=True, nfeat=4,
                        out=dict(coors=self.idx[0], mean=self.mean, voxel_num=self.vnum[b:b + 1],
                                 num_points=self._numpts()),
-                       row_offset=self.row_off[b:b + 2], status=self.status, cap=self.caps[0])
+                       row_offset=self.row_off[b:b + 2], status=self.status, cap=self.caps[0],
+                       n_dev=None if n_dev is None else n_dev[b:b + 1])
         self._seg("voxelize", e0)
 
     def _numpts(self):
@@ -199,6 +210,13 @@ class InferencePlan:
         """All 7 rulebooks + 3 next-level hash tables.  They depend only on voxel COORDINATES, so they are issued on
         a side HIP stream and overlap the feature path; `self.rb_ev[key]` fires when a rulebook is ready."""
         B = self.B
+        if self.pyr is not None:
+            for lvl in range(4):
+                self.pyr.build(lvl, lvl + 1)            # level 0: memsets + hash; l >= 1: ordered emit of level l; tables
+                self.rb_ev["subm%d" % lvl].record()
+                if lvl > 0:
+                    self.rb_ev["down%d" % (lvl - 1)].record()
+            return
         self.tables[0].build(self.idx[0], self.n[0], self.shapes[0], B, self.status)
         for lvl in range(4):
             K.rulebook_subm(self.idx[lvl], self.n[lvl], self.caps[lvl], self.shapes[lvl], B, self.tables[lvl],
@@ -211,7 +229,7 @@ class InferencePlan:
                 self.rb_ev["down%d" % lvl].record()
                 self.tables[lvl + 1].build(self.idx[lvl + 1], self.n[lvl + 1], self.shapes[lvl + 1], B, self.status)
 
-    def backbone(self, keep_middle=False, anchors_mask=None):
+    def backbone(self, keep_middle=False, anchors_mask=None, densify=True):
         main = torch.cuda.current_stream(self.dev)
         e0 = self._ev() if self.prof is not None else None
         if self.overlap:
@@ -242,8 +260,10 @@ class InferencePlan:
             cur ^= 1
         self.sp_out = x
         self._seg("sparse", e0)
+        if not densify:
+            return
         e1 = self._ev() if self.prof is not None else None
-        K.densify(x, self.idx[3], self.n[3], self.caps[3], self.shapes[3], B := self.B, 1, self.dense)
+        K.densify(x, self.idx[3], self.n[3], self.caps[3], self.shapes[3], self.B, 1, self.dense)
         self._seg("densify", e1)
 
     def bev_and_heads(self):
@@ -328,14 +348,63 @@ class InferencePlan:
 
     def run_from_points(self, clouds, anchors_mask=None):
         """One frame batch, raw device point clouds in -> device detection buffers out (no host sync)."""
-        self.voxelize(clouds)
-        self.backbone(anchors_mask=anchors_mask)
-        return self._tail(anchors_mask)
+        with K.ws_scope(self._wsid):
+            self.voxelize(clouds)
+            self.backbone(anchors_mask=anchors_mask)
+            return self._tail(anchors_mask)
 
     def run_from_voxels(self, voxel_feats, coors4, anchors_mask=None):
-        self.load_voxels(voxel_feats, coors4)
-        self.backbone(anchors_mask=anchors_mask)
-        return self._tail(anchors_mask)
+        with K.ws_scope(self._wsid):
+            self.load_voxels(voxel_feats, coors4)
+            self.backbone(anchors_mask=anchors_mask)
+            return self._tail(anchors_mask)
+
+    # ---- hipGraph: the whole frame as ONE launch ---------------------------------------------------------
+    def capture(self, points_cap, ndim=4, stages=("voxelize", "backbone", "tail")):
+        """Capture the frame (raw points -> detections, side stream included) into a hipGraph.  Input staging:
+        `self.pts_in[b]` [points_cap, ndim] f32 and `self.npts` int32 [B]; `run_graph(clouds)` fills them and replays.
+        `stages` lets a caller capture a sub-range (e.g. only the sparse backbone for a roofline measurement)."""
+        dev = self.dev
+        self.pts_cap = int(points_cap)
+        self.pts_in = [torch.zeros(self.pts_cap, ndim, dtype=torch.float32, device=dev) for _ in range(self.B)]
+        self.npts = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        assert self.prof is None, "per-stage event timing and graph capture exclude each other"
+
+        def frame():
+            with K.ws_scope(self._wsid):
+                if "voxelize" in stages:
+                    self.voxelize(self.pts_in, n_dev=self.npts)
+                if "backbone" in stages:
+                    self.backbone()
+                elif "sparse" in stages:              # rulebooks + the 14 sparse convs only (roofline measurement)
+                    self.backbone(densify=False)
+                if "tail" in stages:
+                    self._tail(None)
+                elif self.overlap:
+                    torch.cuda.current_stream(self.dev).wait_event(self.mask_ev)      # join the side stream
+
+        # capture needs a non-default stream (the legacy null stream cannot be captured)
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap):
+            frame()                               # warm-up: every workspace / lazily created event exists
+            cap.synchronize()
+            self.graph = K.Graph().capture(frame)
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        return self.graph
+
+    def stage_inputs(self, clouds):
+        for b, pts in enumerate(clouds or ()):
+            n = min(pts.shape[0], self.pts_cap)
+            self.pts_in[b][:n].copy_(pts[:n], non_blocking=True)
+            self.npts[b:b + 1].fill_(n)
+
+    def run_graph(self, clouds=None):
+        """Replay the captured frame (after staging `clouds`, unless the caller filled pts_in / npts itself)."""
+        if clouds is not None:
+            self.stage_inputs(clouds)
+        self.graph.launch()
+        return self.det
 
     def results(self):
         """The only host sync of a frame: D2H of the (small) detection buffers, like

@@ -75,30 +75,7 @@ def rand_bev_boxes(rng, k, spread=12.0):
     return np.stack([x - w / 2, y - l / 2, x + w / 2, y + l / 2, a], 1).astype(np.float32)
 
 
-def randomize_detector(model, seed=0, cls_bias=-2.0):
-    """Seeded weights + randomised BN running stats (so BN folding is exercised) + a negative cls bias so that
-    ~10^2 anchors pass the 0.1 guided-anchor threshold."""
-    g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            if p.dim() >= 2:
-                fan_in = p[0].numel() if p.dim() == 4 else int(np.prod(p.shape[:-1]))
-                if p.dim() == 5:
-                    fan_in = int(np.prod(p.shape[:4])) // 3          # sparse kernels are mostly empty
-                p.copy_(torch.randn(p.shape, generator=g) * (2.0 / max(fan_in, 1)) ** 0.5)
-            elif name.endswith("bias"):
-                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
-            else:
-                p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.75)
-        for name, b in model.named_buffers():
-            if name.endswith("running_mean"):
-                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
-            elif name.endswith("running_var"):
-                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
-        model.rpn_head.conv_cls.bias.add_(cls_bias)
-        model.rpn_head.conv_box.weight.mul_(0.05)          # keep decoded boxes close to their anchors
-        model.rpn_head.conv_box.bias.mul_(0.5)
-    return model
+randomize_detector = synth.randomize_detector          # product-side helper (bench.py must not import this module)
 
 
 def oracle_params(sd):

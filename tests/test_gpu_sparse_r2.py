@@ -1,0 +1,160 @@
+"""-m gpu parity of the round-2 sparse path: fused rulebook pyramid, gather-GEMM-scatter sparse conv (both row-slice
+sizes + the legacy register-stationary kernel), device-side point count of the voxelizer, hipGraph replay of a frame."""
+import numpy as np
+import pytest
+import torch
+
+import sassd
+from sassd import kernels as K, synth
+from oracle import clib, nets as onets, rulebook as orb
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _level0(name="k21", seed=0, batch=1):
+    idx = []
+    for b in range(batch):
+        _, c, _ = clib.points_to_voxel(H.frame(name, seed + b), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 20000)
+        idx.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+    return np.concatenate(idx, 0)
+
+
+@pytest.mark.parametrize("batch,staged", [(1, False), (2, True), (8, False)])
+def test_rulebook_pyramid_bit_exact(dev, batch, staged):
+    """All seven VxNet rulebooks + the three down-sampled coordinate sets from ONE pyramid build, bit-exact against
+    the oracle (same bar as the per-op chain); batch 8 exercises the chained scan past the resident-grid size."""
+    idx0 = _level0("k21" if batch < 8 else "k17", 0, batch)
+    shape = (40, 1600, 1408)
+    n0 = len(idx0)
+    caps = [n0 + 11] + [2 * n0 + 64] * 3
+    i32 = torch.int32
+    idx = [torch.zeros(c, 4, dtype=i32, device=dev) for c in caps]
+    idx[0][:n0] = torch.from_numpy(idx0).to(dev)
+    n = [torch.tensor([n0 if l == 0 else -7], dtype=i32, device=dev) for l in range(4)]
+    subm = [torch.full((c, 27), -5, dtype=i32, device=dev) for c in caps]
+    down = [None] + [torch.full((c, 27), -5, dtype=i32, device=dev) for c in caps[1:]]
+    st = K.new_status(dev)
+    pyr = K.RulebookPyramid(idx, n, caps, shape, batch, subm, down, st)
+    for rep in range(2):                       # the second build checks that the workspace reset is complete
+        if staged:
+            for l in range(4):
+                pyr.build(l, l + 1)
+        else:
+            pyr.build()
+    torch.cuda.synchronize()
+    assert int(st.item()) == 0
+    ref_idx, ref_shape = idx0, shape
+    for l in range(4):
+        m = int(n[l].item())
+        assert m == len(ref_idx), (l, m, len(ref_idx))
+        assert np.array_equal(idx[l][:m].cpu().numpy(), ref_idx), "coordinates level %d" % l
+        _, onbr = orb.subm_rulebook(ref_idx, ref_shape)
+        assert np.array_equal(subm[l][:m].cpu().numpy(), onbr), "subm level %d" % l
+        if l < 3:
+            nxt_idx, nbr_d, nxt_shape = orb.conv_rulebook(ref_idx, ref_shape, batch)
+            torch.cuda.synchronize()
+            md = int(n[l + 1].item())
+            assert md == len(nxt_idx)
+            assert np.array_equal(down[l + 1][:md].cpu().numpy(), nbr_d), "down level %d" % l
+            ref_idx, ref_shape = nxt_idx, nxt_shape
+    assert ref_shape == (5, 200, 176)
+
+
+def test_rulebook_pyramid_overflow_flag(dev):
+    idx0 = _level0("small", 3, 1)
+    n0 = len(idx0)
+    caps = [n0, n0 // 4, n0, n0]                     # level 1 cannot hold its rows
+    i32 = torch.int32
+    idx = [torch.zeros(c, 4, dtype=i32, device=dev) for c in caps]
+    idx[0][:n0] = torch.from_numpy(idx0).to(dev)
+    n = [torch.tensor([n0], dtype=i32, device=dev)] + [torch.zeros(1, dtype=i32, device=dev) for _ in range(3)]
+    subm = [torch.zeros(c, 27, dtype=i32, device=dev) for c in caps]
+    down = [None] + [torch.zeros(c, 27, dtype=i32, device=dev) for c in caps[1:]]
+    st = K.new_status(dev)
+    K.RulebookPyramid(idx, n, caps, (40, 1600, 1408), 1, subm, down, st).build()
+    torch.cuda.synchronize()
+    assert int(st.item()) & 1 and int(n[1].item()) == caps[1]
+
+
+@pytest.mark.parametrize("mode", ["rw64", "rw128", "legacy"])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (32, 16), (64, 32)])
+def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
+    """subm and strided gather tables, ragged row counts (not multiples of the slice), every forward / data-gradient
+    shape, against the CPU oracle; bar 2e-4 * max|y| (fp32 sums in a different order)."""
+    flags = {"rw64": 64 << 16, "rw128": 128 << 16, "legacy": 256}[mode]
+    if mode == "legacy" and (cin, cout) in ((32, 16), (64, 32)):
+        pytest.skip("covered by the backward tests")
+    idx = _level0("small", 1)
+    shape = (40, 1600, 1408)
+    idx1, nbr_d1, shape1 = orb.conv_rulebook(idx, shape, 1)
+    idx2, nbr_d2, shape2 = orb.conv_rulebook(idx1, shape1, 1)
+    _, nbr_s = orb.subm_rulebook(idx2, shape2)
+    K.debug_set_spconv(flags)
+    try:
+        for nbr, n_in in ((nbr_s, len(idx2)), (nbr_d2, len(idx1))):
+            n = len(nbr)
+            g = torch.Generator().manual_seed(cin * 100 + cout)
+            x = torch.randn(n_in, cin, generator=g)
+            w = torch.randn(27, cin, cout, generator=g) * 0.2
+            scale = torch.rand(cout, generator=g) + 0.5
+            shift = torch.randn(cout, generator=g) * 0.1
+            raw = onets.sparse_conv(x, nbr, w)
+            ref = torch.relu(raw * scale + shift)
+            cap = n + 37
+            nb = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+            nb[:n] = torch.from_numpy(nbr).to(dev)
+            nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+            wp = K.spconv_pack_weight(w.to(dev))
+            y = torch.full((cap, cout), 7.0, device=dev)
+            K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout, scale.to(dev), shift.to(dev), True, y)
+            tol = 2e-4 * max(1.0, raw.abs().max().item())
+            err = (y[:n].cpu() - ref).abs().max().item()
+            assert err < tol, (mode, err)
+            assert bool((y[n:] == 7.0).all()), "rows past the device row count must stay untouched"
+            y2 = K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout)
+            assert (y2[:n].cpu() - raw).abs().max().item() < tol
+    finally:
+        K.debug_set_spconv(0)
+
+
+def test_spconv_empty_and_tiny(dev):
+    """0 rows and fewer rows than one MFMA tile."""
+    for n in (0, 1, 5):
+        cap = 64
+        x = torch.randn(max(n, 1), 32, device=dev)
+        nb = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+        for r in range(n):
+            nb[r, 13] = r
+            if r + 1 < n:
+                nb[r, 14] = r + 1
+        w = torch.randn(27, 32, 32, device=dev) * 0.1
+        y = torch.full((cap, 32), 3.0, device=dev)
+        K.spconv_fwd(x, nb, torch.tensor([n], dtype=torch.int32, device=dev), cap, K.spconv_pack_weight(w), 27, 32, 32,
+                     None, None, False, y)
+        torch.cuda.synchronize()
+        assert bool((y[n:] == 3.0).all())
+        if n:
+            ref = x[:n] @ w[13]
+            ref[:n - 1] += x[1:n] @ w[14]
+            assert (y[:n] - ref).abs().max().item() < 1e-4
+
+
+def test_voxelize_device_count(dev):
+    """sassd_voxelize_dev on a capacity-sized staging buffer == sassd_voxelize on the exact cloud (bit-exact)."""
+    pts = H.frame("k21", 3)
+    p = torch.from_numpy(pts).to(dev)
+    ref = K.voxelize(p, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 20000, coors_cols=4)
+    stage = torch.full((30000, 4), 1e9, device=dev)
+    stage[:len(pts)] = p
+    stage[len(pts):len(pts) + 50] = p[:50]            # garbage past the count must be ignored
+    ndev = torch.tensor([len(pts)], dtype=torch.int32, device=dev)
+    st = K.new_status(dev)
+    got = K.voxelize(stage, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 20000, coors_cols=4, n_dev=ndev, status=st)
+    m = int(ref["voxel_num"].item())
+    assert int(got["voxel_num"].item()) == m and int(st.item()) == 0
+    for k in ("coors", "num_points", "mean", "voxels"):
+        assert torch.equal(got[k][:m], ref[k][:m]), k
+    ndev.fill_(0)
+    got = K.voxelize(stage, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 20000, coors_cols=4, n_dev=ndev)
+    assert int(got["voxel_num"].item()) == 0

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
-"""Ablation timing of the 64->64 submanifold sparse conv on a K21 frame (debug switches in spconv.hip):
-bit0 no gather loads, bit1 no LDS scatter-accumulate, bit2 no MFMA, bit3 no weight-fragment loads."""
-import ctypes
+"""Per-layer timing + ablation of the sparse path on a synthetic frame batch (debug switches of spconv.hip):
+bit0 no gather loads, bit1 no LDS scatter-add, bit2 no MFMA, bit3 no weight loads, bit8 legacy register-stationary
+kernel, bits 16+ row-slice size.  Also times the rulebook build (fused pyramid vs the per-op chain).
+
+  python tools/ablate_spconv.py [--config car|multi|waymo] [--batch B] [--ablate]
+"""
+import argparse
 import os
 import sys
 
@@ -9,33 +13,80 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import sassd  # noqa: E402
-from sassd import _C, kernels as K, synth  # noqa: E402
-import bench  # noqa: E402
+from sassd import kernels as K, synth  # noqa: E402
 from sassd.pipeline import InferencePlan  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="car")
+ap.add_argument("--batch", type=int, default=0)
+ap.add_argument("--ablate", action="store_true")
+args = ap.parse_args()
+
 dev = torch.device("cuda:0")
-model, an, bv, cal = bench.build_model(0)
-plan = InferencePlan(model.state_dict(), batch_size=1, anchors=an, anchors_bv=bv, device=dev)
-plan.run_from_points([torch.from_numpy(synth.k21(0)).to(dev)])
-torch.cuda.synchronize()
-lib = _C.lib()
-lib._handle  # noqa
-setdbg = ctypes.CDLL(_C.LIB_PATH).sassd_debug_set_spconv
-kind, cin, cout, key, wp, scale, shift = plan.sp[12]      # conv3.2 (subm3, 64->64)
-x = plan.feat[0].clone()
-y = torch.empty_like(x)
-for lvl, key in ((3, "subm3"), (2, "subm2")):
-    for flags in (0,):
-        setdbg(flags)
-        for _ in range(3):
-            K.spconv_fwd(x, plan.nbr[key], plan.n[lvl], plan.caps[lvl], wp, 27, 64, 64, scale, shift, True, y)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            K.spconv_fwd(x, plan.nbr[key], plan.n[lvl], plan.caps[lvl], wp, 27, 64, 64, scale, shift, True, y)
-        e1.record()
-        torch.cuda.synchronize()
-        print("%s flags=%2d  %.1f us" % (key, flags, e0.elapsed_time(e1) / 20 * 1e3))
-setdbg(0)
+w = synth.workload(args.config)
+B = args.batch or w["batch"]
+model, _ = synth.build_detector_for(w, 0)
+sd = model.state_dict()
+clouds = [torch.from_numpy(w["frame"](i)).to(dev) for i in range(B)]
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+plans = {f: InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["anchors_bv"], device=dev,
+                          fused_rulebooks=f, overlap=False, **w["plan"]) for f in (True, False)}
+for f, plan in plans.items():
+    plan.run_from_points(clouds)
+    torch.cuda.synchronize()
+    assert int(plan.status.item()) == 0
+    with K.ws_scope(plan._wsid):
+        print("rulebooks %-9s %8.1f us   (rows %s)" % ("fused" if f else "per-op", timeit(plan.rulebooks),
+                                                       [int(t.item()) for t in plan.n]))
+plan = plans[True]
+work = plan.sparse_work()
+print("pairs", work["pairs"], "bytes_gs %.1f MB" % (work["bytes_gs"] / 1e6))
+
+MODES = [("legacy", 256), ("gs rw64", 64 << 16), ("gs rw128", 128 << 16)]
+layers = []
+lvl = 0
+for kind, cin, cout, key, wp, scale, shift in plan.sp:
+    if kind == "down":
+        lvl += 1
+    layers.append((kind, cin, cout, key, wp, scale, shift, lvl))
+seen = set()
+tot = {m: 0.0 for m, _ in MODES}
+for kind, cin, cout, key, wp, scale, shift, lvl in layers:
+    nin = plan.caps[lvl - 1] if kind == "down" else plan.caps[lvl]
+    x = torch.randn(nin, cin, device=dev)
+    y = torch.empty(plan.caps[lvl], cout, device=dev)
+    nbr = plan.nbr[key] if key else None
+    k = 27 if key else 1
+    line = "%-5s %-6s %2d->%2d rows %7d:" % (kind, key or "-", cin, cout, work["n"][lvl])
+    for mname, flags in MODES:
+        K.debug_set_spconv(flags)
+        us = timeit(lambda: K.spconv_fwd(x, nbr, plan.n[lvl], plan.caps[lvl], wp, k, cin, cout, scale, shift, True, y))
+        tot[mname] += us
+        line += "  %s %7.1f us" % (mname, us)
+    print(line)
+    if args.ablate and (kind, key, cin) not in seen and cin >= 16 and key:
+        seen.add((kind, key, cin))
+        for mname, base in MODES[1:]:
+            s = "        ablation %-8s" % mname
+            for bit, nm in ((1, "no-gather"), (2, "no-scatter"), (4, "no-mfma"), (8, "no-wload"), (15, "none-of-them")):
+                K.debug_set_spconv(base | bit)
+                s += "  %s %6.1f" % (nm, timeit(lambda: K.spconv_fwd(x, nbr, plan.n[lvl], plan.caps[lvl], wp, k, cin,
+                                                                      cout, scale, shift, True, y)))
+            print(s)
+K.debug_set_spconv(0)
+print("sum of 14 layers:", {m: round(v, 1) for m, v in tot.items()}, "us;  bytes_gs GB/s:",
+      {m: round(work["bytes_gs"] / v / 1e3, 1) for m, v in tot.items()})

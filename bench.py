@@ -57,7 +57,9 @@ def build_model(seed=0, dev=None, config="car"):
     w = synth.workload(config)
     model, cfg = synth.build_detector_for(w, seed)
     if dev is not None:
-        cal_cloud = synth.lidar64(11)[:3000] if config != "waymo" else synth.waymo_synth(11)[:30000]
+        # calibration frame: a sparse KITTI crop (3000 pts) as in the parity tests; a full Waymo-scale frame (the anchor
+        # mask of a 30k-point crop would under-count the candidates of a 180k-point frame)
+        cal_cloud = synth.lidar64(11)[:3000] if config != "waymo" else w["frame"](11)
         synth.calibrate_cls_head_on_device(model, w, dev, cal_cloud, target_count=100 if config != "waymo" else 600)
     return model, w
 

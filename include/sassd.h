@@ -115,7 +115,7 @@ int sassd_rulebook_pairs(const int32_t *nbr, const int32_t *n_out_ptr, int cap_o
 
 /* Fused rulebook PYRAMID: all gather tables of a stack of `levels` resolutions (level l: SubMConv3d k=3 rulebook,
  * indice_key "subm<l>"; l-1 -> l: SparseConv3d(k=3,s=2,p=1) rulebook + output coordinates) -- the seven
- * get_indice_pairs calls of VxNet (cmn.py:147-173, 197-206) in 9 launches instead of 30.
+ * get_indice_pairs calls of VxNet (cmn.py:147-173, 197-206) in 11 kernel launches instead of 30.
  *   indices[l]  [caps[l],4] i32 (b,z,y,x): level 0 is the input, levels >= 1 are written (ascending linear order)
  *   n_ptrs[l]   device int32 row counts: level 0 is the input, levels >= 1 are written
  *   D,H,W       spatial shape of level 0; level l+1 = (dim-1)/2+1 per axis

@@ -28,6 +28,21 @@ static inline int sassd_hip(hipError_t e)
     return SASSD_OK;
 }
 
+// Opt a kernel into more than 64 KB of dynamic LDS, once per (device, kernel): the attribute is per device, so every
+// call site keeps a device bit mask (`static std::atomic<unsigned long long> done{0}`; idempotent if threads race).
+#include <atomic>
+static inline int sassd_dyn_lds(const void *fn, size_t bytes, std::atomic<unsigned long long> &done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SASSD_EHIP;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return SASSD_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { g_sassd_last_hip_error = (int)e; return SASSD_EHIP; }
+    done.fetch_or(bit, std::memory_order_release);
+    return SASSD_OK;
+}
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline unsigned next_pow2(unsigned x)

@@ -329,12 +329,10 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
     P.relu = relu;
     P.dbg = g_wino_dbg;
     const size_t lds = (size_t)(2 * kRawBuf) * sizeof(float);                       // 147 456 B
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)conv2d_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return sassd_launch_status();
-        attr_done = true;
+    {
+        static std::atomic<unsigned long long> attr_done{0};
+        const int rc = sassd_dyn_lds((const void *)conv2d_wino_kernel, lds, attr_done);      // per device, thread safe
+        if (rc) return rc;
     }
     P.ngrp = cdiv(P.tiles, kNT);
     const int per_xcd = cdiv(cdiv(P.ngrp, 8), kGb) * kGb;       // groups per XCD, padded to whole blocks

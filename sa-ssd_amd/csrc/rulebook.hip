@@ -192,21 +192,47 @@ inline bool lin_fits(int D, int H, int W, int B) { return (double)D * H * W * B 
 
 // ------------------------------------------------------------------------------------------------------------------
 // Fused rulebook pyramid: every gather table of a submanifold / strided-conv stack (level l: SubMConv3d rulebook;
-// l -> l+1: SparseConv3d(k3,s2,p1) rulebook + the output coordinates) in 2 + 2*(L-1) + 1 launches and two memsets,
-// instead of the per-op chain above (30 launches for the four VxNet levels of cmn.py:147-173).
-//   rb_level_kernel   one thread per (row of level l, offset k): the subm table of level l (hash of level l), the
-//                     strided table INTO level l (hash of level l-1), and -- threads k < 8 -- the marks of the
-//                     row's <= 8 strided outputs in the bitmap of level l+1.  All three only read finished tables.
-//   rb_emit_kernel    single-pass ordered compaction of the bitmap: workgroups take a ticket (start order), publish
-//                     their popcount in a tagged 64-bit word and sum their predecessors' words (chained scan; a
-//                     ticket only waits for tickets that are already running, so any grid size makes progress),
-//                     then emit the coordinates in ascending linear order AND insert them into the next level's hash.
+// l -> l+1: SparseConv3d(k3,s2,p1) rulebook + the output coordinates) in 2 + 3*(L-1) launches and two memsets
+// (11 kernel launches instead of 30 for the four VxNet levels of cmn.py:147-173).
+//   coordinate -> row lookup   level 0 (voxelizer rows, first-touch order): the open-addressing hash.  Levels >= 1
+//                     are emitted in ascending linear order, so their occupancy BITMAP plus a per-word rank array is a
+//                     perfect index: row(c) = rank[c >> 5] + popcount(bitmap[c >> 5] below bit c) -- two independent
+//                     loads, no probing, no inserts (hash inserts from the emit kernel were a chain of dependent
+//                     atomic round trips per thread: 50-110 us per level).
+//   rb_level_kernel   one thread per (row of level l, offset k): the subm table of level l, the strided table INTO
+//                     level l (lookup in level l-1) and -- threads k < 8 -- the marks of the row's <= 8 strided
+//                     outputs in the bitmap of level l+1.  All three only read finished structures.
+//   rb_count_kernel   set bits per 256-word bitmap block + per 64-block super-block.
+//   rb_emit_kernel    ordered compaction of the bitmap: every workgroup sums the (super-)counters before it (a few
+//                     hundred L2-resident ints; no single-workgroup scan pass and no inter-workgroup waiting -- a
+//                     chained single-pass scan with tagged words measured 70-150 us here), writes the rank array and
+//                     emits its coordinates in ascending linear order: one word per thread, the word's first cell
+//                     decomposed once, its <= 32 set bits walked with carries.
 // ------------------------------------------------------------------------------------------------------------------
+struct Lookup {
+    const unsigned *bitmap;    // nullptr -> hash
+    const int *rank;
+    HashView hv;
+    int cap;                   // rows past the level's capacity do not exist
+};
+
+__device__ __forceinline__ int lookup_row(const Lookup &L, unsigned key)
+{
+    if (L.bitmap) {
+        const unsigned w = L.bitmap[key >> 5], b = 1u << (key & 31);
+        if (!(w & b)) return -1;
+        const int r = L.rank[key >> 5] + __popc(w & (b - 1));
+        return r < L.cap ? r : -1;
+    }
+    const int e = hash_find(L.hv.keys, L.hv.mask, key);
+    return e >= 0 ? L.hv.vals[e] : -1;
+}
+
 struct LevelArgs {
     const int32_t *idx; const int32_t *n_ptr; int cap; int D, H, W;
-    HashView hv;               // this level's table (complete)
+    Lookup cur;                // this level's index (complete)
     int32_t *nbr_subm;         // [cap,27] or nullptr
-    HashView hv_prev;          // previous (finer) level's table
+    Lookup prev;               // previous (finer) level's index
     int pD, pH, pW;            // previous level's dims
     int32_t *nbr_down;         // [cap,27] strided table into this level, or nullptr
     unsigned *bitmap_next;     // marks of level l+1's outputs, or nullptr
@@ -225,21 +251,15 @@ __global__ void __launch_bounds__(256) rb_level_kernel(LevelArgs A)
         const int z = c.y + kz - 1, y = c.z + ky - 1, x = c.w + kx - 1;
         int r = -1;
         if (k == 13) r = row;
-        else if (z >= 0 && z < A.D && y >= 0 && y < A.H && x >= 0 && x < A.W) {
-            const unsigned key = (((unsigned)c.x * A.D + z) * A.H + y) * A.W + x;
-            const int e = hash_find(A.hv.keys, A.hv.mask, key);
-            if (e >= 0) r = A.hv.vals[e];
-        }
+        else if (z >= 0 && z < A.D && y >= 0 && y < A.H && x >= 0 && x < A.W)
+            r = lookup_row(A.cur, (((unsigned)c.x * A.D + z) * A.H + y) * A.W + x);
         A.nbr_subm[t] = r;
     }
     if (A.nbr_down) {
         const int z = 2 * c.y - 1 + kz, y = 2 * c.z - 1 + ky, x = 2 * c.w - 1 + kx;
         int r = -1;
-        if (z >= 0 && z < A.pD && y >= 0 && y < A.pH && x >= 0 && x < A.pW) {
-            const unsigned key = (((unsigned)c.x * A.pD + z) * A.pH + y) * A.pW + x;
-            const int e = hash_find(A.hv_prev.keys, A.hv_prev.mask, key);
-            if (e >= 0) r = A.hv_prev.vals[e];
-        }
+        if (z >= 0 && z < A.pD && y >= 0 && y < A.pH && x >= 0 && x < A.pW)
+            r = lookup_row(A.prev, (((unsigned)c.x * A.pD + z) * A.pH + y) * A.pW + x);
         A.nbr_down[t] = r;
     }
     if (A.bitmap_next && k < 8) {
@@ -253,69 +273,70 @@ __global__ void __launch_bounds__(256) rb_level_kernel(LevelArgs A)
     }
 }
 
-__global__ void __launch_bounds__(256) rb_emit_kernel(const unsigned *__restrict__ bitmap, int nwords, int nblk,
-                                                      unsigned long long *state, unsigned *ticket, int OD, int OH,
-                                                      int OW, int cap_out, int32_t *__restrict__ out_idx,
-                                                      int32_t *n_out_ptr, HashView hv_next, int32_t *status)
+constexpr int kEmitWords = 256;          // bitmap words per workgroup of the pyramid's count / emit kernels (1 / thread)
+constexpr int kSupShift = 6;             // super-counter = 64 blocks
+
+__global__ void __launch_bounds__(256) rb_count_kernel(const unsigned *__restrict__ bitmap, int nwords,
+                                                       int *__restrict__ bcnt, int *__restrict__ sup)
 {
     __shared__ int wsum[17];
-    __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = (int)atomicAdd(ticket, 1u);
-    __syncthreads();
-    const int tk = s_ticket;                         // logical block index = start order
-    const int base = tk * kWordsPerBlock + threadIdx.x * 4;
-    unsigned w[4];
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { w[k] = (base + k < nwords) ? bitmap[base + k] : 0u; s += __popc(w[k]); }
+    const int i = blockIdx.x * kEmitWords + threadIdx.x;
+    const int s = i < nwords ? __popc(bitmap[i]) : 0;
     int tot;
-    const int ex = block_exclusive_scan(s, wsum, &tot);
-    if (threadIdx.x == 0)
-        __hip_atomic_store(&state[tk], (1ull << 32) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int part = 0;
-    for (int j = threadIdx.x; j < tk; j += 256) {
-        unsigned long long v;
-        for (;;) {
-            v = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v >> 32) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        part += (int)(unsigned)v;
+    block_exclusive_scan(s, wsum, &tot);
+    if (threadIdx.x == 0) {
+        bcnt[blockIdx.x] = tot;
+        if (tot) atomicAdd(&sup[blockIdx.x >> kSupShift], tot);
     }
+}
+
+__global__ void __launch_bounds__(256) rb_emit_kernel(const unsigned *__restrict__ bitmap, int nwords, int nblk,
+                                                      const int *__restrict__ bcnt, const int *__restrict__ sup,
+                                                      int *__restrict__ rank, int OD, int OH, int OW, int cap_out,
+                                                      int32_t *__restrict__ out_idx, int32_t *n_out_ptr,
+                                                      int32_t *status)
+{
+    __shared__ int wsum[17];
+    const int blk = blockIdx.x;
+    // rows emitted before this block = whole super-blocks + the blocks of its own super-block before it
+    const int nsup = blk >> kSupShift;
+    int part = 0;
+    for (int j = threadIdx.x; j < nsup; j += 256) part += sup[j];
+    if ((int)threadIdx.x < blk - (nsup << kSupShift)) part += bcnt[(nsup << kSupShift) + threadIdx.x];
     int before;
-    block_exclusive_scan(part, wsum, &before);       // block total of the predecessors' counts
+    block_exclusive_scan(part, wsum, &before);
+    const int wi = blk * kEmitWords + threadIdx.x;
+    unsigned m = wi < nwords ? bitmap[wi] : 0u;
+    int tot;
+    const int ex = block_exclusive_scan(__popc(m), wsum, &tot);
     int row = before + ex;
-    if (tk == nblk - 1 && threadIdx.x == 0) {
+    if (wi < nwords) rank[wi] = row;                  // rank of a word = set bits before it
+    if (blk == nblk - 1 && threadIdx.x == 0) {
         int total = before + tot;
         if (total > cap_out) { if (status) atomicOr(status, SASSD_ST_VOXEL_OVERFLOW); total = cap_out; }
         *n_out_ptr = total;
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        unsigned m = w[k];
-        while (m) {
-            const int bit = __ffs(m) - 1;
-            m &= m - 1;
-            if (row < cap_out) {
-                const unsigned key = (unsigned)(base + k) * 32u + bit;
-                unsigned lin = key;
-                const int x = lin % OW; lin /= OW;
-                const int y = lin % OH; lin /= OH;
-                const int z = lin % OD; lin /= OD;
-                ((int4 *)out_idx)[row] = make_int4((int)lin, z, y, x);
-                const int e = hash_insert(hv_next.keys, hv_next.mask, key);
-                if (e < 0) { if (status) atomicOr(status, SASSD_ST_HASH_FULL); }
-                else hv_next.vals[e] = row;
-            }
-            ++row;
-        }
+    if (!m) return;
+    // coordinates of the word's first cell once (three divisions), then walk the <= 32 set bits with carries
+    unsigned lin = (unsigned)wi * 32u;
+    int x = lin % OW; lin /= OW;
+    int y = lin % OH; lin /= OH;
+    int z = lin % OD; lin /= OD;
+    int b = (int)lin, prev = 0;
+    while (m) {
+        const int bit = __ffs(m) - 1;
+        m &= m - 1;
+        x += bit - prev; prev = bit;
+        while (x >= OW) { x -= OW; if (++y == OH) { y = 0; if (++z == OD) { z = 0; ++b; } } }
+        if (row < cap_out) ((int4 *)out_idx)[row] = make_int4(b, z, y, x);
+        ++row;
     }
 }
 
 constexpr int kMaxLevels = 8;
 
 struct PyramidLayout {
-    size_t keys[kMaxLevels], vals[kMaxLevels], bitmap[kMaxLevels], state[kMaxLevels], ticket;
+    size_t keys, vals, bitmap[kMaxLevels], bcnt[kMaxLevels], sup[kMaxLevels], rank[kMaxLevels];
     size_t keys_end, zero_begin, zero_end, total;
     int nwords[kMaxLevels], nblk[kMaxLevels];
     int dims[kMaxLevels][3];
@@ -325,22 +346,23 @@ bool pyramid_layout(int levels, const int *caps, int D, int H, int W, int B, Pyr
 {
     if (levels < 1 || levels > kMaxLevels) return false;
     size_t o = 0;
-    for (int l = 0; l < levels; ++l) { L.keys[l] = o; o += align_up((size_t)hash_cap(caps[l]) * 4, 256); }
+    L.keys = o; o += align_up((size_t)hash_cap(caps[0]) * 4, 256);          // level-0 hash only
     L.keys_end = o;
-    for (int l = 0; l < levels; ++l) { L.vals[l] = o; o += align_up((size_t)hash_cap(caps[l]) * 4, 256); }
+    L.vals = o; o += align_up((size_t)hash_cap(caps[0]) * 4, 256);
     L.zero_begin = o;
     L.dims[0][0] = D; L.dims[0][1] = H; L.dims[0][2] = W;
+    if (!lin_fits(D, H, W, B)) return false;
     for (int l = 0; l + 1 < levels; ++l) {
         for (int a = 0; a < 3; ++a) L.dims[l + 1][a] = (L.dims[l][a] - 1) / 2 + 1;
-        if (!lin_fits(L.dims[l][0], L.dims[l][1], L.dims[l][2], B)) return false;
         const size_t cells = (size_t)B * L.dims[l + 1][0] * L.dims[l + 1][1] * L.dims[l + 1][2];
         L.nwords[l] = (int)((cells + 31) / 32);
-        L.nblk[l] = cdiv(L.nwords[l], kWordsPerBlock);
+        L.nblk[l] = cdiv(L.nwords[l], kEmitWords);
         L.bitmap[l] = o; o += align_up((size_t)L.nwords[l] * 4, 256);
-        L.state[l] = o;  o += align_up((size_t)L.nblk[l] * 8, 256);
+        L.sup[l] = o;    o += align_up((size_t)((L.nblk[l] >> kSupShift) + 1) * 4, 256);
     }
-    L.ticket = o; o += 256;
     L.zero_end = o;
+    for (int l = 0; l + 1 < levels; ++l) { L.bcnt[l] = o; o += align_up((size_t)L.nblk[l] * 4, 256); }
+    for (int l = 0; l + 1 < levels; ++l) { L.rank[l] = o; o += align_up((size_t)L.nwords[l] * 4, 256); }
     L.total = o;
     return true;
 }
@@ -465,32 +487,40 @@ extern "C" int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32
     }
     char *w = (char *)workspace;
     int rc;
-    HashView hv[kMaxLevels];
+    Lookup look[kMaxLevels];
     for (int l = 0; l < levels; ++l) {
-        hv[l].keys = (unsigned *)(w + L.keys[l]);
-        hv[l].vals = (int *)(w + L.vals[l]);
-        hv[l].mask = hash_cap(caps[l]) - 1;
+        look[l].cap = caps[l];
+        if (l == 0) {
+            look[l].bitmap = nullptr; look[l].rank = nullptr;
+            look[l].hv.keys = (unsigned *)(w + L.keys); look[l].hv.vals = (int *)(w + L.vals);
+            look[l].hv.mask = hash_cap(caps[0]) - 1;
+        } else {
+            look[l].bitmap = (const unsigned *)(w + L.bitmap[l - 1]);
+            look[l].rank = (const int *)(w + L.rank[l - 1]);
+            look[l].hv = look[0].hv;
+        }
     }
     for (int l = level_begin; l < level_end; ++l) {
         if (l == 0) {
             if ((rc = sassd_hip(hipMemsetAsync(w, 0xFF, L.keys_end, stream)))) return rc;
-            if ((rc = sassd_hip(hipMemsetAsync(w + L.zero_begin, 0, L.zero_end - L.zero_begin, stream)))) return rc;
+            if (L.zero_end > L.zero_begin &&
+                (rc = sassd_hip(hipMemsetAsync(w + L.zero_begin, 0, L.zero_end - L.zero_begin, stream)))) return rc;
             hipLaunchKernelGGL(hash_build_kernel, dim3(cdiv(caps[0], 256)), dim3(256), 0, stream, indices[0],
-                               n_ptrs[0], caps[0], L.dims[0][0], L.dims[0][1], L.dims[0][2], hv[0], status);
+                               n_ptrs[0], caps[0], L.dims[0][0], L.dims[0][1], L.dims[0][2], look[0].hv, status);
         } else {
             const int p = l - 1;
             hipLaunchKernelGGL(rb_emit_kernel, dim3(L.nblk[p]), dim3(256), 0, stream,
                                (const unsigned *)(w + L.bitmap[p]), L.nwords[p], L.nblk[p],
-                               (unsigned long long *)(w + L.state[p]), (unsigned *)(w + L.ticket) + p, L.dims[l][0],
-                               L.dims[l][1], L.dims[l][2], caps[l], indices[l], n_ptrs[l], hv[l], status);
+                               (const int *)(w + L.bcnt[p]), (const int *)(w + L.sup[p]), (int *)(w + L.rank[p]),
+                               L.dims[l][0], L.dims[l][1], L.dims[l][2], caps[l], indices[l], n_ptrs[l], status);
         }
         LevelArgs A;
         A.idx = indices[l]; A.n_ptr = n_ptrs[l]; A.cap = caps[l];
         A.D = L.dims[l][0]; A.H = L.dims[l][1]; A.W = L.dims[l][2];
-        A.hv = hv[l];
+        A.cur = look[l];
         A.nbr_subm = nbr_subm[l];
         const int pl = l > 0 ? l - 1 : 0;
-        A.hv_prev = hv[pl];
+        A.prev = look[pl];
         A.pD = L.dims[pl][0]; A.pH = L.dims[pl][1]; A.pW = L.dims[pl][2];
         A.nbr_down = l > 0 ? nbr_down[l] : nullptr;
         const bool last = (l + 1 == levels);
@@ -498,6 +528,10 @@ extern "C" int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32
         A.OD = last ? 1 : L.dims[l + 1][0]; A.OH = last ? 1 : L.dims[l + 1][1]; A.OW = last ? 1 : L.dims[l + 1][2];
         if (A.nbr_subm || A.nbr_down || A.bitmap_next)
             hipLaunchKernelGGL(rb_level_kernel, dim3(cdiv(caps[l] * 27, 256)), dim3(256), 0, stream, A);
+        if (!last)
+            hipLaunchKernelGGL(rb_count_kernel, dim3(L.nblk[l]), dim3(256), 0, stream,
+                               (const unsigned *)(w + L.bitmap[l]), L.nwords[l], (int *)(w + L.bcnt[l]),
+                               (int *)(w + L.sup[l]));
     }
     return sassd_launch_status();
 }

@@ -257,96 +257,137 @@ int launch_pack(const float *w, int K, float *packed, int transposed, hipStream_
 // ticket counter (heaviest offsets first: centre, faces, edges, corners):
 //   compaction   the wave scans the offset's column of the workgroup's rulebook slice (staged once in LDS), ballots
 //                the rows that have a pair and writes the (input row, local output row) list -- the M dimension of
-//                the MFMA is filled with PAIRS, ceil(n_k/16) tiles instead of RW/16 (75-85 % full at RW = 64,
-//                85-95 % at RW = 128)
-//   B operand    W[k] (Cin x Cout, pre-packed fragment order) lives in REGISTERS for the whole offset: loaded once
-//                per (workgroup, offset) straight from L2, reused by every tile of that offset
-//   A operand    pair rows gathered from HBM/L2 in fragment order, double buffered across tiles
-//   scatter      D tiles are added into the workgroup's fp32 accumulator slab in LDS with ds_add_f32 (each output
-//                row occurs at most once per offset, different offsets = different waves: LDS atomics, no barrier)
-//   epilogue     ONE barrier, then scale / shift / ReLU and coalesced 16-B row stores.
-// No barrier inside the main loop; waves of one workgroup never wait for each other until the epilogue.  fp32 adds
-// of the <= 27 offset contributions of a row arrive in a timing-dependent order (last-ulp run-to-run variation; the
-// rulebooks and voxels stay bit-exact, the parity bar on features is 1e-4).
-// Workgroup -> rows: blocks that land on the same XCD (blockIdx % 8) take one contiguous range of row slices, so
-// the gathers of neighbouring voxels hit that XCD's L2.
+//                the MFMA is filled with PAIRS: ceil(n_k/16) tiles instead of RW/16 (75-85 % full at RW = 64)
+//   W operand    W[k] (Cin x Cout, pre-packed fragment order) lives in REGISTERS for the whole offset, loaded once
+//                per (workgroup, offset) straight from L2 and double buffered: the next non-empty offset's weights are
+//                in flight while the current offset's tiles run
+//   X operand    pair rows gathered from HBM/L2 in fragment order, double buffered across tiles
+//   accumulate   every wave owns a PRIVATE fp32 slab [RW][Cout] in LDS.  The MFMA is issued transposed
+//                (D^T = W^T X^T: operands swapped), so a lane holds 4 consecutive output channels of ONE pair:
+//                the tile's C input is one ds_read_b128 per 16 channels from the pair's output row, the result one
+//                ds_write_b128 back -- no atomics (LDS float atomics measured ~2.6 cycles per LANE: a first version
+//                with ds_add_f32 into a shared slab spent 70 % of its time there), no barrier, and a row occurs at
+//                most once per offset, so lanes of one instruction never collide
+//   epilogue     ONE barrier, then the NW slabs are summed in wave order (deterministic), scale / shift / ReLU and
+//                coalesced 16-B row stores.
+// Workgroup -> rows: runs of 8 consecutive row slices go to the same XCD (blockIdx % 8), so the gathers of
+// neighbouring voxels hit that XCD's L2.
 // ------------------------------------------------------------------------------------------------------------------
 __constant__ int c_offset_order[kK] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25,
                                        0, 2, 6, 8, 18, 20, 24, 26};
 
-template <int CIN, int COUT, int RW, int NW>
-__global__ void __launch_bounds__(NW * 64)
+template <int COUT, int RW, int NW, int CS>
+constexpr size_t gs_lds_bytes() { return (size_t)(NW * RW * (COUT / CS) + RW * kK + NW * 2 * RW + 4) * 4; }
+
+// CS = output-channel split: a wave accumulates COUT/CS channels (its slab, weight registers and MFMA count shrink by
+// CS; waves of different channel groups take offsets from separate ticket counters and gather the same pair rows).
+// WPS = waves per SIMD the register allocation must allow (workgroups per CU x NW / 4).
+template <int CIN, int COUT, int RW, int NW, int CS, int WPS>
+__global__ void __launch_bounds__(NW * 64, WPS)
 spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_ptr,
                  int cap, const float *__restrict__ wp, const float *__restrict__ scale,
                  const float *__restrict__ shift, int relu, float *__restrict__ y, int dbg)
 {
     constexpr int KS = CIN / 4, NT = COUT / 16;
-    constexpr int LDA = COUT + 4;
+    constexpr int CW = COUT / CS, NTW = CW / 16;             // channels / 16-channel tiles per wave
+    constexpr int NCH = CW / 4;                              // 16-byte chunks per slab row, XOR-swizzled by the row
     constexpr int NH = RW / 64;
-    __shared__ __attribute__((aligned(16))) float acc[RW * LDA];
-    __shared__ int nbr_s[RW * kK];
-    __shared__ __attribute__((aligned(16))) int lst_in[NW][RW];
-    __shared__ __attribute__((aligned(16))) int lst_out[NW][RW];
-    __shared__ int next_slot;
+    static_assert(NW % CS == 0 && NTW >= 1, "bad channel split");
+    extern __shared__ __attribute__((aligned(16))) float gs_lds[];
+    float *slabs = gs_lds;                                   // [NW][RW][CW]
+    int *nbr_s = (int *)(gs_lds + NW * RW * CW);             // [RW][27]
+    int *lists = nbr_s + RW * kK;                            // [NW][2][RW]
+    int *next_slot = lists + NW * 2 * RW;                    // [CS]
 
-    const int n = min(*n_ptr, cap);
-    const int nslice = (n + RW - 1) / RW;
-    const int per_xcd = (nslice + 7) >> 3;
-    const int slice = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || slice >= nslice) return;      // workgroup-uniform
+    // Workgroup -> row slice: runs of 8 consecutive slices go to one XCD (blockIdx % 8), round-robin over the XCDs.  The
+    // map depends on the capacity only, so the slice's rulebook rows are requested BEFORE the device row count is
+    // known (one dependent memory round trip less on the launch's critical path; rows past the count are masked).
+    const int g = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+    const int slice = (((g >> 3) << 3) + xcd) * 8 + (g & 7);
     const int r0 = slice * RW;
-    const int rows = min(RW, n - r0);
+    const int rows_cap = min(RW, cap - r0);
+    if (rows_cap <= 0) return;                               // workgroup-uniform, host-known
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, m16 = lane & 15;
-
-    for (int i = tid; i < RW * kK; i += NW * 64) nbr_s[i] = (i < rows * kK) ? nbr[(size_t)r0 * kK + i] : -1;
-    for (int i = tid; i < RW * LDA; i += NW * 64) acc[i] = 0.f;
-    if (tid == 0) next_slot = 0;
+    const int half = wave % CS;                              // this wave's channel group
+    constexpr int NST = (RW * kK + NW * 64 - 1) / (NW * 64);
+    int stage[NST];
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int i = tid + j * NW * 64;
+        stage[j] = (i < rows_cap * kK) ? nbr[(size_t)r0 * kK + i] : -1;
+    }
+    float b0[NTW][KS], b1[NTW][KS];
+    float a0[KS], a1[KS];
+    auto load_w = [&](int k, float (&b)[NTW][KS]) {             // fragment order, 16-B pieces, coalesced
+        if (dbg & 8) return;
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) load_vec<KS>(wp + (((size_t)k * NT + half * NTW + u) * 64 + lane) * KS, b[u]);
+    };
+    // every wave starts on a fixed offset (the heaviest ones), so its weights are requested at kernel entry as well
+    int k = c_offset_order[wave / CS];
+    load_w(k, b0);
+    const int n = min(*n_ptr, cap);
+    if (r0 >= n) return;                                     // workgroup-uniform
+    const int rows = min(RW, n - r0);
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int i = tid + j * NW * 64;
+        if (i < RW * kK) nbr_s[i] = (i < rows * kK) ? stage[j] : -1;
+    }
+    for (int i = tid; i < NW * RW * CW / 4; i += NW * 64) ((float4 *)slabs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < CS) next_slot[tid] = NW / CS;
     __syncthreads();
 
-    int *lin = lst_in[wave], *lout = lst_out[wave];
-    float b[NT][KS];
-    float a0[KS], a1[KS];
+    float *slab = slabs + wave * RW * CW;
+    int *lin = lists + wave * 2 * RW, *lout = lin + RW;
 
-    auto fetch_a = [&](int t, float (&af)[KS]) {
-        const int in = lin[t * 16 + m16];
-        if (in >= 0 && !(dbg & 1)) load_vec<KS>(x + (size_t)in * CIN + q * KS, af);
-        else {
+    // next kernel offset (heaviest first) that has at least one pair in this workgroup's rows, or -1
+    auto grab = [&]() -> int {
+        for (;;) {
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(next_slot + half, 1);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot >= kK) return -1;
+            const int k = c_offset_order[slot];
+            bool any = false;
 #pragma unroll
-            for (int i = 0; i < KS; ++i) af[i] = 0.f;
+            for (int h = 0; h < NH; ++h) any = any || (__ballot(nbr_s[(h * 64 + lane) * kK + k] >= 0) != 0ull);
+            if (any) return k;
         }
     };
-    auto tile = [&](int t, int nk, const float (&af)[KS]) {
-        f32x4 d[NT];
+    // pair rows of tile t; the padding of the last tile points at input row 0: an invalid pair only feeds ITS OWN column
+    // of D^T, which is never written back, so no zero fill is needed
+    auto fetch_a = [&](int t, float (&af)[KS]) {
+        const int in = lin[t * 16 + m16];
+        if (!(dbg & 1)) load_vec<KS>(x + (size_t)in * CIN + q * KS, af);
+    };
+    // one tile of 16 pairs: D^T[cout = u*16 + q*4 + r][pair = m16] += W[k]^T X^T, accumulated in the pair's slab row
+    auto tile = [&](int t, int nk, const float (&af)[KS], const float (&b)[NTW][KS]) {
+        const bool valid = t * 16 + m16 < nk;
+        const int orow = lout[t * 16 + m16];
+        float *row = slab + orow * CW;
+        const int sw = orow & (NCH - 1);
+        f32x4 d[NTW];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) d[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NTW; ++u) {                      // padded pairs read slab row 0 and drop the result
+            const float4 c = *(const float4 *)(row + (((u * 4 + q) ^ sw) << 2));
+            d[u] = (f32x4){c.x, c.y, c.z, c.w};
+        }
         if (!(dbg & 4)) {
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-                for (int u = 0; u < NT; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk], b[u][kk], d[u], 0, 0, 0);
+                for (int u = 0; u < NTW; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u][kk], af[kk], d[u], 0, 0, 0);
         }
-        const int4 ol = *(const int4 *)(lout + t * 16 + q * 4);            // D[row = q*4 + reg][col = m16]
-        const int pbase = t * 16 + q * 4;
-        if (!(dbg & 2)) {
-            const int olr[4] = {ol.x, ol.y, ol.z, ol.w};
+        if (valid && !(dbg & 2)) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                if (pbase + reg < nk) {
-                    float *dst = acc + olr[reg] * LDA + m16;
-#pragma unroll
-                    for (int u = 0; u < NT; ++u) atomicAdd(dst + u * 16, d[u][reg]);
-                }
+            for (int u = 0; u < NTW; ++u)
+                *(float4 *)(row + (((u * 4 + q) ^ sw) << 2)) = make_float4(d[u][0], d[u][1], d[u][2], d[u][3]);
         }
     };
-
-    for (;;) {
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&next_slot, 1);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= kK) break;
-        const int k = c_offset_order[slot];
+    auto process = [&](int k, const float (&b)[NTW][KS]) {
         // ---- compaction of offset k over the workgroup's rows ----------------------------------------
         int nk = 0;
 #pragma unroll
@@ -359,38 +400,55 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
             nk += __popcll(mk);
         }
         nk = __builtin_amdgcn_readfirstlane(nk);
-        if (nk == 0) continue;
         const int ntile = (nk + 15) >> 4;
-        if (lane < ntile * 16 - nk) { lin[nk + lane] = -1; lout[nk + lane] = 0; }     // pad the last tile
-        // ---- W[k] -> registers (fragment order, 16-B pieces, coalesced) ------------------------------
-        if (!(dbg & 8)) {
-#pragma unroll
-            for (int u = 0; u < NT; ++u) load_vec<KS>(wp + (((size_t)k * NT + u) * 64 + lane) * KS, b[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < NT; ++u)
-#pragma unroll
-                for (int i = 0; i < KS; ++i) b[u][i] = 1.f;
-        }
+        if (lane < ntile * 16 - nk) { lin[nk + lane] = 0; lout[nk + lane] = 0; }      // pad the last tile
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own list writes precede its list reads
         fetch_a(0, a0);
         for (int t = 0; t < ntile; t += 2) {
             if (t + 1 < ntile) fetch_a(t + 1, a1);
-            tile(t, nk, a0);
+            tile(t, nk, a0, b);
             if (t + 1 < ntile) {
                 if (t + 2 < ntile) fetch_a(t + 2, a0);
-                tile(t + 1, nk, a1);
+                tile(t + 1, nk, a1, b);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // list reads done before the next offset rewrites it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // list / slab accesses retired before the lists are rewritten
+    };
+
+    {
+        bool any = false;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) any = any || (__ballot(nbr_s[(h * 64 + lane) * kK + k] >= 0) != 0ull);
+        if (!any || wave / CS >= kK) {                       // the pre-assigned offset has no pair here: take a ticket
+            k = grab();
+            if (k >= 0) load_w(k, b0);
+        }
+    }
+    while (k >= 0) {
+        int kn = grab();
+        if (kn >= 0) load_w(kn, b1);
+        process(k, b0);
+        k = kn;
+        if (k < 0) break;
+        kn = grab();
+        if (kn >= 0) load_w(kn, b0);
+        process(k, b1);
+        k = kn;
     }
     __syncthreads();
 
-    // ---- epilogue: folded BatchNorm / bias / ReLU, one 16-B piece per thread and step ----------------------
+    // ---- epilogue: sum the wave slabs in wave order, folded BatchNorm / bias / ReLU, 16-B row stores ----------
     constexpr int C4 = COUT / 4;
     for (int i = tid; i < rows * C4; i += NW * 64) {
         const int r = i / C4, c4 = i - r * C4;
-        float4 v = *(const float4 *)(acc + r * LDA + c4 * 4);
+        const int hh = c4 / NCH, ch = (c4 - hh * NCH) ^ (r & (NCH - 1));
+        const float *src = slabs + (hh * RW + r) * CW + ch * 4;          // slab of wave hh, then hh + CS, ...
+        float4 v = *(const float4 *)src;
+#pragma unroll
+        for (int w = 1; w < NW / CS; ++w) {
+            const float4 p = *(const float4 *)(src + w * CS * RW * CW);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
         const float4 sc = scale ? *(const float4 *)(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 sh = shift ? *(const float4 *)(shift + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
@@ -399,28 +457,45 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
     }
 }
 
-int g_spconv_rw = 0;            // 0 = choose by capacity; 64 / 128 forced (tools/, tests)
+int g_spconv_cfg = 0;           // 0 = default geometry; 1..3 alternatives (tools/, tests)
+
+template <int CIN, int COUT, int RW, int NW, int CS, int WPS>
+int launch_gs_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp,
+                  const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
+{
+    constexpr size_t lds = gs_lds_bytes<COUT, RW, NW, CS>();
+    static_assert(lds <= 160 * 1024, "workgroup slabs exceed the 160 KB LDS");
+    static std::atomic<unsigned long long> attr_done{0};
+    const void *fn = (const void *)spconv_gs_kernel<CIN, COUT, RW, NW, CS, WPS>;
+    int rc = sassd_dyn_lds(fn, lds, attr_done);
+    if (rc) return rc;
+    const int grid = 64 * cdiv(cdiv(cap, RW), 64);
+    hipLaunchKernelGGL((spconv_gs_kernel<CIN, COUT, RW, NW, CS, WPS>), dim3(grid), dim3(NW * 64), lds, stream, x, nbr,
+                       n_ptr, cap, wp, scale, shift, relu, y, g_spconv_dbg & 15);
+    return sassd_launch_status();
+}
 
 template <int CIN, int COUT>
 int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp, int K,
               const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
 {
-    // capacity is the only size the host knows (row counts live on the device): KITTI-scale single frames take 64-row
-    // slices (>= 200 workgroups for 13-18 k rows), batches / Waymo-scale frames 128-row slices (denser MFMA tiles,
-    // half the weight traffic)
-    const int rw = g_spconv_rw ? g_spconv_rw : (cap <= 65536 ? 64 : 128);
-    const int dbg = g_spconv_dbg & 15;
-    if (rw == 64) {
-        const int grid = 8 * cdiv(cdiv(cap, 64), 8);
-        hipLaunchKernelGGL((spconv_gs_kernel<CIN, COUT, 64, 8>), dim3(grid), dim3(512), 0, stream, x, nbr, n_ptr, cap,
-                           wp, scale, shift, relu, y, dbg);
-    } else {
-        const int grid = 8 * cdiv(cdiv(cap, 128), 8);
-        hipLaunchKernelGGL((spconv_gs_kernel<CIN, COUT, 128, 8>), dim3(grid), dim3(512), 0, stream, x, nbr, n_ptr, cap,
-                           wp, scale, shift, relu, y, dbg);
-    }
     (void)K;
-    return sassd_launch_status();
+    // geometries (64-row slices unless noted): cfg 0 = 8 waves; 1 = 4 waves, two workgroups per CU at 64 channels;
+    // 2 = 128-row slices; 3 = 8 waves with the output channels split over wave pairs (64-channel layers)
+    if (g_spconv_cfg == 1) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 2) {
+        if constexpr (COUT <= 32) return launch_gs_cfg<CIN, COUT, 128, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+        else return launch_gs_cfg<CIN, COUT, 128, 4, 1, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    }
+    if constexpr (COUT == 64) {
+        if (g_spconv_cfg == 3) return launch_gs_cfg<CIN, COUT, 64, 8, 2, 4>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+        if (g_spconv_cfg == 4) return launch_gs_cfg<CIN, COUT, 64, 16, 2, 4>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    }
+    if (g_spconv_cfg == 5) return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    // default: KITTI-scale single frames (capacity <= 64 k rows) one 8-wave workgroup per CU, larger batches / frames
+    // two 4-wave workgroups per CU (measured: 316 vs 330 us at B=1, 1385 vs 1500 us at multi_cfg B=8)
+    if (cap > 65536) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
 }
 
 // forward / data-gradient dispatch: gather-GEMM-scatter for 27-offset layers with Cin >= 16, the register-stationary
@@ -630,9 +705,9 @@ extern "C" int sassd_spconv_bwd_weight(const float *x, const float *dy, const in
 namespace {
 }  // namespace
 
-// debug / ablation switches (tools/ablate_spconv.py): bit0 no gather loads, bit1 no LDS scatter-add, bit2 no MFMA,
-// bit3 no weight loads, bit8 legacy register-stationary kernel; bits 16.. force the row-slice size (64 / 128)
-extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags & 0xFFFF; g_spconv_rw = flags >> 16; }
+// debug / ablation switches (tools/ablate_spconv.py): bit0 no gather loads, bit1 no slab accumulate, bit2 no MFMA,
+// bit3 no weight loads, bit8 legacy register-stationary kernel; bits 16.. select the workgroup geometry (0 default)
+extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags & 0xFFFF; g_spconv_cfg = flags >> 16; }
 
 extern "C" size_t sassd_spconv_packed_floats(int K, int Cin, int Cout) { return (size_t)K * Cin * Cout; }
 

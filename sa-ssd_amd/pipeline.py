@@ -151,7 +151,7 @@ class InferencePlan:
         self.det = dict(boxes=z(B, self.capD, 7), scores=z(B, self.capD), labels=z(B, self.capD, dt=i32),
                         counts=z(B, dt=i32))
         self.middle = {}
-        # all seven rulebooks through the fused pyramid (9 launches); the per-op chain (30) stays selectable for A/B
+        # all seven rulebooks through the fused pyramid (11 launches); the per-op chain (30) stays selectable for A/B
         self.pyr = None
         if fused_rulebooks:
             self.pyr = K.RulebookPyramid(self.idx, self.n, self.caps, self.shape0, B,

@@ -77,12 +77,15 @@ def test_rulebook_pyramid_overflow_flag(dev):
     assert int(st.item()) & 1 and int(n[1].item()) == caps[1]
 
 
-@pytest.mark.parametrize("mode", ["rw64", "rw128", "legacy"])
+@pytest.mark.parametrize("mode", ["default", "rw64x4", "rw128", "split2", "split2x16", "rw64x8", "legacy"])
 @pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (32, 16), (64, 32)])
 def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
     """subm and strided gather tables, ragged row counts (not multiples of the slice), every forward / data-gradient
     shape, against the CPU oracle; bar 2e-4 * max|y| (fp32 sums in a different order)."""
-    flags = {"rw64": 64 << 16, "rw128": 128 << 16, "legacy": 256}[mode]
+    flags = {"default": 0, "rw64x4": 1 << 16, "rw128": 2 << 16, "split2": 3 << 16, "split2x16": 4 << 16,
+             "rw64x8": 5 << 16, "legacy": 256}[mode]
+    if mode.startswith("split2") and cout != 64:
+        pytest.skip("the channel split exists for 64-channel layers")
     if mode == "legacy" and (cin, cout) in ((32, 16), (64, 32)):
         pytest.skip("covered by the backward tests")
     idx = _level0("small", 1)

@@ -48,7 +48,7 @@ plans = {f: InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["
 for f, plan in plans.items():
     plan.run_from_points(clouds)
     torch.cuda.synchronize()
-    assert int(plan.status.item()) == 0
+    assert (int(plan.status.item()) & ~4) == 0            # bit 2 = candidate-box overflow of the uncalibrated head
     with K.ws_scope(plan._wsid):
         print("rulebooks %-9s %8.1f us   (rows %s)" % ("fused" if f else "per-op", timeit(plan.rulebooks),
                                                        [int(t.item()) for t in plan.n]))
@@ -56,7 +56,7 @@ plan = plans[True]
 work = plan.sparse_work()
 print("pairs", work["pairs"], "bytes_gs %.1f MB" % (work["bytes_gs"] / 1e6))
 
-MODES = [("legacy", 256), ("gs rw64", 64 << 16), ("gs rw128", 128 << 16)]
+MODES = [("legacy", 256), ("gs 64x8", 5 << 16), ("gs 64x4", 1 << 16), ("gs split2x16", 4 << 16), ("default", 0)]
 layers = []
 lvl = 0
 for kind, cin, cout, key, wp, scale, shift in plan.sp:
@@ -82,7 +82,7 @@ for kind, cin, cout, key, wp, scale, shift, lvl in layers:
         seen.add((kind, key, cin))
         for mname, base in MODES[1:]:
             s = "        ablation %-8s" % mname
-            for bit, nm in ((1, "no-gather"), (2, "no-scatter"), (4, "no-mfma"), (8, "no-wload"), (15, "none-of-them")):
+            for bit, nm in ((1, "no-gather"), (2, "no-slab"), (4, "no-mfma"), (8, "no-wload"), (15, "none-of-them")):
                 K.debug_set_spconv(base | bit)
                 s += "  %s %6.1f" % (nm, timeit(lambda: K.spconv_fwd(x, nbr, plan.n[lvl], plan.caps[lvl], wp, k, cin,
                                                                       cout, scale, shift, True, y)))

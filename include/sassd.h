@@ -190,6 +190,20 @@ int sassd_conv2d_wino_pack_weight(const float *w, int Cout, int Cin, float *pack
 int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, const float *scale, const float *shift, int relu,
                           float *y, int batch, int Cin, int Cout, int H, int W, void *stream);
 
+/* The same layers through Winograd F(4x4,3x3) as THREE launches: input transform -> 36 fp32-MFMA GEMMs
+ * (Cout x Cin x tiles) -> output transform with the folded BatchNorm / bias / ReLU epilogue.  4x fewer multiplications
+ * than the direct convolution (1.78x fewer than F(2x2)) and no VALU work inside the contraction; fp32 rounding error
+ * ~6x the direct kernel's (2.4e-6 relative after seven layers).  Needs Cin % 32 == 0, Cout % 256 == 0, H % 4 == 0,
+ * W % 4 == 0 and a caller workspace (transformed input + product tensors, 36 planes each). */
+int sassd_conv2d_wino4_supported(int Cin, int Cout, int H, int W);
+void sassd_debug_set_wino4(int cfg, int dbg);     /* GEMM tile geometry / ablation switches (tools/run_wino4.py) */
+size_t sassd_conv2d_wino4_packed_floats(int Cin, int Cout);
+int sassd_conv2d_wino4_pack_weight(const float *w /*[Cout,Cin,3,3]*/, int Cout, int Cin, float *packed, void *stream);
+size_t sassd_conv2d_wino4_workspace_bytes(int batch, int Cin, int Cout, int H, int W);
+int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, const float *scale, const float *shift, int relu,
+                           float *y, int batch, int Cin, int Cout, int H, int W, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* Training: weight gradient of the same convolutions (autograd of nn.Conv2d at cmn.py:240-262 and
  * ssd_rotate_head.py:120-125,424-429; cuDNN in the reference).  x [B,Cin,H,W], dy [B,Cout,H,W] NCHW fp32 ->
  * dw [Cout,Cin,k,k] (torch layout), overwritten or accumulated.  Split-K over pixels with a deterministic second-stage

@@ -87,6 +87,12 @@ _SIGS = {
     "sassd_conv2d_wino_packed_floats": (_SZ, [_I, _I]),
     "sassd_conv2d_wino_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv2d_wino_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "sassd_conv2d_wino4_supported": (_I, [_I, _I, _I, _I]),
+    "sassd_debug_set_wino4": (None, [_I, _I]),
+    "sassd_conv2d_wino4_packed_floats": (_SZ, [_I, _I]),
+    "sassd_conv2d_wino4_pack_weight": (_I, [_P, _I, _I, _P, _P]),
+    "sassd_conv2d_wino4_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "sassd_conv2d_wino4_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_conv2d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "sassd_conv2d_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_rotate_iou_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),

@@ -1,0 +1,407 @@
+// conv2d_wino4.hip -- 3x3 stride-1 pad-1 convolution of the BEV network through Winograd F(4x4, 3x3):
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   per 4x4 output tile, summed over input channels
+// (mmdet/models/necks/cmn.py:240-262: conv0 320->256 and conv1-6 256->256 at 200x176, 93 % of the dense FLOPs).
+//
+// fp32 MFMA and fp32 VALU share one 157 TF peak on MI355X, so the only lever past a good direct kernel is fewer
+// multiplications.  F(2x2,3x3) (conv2d_wino.hip) needs 16 per 4 outputs; F(4x4,3x3) needs 36 per 16 outputs: 4x
+// fewer than the direct convolution, 1.78x fewer than F(2x2).  The fused F(2x2) kernel is bound by the VALU work of
+// its in-loop input transform (every transformed value feeds only 32 output channels); here the transforms are taken
+// OUT of the contraction, so that the hot loop is a plain batched GEMM with no VALU work at all:
+//   1. wino4_in_kernel    V[p][ci][t] = (B^T d B)[p]         x [B,Cin,H,W] -> V [36][Cin][Tp]       (HBM stream)
+//   2. wino4_gemm_kernel  M[p][co][t] = sum_ci U[p][ci][co] V[p][ci][t]     36 GEMMs 256 x Cin x T   (fp32 MFMA)
+//   3. wino4_out_kernel   Y = A^T M A, folded BatchNorm / bias / ReLU        M [36][Cout][Tp] -> y    (HBM stream)
+// with U = G g G^T packed once per weight update as [36][Cin][Cout].  T = B * (H/4) * (W/4) tiles (2200 per KITTI
+// BEV map), padded to a multiple of the GEMM's 64-column block.  Per 256->256 layer: 10.4 GFLOP on the MFMA (41.5
+// direct), 81 MB of V and M each; both transforms are elementwise streams.
+// Numerics: F(4x4,3x3) in fp32 has ~6x the rounding error of the direct convolution (2.4e-6 relative L2 after seven
+// chained layers, tools/wino4_numerics.py) -- two orders of magnitude inside the 2e-4 BEV-feature parity bar.
+//
+// GEMM kernel: workgroup = 128 output channels x 32 WN tiles of one Winograd position, 2 x WN waves, each wave a 64 x 32
+// block = two v_mfma_f32_32x32x2_f32 accumulators sharing one B fragment.  A ([k][128 co]) and B ([k][32 WN t]) chunks
+// of 32 input channels are staged by global->LDS DMA in their natural row-major form (both operands are K-major with
+// the M / N index contiguous, so fragment reads are 32 consecutive dwords: conflict free), double buffered, one
+// barrier per chunk; two workgroups per CU.  WN is picked per launch so that the last round of workgroups is full
+// (w4_pick_wn).  Work order: all tile blocks of one (position, channel half) run back to back on ONE XCD
+// (blockIdx % 8), so V[p] crosses the fabric twice and U[p] once per layer.  Measured (B=1, 256->256 @200x176):
+// MFMA part ~70 % of the fp32 peak, bounded by the workgroup rounds; the two transforms run at HBM speed.
+#include "common.h"
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+
+constexpr int kBM = 128, kKC = 32;           // channel-block / chunk granularity every GEMM geometry divides
+
+// ---- weights: U[p][ci][co] = (G g G^T)[p],  G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],
+//                                                   [1/24,-1/12,1/6],[0,0,1]]
+__device__ __forceinline__ void g_row(const float g0, const float g1, const float g2, float (&o)[6])
+{
+    o[0] = g0 * 0.25f;
+    const float s = (g0 + g2) * (-1.f / 6.f), m = g1 * (1.f / 6.f);
+    o[1] = s - m;
+    o[2] = s + m;
+    const float t = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), n = g1 * (1.f / 12.f);
+    o[3] = t + n;
+    o[4] = t - n;
+    o[5] = g2;
+}
+
+__global__ void wino4_pack_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ U)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * Cin) return;
+    const int co = i % Cout, ci = i / Cout;
+    const float *g = w + ((size_t)co * Cin + ci) * 9;
+    float t[3][6];                                    // columns of g transformed along the rows: (G g)^T
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g_row(g[c], g[3 + c], g[6 + c], t[c]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        float o[6];
+        g_row(t[0][r], t[1][r], t[2][r], o);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) U[((size_t)(r * 6 + c) * Cin + ci) * Cout + co] = o[c];
+    }
+}
+
+// ---- input transform: B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],
+//                               [0,4,0,-5,0,1]]
+__device__ __forceinline__ void bt_vec(const float (&d)[6], float (&o)[6])
+{
+    o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1];
+    o[1] = a + b;
+    o[2] = a - b;
+    const float c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+    o[3] = c + e;
+    o[4] = c - e;
+    o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+struct W4Geom { int B, C, H, W, TH, TW, T, Tp; };
+
+// one thread = one (channel, tile): 36 loads (neighbouring threads' patches overlap: L1), 36 coalesced plane stores
+__global__ void __launch_bounds__(256) wino4_in_kernel(const float *__restrict__ x, W4Geom G, float *__restrict__ V)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (t >= G.T) return;
+    const int tpi = G.TH * G.TW;
+    const int b = t / tpi, r = t - b * tpi;
+    const int ty = r / G.TW, tx = r - ty * G.TW;
+    const float *src = x + ((size_t)b * G.C + c) * G.H * G.W;
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    float d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int yy = y0 + i;
+        const bool rok = yy >= 0 && yy < G.H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int xx = x0 + j;
+            d[i][j] = (rok && xx >= 0 && xx < G.W) ? src[(size_t)yy * G.W + xx] : 0.f;
+        }
+    }
+    float u[6][6];                                    // u[j] = B^T (column j of d)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float o[6];
+        bt_vec(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) u[i][j] = o[i];
+    }
+    const size_t plane = (size_t)G.C * G.Tp;
+    float *dst = V + (size_t)c * G.Tp + t;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float o[6];
+        bt_vec(u[i], o);                              // (B^T d) B = rows transformed again
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dst[(size_t)(i * 6 + j) * plane] = o[j];
+    }
+}
+
+// ---- output transform: A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]
+__device__ __forceinline__ void at_vec(const float (&m)[6], float (&o)[4])
+{
+    const float s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
+    o[0] = m[0] + s1 + s2;
+    o[1] = d1 + 2.f * d2;
+    o[2] = s1 + 4.f * s2;
+    o[3] = d1 + 8.f * d2 + m[5];
+}
+
+__global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict__ M, W4Geom G, int Cout,
+                                                        const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, int relu,
+                                                        float *__restrict__ y)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int co = blockIdx.y;
+    if (t >= G.T) return;
+    const size_t plane = (size_t)Cout * G.Tp;
+    const float *src = M + (size_t)co * G.Tp + t;
+    float v[4][6];                                    // A^T m : 4 rows x 6 columns
+    {
+        float m[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[i][j] = src[(size_t)(i * 6 + j) * plane];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
+            float o[4];
+            at_vec(col, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i][j] = o[i];
+        }
+    }
+    const int tpi = G.TH * G.TW;
+    const int b = t / tpi, r = t - b * tpi;
+    const int ty = r / G.TW, tx = r - ty * G.TW;
+    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+    float *dst = y + (((size_t)b * Cout + co) * G.H + 4 * ty) * G.W + 4 * tx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float o[4];
+        at_vec(v[i], o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = o[j] * sc + sh;
+            if (relu) o[j] = fmaxf(o[j], 0.f);
+        }
+        *reinterpret_cast<float4 *>(dst + (size_t)i * G.W) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- the 36 GEMMs ---------------------------------------------------------------------------------------------------
+struct W4Gemm {
+    const float *U, *V;
+    float *M;
+    int Cin, Cout, Tp;
+    int nmb, nnb;            // channel blocks, tile blocks
+    int pairs_per_xcd;       // (position, channel block) pairs per XCD
+    int dbg;                 // ablation: bit0 stage only the first chunk, bit1 no MFMA
+};
+
+// WM x WN waves; a wave owns a 64 x (32 NB) block = 2 x NB accumulators of v_mfma_f32_32x32x2_f32.
+template <int WM, int WN, int NB, int KC>
+__global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
+{
+    constexpr int NWV = WM * WN, BM = 64 * WM, BN = 32 * NB * WN;
+    constexpr int STAGE = (BM + BN) * KC;
+    constexpr int NLA = KC * BM / 256, NLB = KC * BN / 256;          // 1 KB wave-loads per chunk
+    constexpr int LPW = (NLA + NLB + NWV - 1) / NWV;                 // ... per wave
+    extern __shared__ __attribute__((aligned(16))) float w4_lds[];   // [2][A KC x BM | B KC x BN]
+    float *lds = w4_lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-local order: blockIdx % 8 = XCD; inside an XCD the tile blocks of one (position, channel block) pair are
+    // consecutive, so concurrently running workgroups share U[p] (and V[p] with the other channel blocks' XCDs only)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int q = j / P.nnb, nb = j - q * P.nnb;
+    const int pair = xcd * P.pairs_per_xcd + q;
+    if (pair >= 36 * P.nmb) return;
+    const int p = pair / P.nmb, mb = pair - p * P.nmb;
+    const float *Ub = P.U + (size_t)p * P.Cin * P.Cout + mb * BM;          // + k * Cout
+    const float *Vb = P.V + (size_t)p * P.Cin * P.Tp + nb * BN;            // + k * Tp
+    // DMA map: wave-load id t = wave + NWV * i; t < NLA: A rows (BM/4 16-byte pieces per row), else B rows.  The LDS
+    // destination of a wave-load is lane-linear, i.e. the natural row-major [k][m] / [k][n] image.
+    const float *src[LPW];
+    size_t kstride[LPW];
+    int dst[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int t = wave + NWV * i;
+        if (t < NLA) {
+            const int e = t * 64 + lane;
+            src[i] = Ub + (size_t)(e / (BM / 4)) * P.Cout + (e % (BM / 4)) * 4;
+            kstride[i] = (size_t)KC * P.Cout;
+            dst[i] = t * 256;
+        } else {
+            const int e = (t - NLA) * 64 + lane;
+            src[i] = Vb + (size_t)(e / (BN / 4)) * P.Tp + (e % (BN / 4)) * 4;
+            kstride[i] = (size_t)KC * P.Tp;
+            dst[i] = BM * KC + (t - NLA) * 256;
+        }
+    }
+    auto dma = [&](int chunk, float *stage) {
+#pragma unroll
+        for (int i = 0; i < LPW; ++i)
+            if (wave + NWV * i < NLA + NLB)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[i] + chunk * kstride[i]), (lds_ptr_t)(stage + dst[i]), 16,
+                                                 0, 0);
+    };
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, kh = lane >> 5;
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nchunk = P.Cin / KC;
+    dma(0, lds);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        float *cur = lds + (c & 1) * STAGE;
+        if (c + 1 < nchunk && !(P.dbg & 1)) dma(c + 1, lds + ((c + 1) & 1) * STAGE);
+        const float *As = cur + kh * BM + wm * 64 + l31;                      // + 2*kk*BM
+        const float *Bs = cur + BM * KC + kh * BN + wn * 32 * NB + l31;       // + 2*kk*BN
+        if (!(P.dbg & 2)) {
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                const float a0 = As[2 * kk * BM], a1 = As[2 * kk * BM + 32];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const float bv = Bs[2 * kk * BN + 32 * b];
+                    acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][b], 0, 0, 0);
+                    acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                // (the compiler drains vmcnt: chunk c+1 has landed)
+    }
+    // Epilogue through LDS (the staging buffers are dead): D[row = (r & 3) + 8 * (r >> 2) + 4 * kh][col = l31] goes to the
+    // wave's [64][32 NB] image, then 16-byte row stores (a dword store per accumulator register is ~6x slower per byte)
+    constexpr int WCOLS = 32 * NB;
+    float *img = lds + wave * 64 * WCOLS;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * WCOLS + b * 32 + l31] = acc[a][b][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private image: no barrier needed
+    float *Mb = P.M + ((size_t)p * P.Cout + mb * BM + wm * 64) * P.Tp + nb * BN + wn * WCOLS;
+    constexpr int C4 = WCOLS / 4, RPI = 64 / C4;        // float4 per row, rows per wave-instruction
+#pragma unroll
+    for (int i = 0; i < 64 / RPI; ++i) {
+        const int row = i * RPI + lane / C4, c4 = lane % C4;
+        *reinterpret_cast<float4 *>(Mb + (size_t)row * P.Tp + c4 * 4) = *reinterpret_cast<const float4 *>(img + row * WCOLS + c4 * 4);
+    }
+}
+
+int g_wino4_cfg = 0, g_wino4_dbg = 0;
+
+template <int WM, int WN, int NB, int KC>
+int launch_w4_gemm(W4Gemm P, hipStream_t stream)
+{
+    constexpr int BM = 64 * WM, BN = 32 * NB * WN;
+    constexpr size_t stage_b = (size_t)2 * (BM + BN) * KC * 4, img_b = (size_t)WM * WN * 64 * 32 * NB * 4;
+    constexpr size_t lds = stage_b > img_b ? stage_b : img_b;        // the epilogue image reuses the staging buffers
+    static std::atomic<unsigned long long> attr_done{0};
+    const void *fn = (const void *)wino4_gemm_kernel<WM, WN, NB, KC>;
+    int rc = sassd_dyn_lds(fn, lds, attr_done);
+    if (rc) return rc;
+    P.nmb = P.Cout / BM; P.nnb = P.Tp / BN;
+    P.pairs_per_xcd = cdiv(36 * P.nmb, 8);
+    P.dbg = g_wino4_dbg;
+    hipLaunchKernelGGL((wino4_gemm_kernel<WM, WN, NB, KC>), dim3(8 * P.pairs_per_xcd * P.nnb), dim3(WM * WN * 64), lds,
+                       stream, P);
+    return sassd_launch_status();
+}
+
+// Tile-block width of the GEMM (32 WN columns, WN waves across): all workgroups do equal work, so the launch takes
+// ceil(units / resident slots) rounds -- pick the width whose LAST round is fullest.  KITTI B=1 (2200 tiles): 160
+// columns -> 1008 units = 1.97 rounds of 512 slots (64 / 96 / 128 / 192 columns all waste 17 %).
+inline int w4_pick_wn(int T, int Cout)
+{
+    int best = 4;
+    double best_cost = 1e30;
+    for (int wn = 2; wn <= 6; ++wn) {
+        const int bn = 32 * wn;
+        const size_t lds = (size_t)2 * (kBM + bn) * kKC * 4;
+        int wgs = (int)((size_t)160 * 1024 / lds);
+        if (wgs > 32 / (2 * wn)) wgs = 32 / (2 * wn);
+        if (wgs < 1) wgs = 1;
+        const long units = (long)36 * (Cout / kBM) * cdiv(T, bn);
+        const long rounds = (units + 256L * wgs - 1) / (256L * wgs);
+        const double cost = (double)rounds * wgs * bn;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = wn; }
+    }
+    return best;
+}
+
+inline int w4_wn(int T, int Cout) { return (g_wino4_cfg >= 2 && g_wino4_cfg <= 6) ? g_wino4_cfg : w4_pick_wn(T, Cout); }
+
+inline int w4_tiles_padded(int B, int H, int W, int Cout)
+{
+    const int T = B * (H / 4) * (W / 4);
+    const int bn = 32 * w4_wn(T, Cout);
+    return cdiv(T, bn) * bn;
+}
+
+}  // namespace
+
+// ablation / geometry switches of the F(4x4) GEMM (tools/run_wino4.py): cfg 0 = pick the tile-block width from the
+// tile count, 2..6 = force 32*cfg columns; dbg bit0 stage only the first chunk, bit1 no MFMA
+extern "C" void sassd_debug_set_wino4(int cfg, int dbg) { g_wino4_cfg = cfg; g_wino4_dbg = dbg; }
+
+extern "C" int sassd_conv2d_wino4_supported(int Cin, int Cout, int H, int W)
+{
+    return (Cin >= kKC && Cin % kKC == 0 && Cout >= 256 && Cout % 256 == 0 && H >= 4 && H % 4 == 0 && W >= 4 && W % 4 == 0)
+               ? 1 : 0;
+}
+
+extern "C" size_t sassd_conv2d_wino4_packed_floats(int Cin, int Cout)
+{
+    if (Cin < 1 || Cout < 1) return 0;
+    return (size_t)36 * Cin * Cout;
+}
+
+extern "C" int sassd_conv2d_wino4_pack_weight(const float *w, int Cout, int Cin, float *packed, void *stream_)
+{
+    if (!w || !packed || Cin < 1 || Cout < 1) return SASSD_EINVAL;
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(cdiv(Cout * Cin, 256)), dim3(256), 0, (hipStream_t)stream_, w, Cout, Cin,
+                       packed);
+    return sassd_launch_status();
+}
+
+extern "C" size_t sassd_conv2d_wino4_workspace_bytes(int batch, int Cin, int Cout, int H, int W)
+{
+    if (!sassd_conv2d_wino4_supported(Cin, Cout, H, W) || batch < 1) return 0;
+    // (sized for the widest tile block, so that a forced geometry never outgrows a caller's buffer)
+    const size_t Tp = (size_t)cdiv(batch * (H / 4) * (W / 4), 192) * 192 + 192;
+    return align_up(36 * (size_t)Cin * Tp * 4, 256) + align_up(36 * (size_t)Cout * Tp * 4, 256);
+}
+
+extern "C" int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, const float *scale, const float *shift,
+                                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, void *workspace,
+                                      size_t workspace_bytes, void *stream_)
+{
+    if (!x || !w_packed || !y || !workspace || batch < 1 || !sassd_conv2d_wino4_supported(Cin, Cout, H, W))
+        return SASSD_EINVAL;
+    if (((uintptr_t)y & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)workspace & 15)) return SASSD_EINVAL;
+    if (workspace_bytes < sassd_conv2d_wino4_workspace_bytes(batch, Cin, Cout, H, W)) return SASSD_ENOSPC;
+    hipStream_t stream = (hipStream_t)stream_;
+    W4Geom G;
+    G.B = batch; G.C = Cin; G.H = H; G.W = W; G.TH = H / 4; G.TW = W / 4; G.T = batch * G.TH * G.TW;
+    G.Tp = w4_tiles_padded(batch, H, W, Cout);
+    float *V = (float *)workspace;
+    float *M = (float *)((char *)workspace + align_up(36 * (size_t)Cin * G.Tp * 4, 256));
+    // the padding columns of V feed padding columns of M that the output transform never reads; they only have to be
+    // finite-or-not-read: the GEMM's columns are independent, so stale values cannot leak into real tiles
+    hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V);
+    W4Gemm P;
+    P.U = w_packed; P.V = V; P.M = M; P.Cin = Cin; P.Cout = Cout; P.Tp = G.Tp;
+    int rc;
+    switch (w4_wn(G.T, Cout)) {                                      // 128 channels x 32 WN tiles, 2 x WN waves of 64 x 32
+    case 2: rc = launch_w4_gemm<2, 2, 1, kKC>(P, stream); break;
+    case 3: rc = launch_w4_gemm<2, 3, 1, kKC>(P, stream); break;
+    case 4: rc = launch_w4_gemm<2, 4, 1, kKC>(P, stream); break;
+    case 5: rc = launch_w4_gemm<2, 5, 1, kKC>(P, stream); break;
+    default: rc = launch_w4_gemm<2, 6, 1, kKC>(P, stream); break;
+    }
+    if (rc) return rc;
+    W4Geom Go = G;
+    Go.C = Cout;
+    hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
+                       scale, shift, relu, y);
+    return sassd_launch_status();
+}

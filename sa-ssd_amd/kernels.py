@@ -372,6 +372,43 @@ def conv2d_wino_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=Non
     return y
 
 
+def conv2d_wino4_supported(cin, cout, h, w):
+    return bool(_C.lib().sassd_conv2d_wino4_supported(int(cin), int(cout), int(h), int(w)))
+
+
+def conv2d_wino4_pack_weight(w):
+    """w [Cout,Cin,3,3] -> U = G g G^T of Winograd F(4x4,3x3) as [36][Cin][Cout] (once per weight update)."""
+    _chk_cuda(w)
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    L = _C.lib()
+    packed = torch.empty(L.sassd_conv2d_wino4_packed_floats(cin, cout), dtype=torch.float32, device=w.device)
+    _C.check(L.sassd_conv2d_wino4_pack_weight(_C.ptr(w.contiguous()), cout, cin, _C.ptr(packed), _C.stream()),
+             "sassd_conv2d_wino4_pack_weight")
+    return packed
+
+
+def conv2d_wino4_workspace(b, cin, cout, h, w, device):
+    n = _C.lib().sassd_conv2d_wino4_workspace_bytes(b, cin, cout, h, w)
+    return torch.empty(max(n, 256), dtype=torch.uint8, device=device)
+
+
+def conv2d_wino4_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=None, ws=None):
+    """3x3 pad-1 conv through Winograd F(4x4,3x3): input transform, 36 fp32-MFMA GEMMs, output transform + epilogue."""
+    _chk_cuda(x, w_packed)
+    b, cin, h, w = x.shape
+    if y is None:
+        y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
+    L = _C.lib()
+    wsb = L.sassd_conv2d_wino4_workspace_bytes(b, cin, cout, h, w)
+    if ws is None or ws.numel() < wsb:
+        ws = workspace("conv2d_wino4", wsb, x.device)
+    _C.check(L.sassd_conv2d_wino4_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
+                                      _C.ptr(y), b, cin, cout, h, w, _C.ptr(ws), ws.numel(), _C.stream()),
+             "sassd_conv2d_wino4_fwd")
+    return y
+
+
 def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False):
     """x [B,Cin,H,W], dy [B,Cout,H,W] -> dw [Cout,Cin,k,k] on the fp32-MFMA split-K kernel."""
     _chk_cuda(x, dy)

@@ -95,10 +95,21 @@ class InferencePlan:
                 c = cin // D3
                 w = w.view(cout, c, D3, 3, 3).permute(0, 2, 1, 3, 4).reshape(cout, cin, 3, 3)
             scale, shift = fold_bn(sd, "neck.fcn.bn%d" % i)
-            # 3x3 layers go through the Winograd F(2x2,3x3) kernel (2.25x fewer MFMA flops) when the shape allows
-            wino = bool(winograd) and w.shape[2] == 3 and K.conv2d_wino_supported(w.shape[1], w.shape[0], self.H, self.W)
-            wp = K.conv2d_wino_pack_weight(w.contiguous()) if wino else K.conv2d_pack_weight(w.contiguous())
+            # 3x3 layers: Winograd F(4x4,3x3) (transform + 36 MFMA GEMMs + transform: 4x fewer multiplications) when the
+            # shape allows, else the fused F(2x2,3x3) kernel (2.25x fewer), else the direct kernel.  `winograd` = 2
+            # forces F(2x2), 0 / False the direct kernel (A/B)
+            wino = 0
+            if winograd and w.shape[2] == 3:
+                if winograd != 2 and K.conv2d_wino4_supported(w.shape[1], w.shape[0], self.H, self.W):
+                    wino = 4
+                elif K.conv2d_wino_supported(w.shape[1], w.shape[0], self.H, self.W):
+                    wino = 2
+            wp = (K.conv2d_wino4_pack_weight(w.contiguous()) if wino == 4 else
+                  K.conv2d_wino_pack_weight(w.contiguous()) if wino == 2 else K.conv2d_pack_weight(w.contiguous()))
             self.bev.append((wp, w.shape[0], w.shape[2], scale, shift, wino))
+        self.wino4_ws = None
+        if any(l[5] == 4 for l in self.bev):
+            self.wino4_ws = K.conv2d_wino4_workspace(self.B, max(64 * D3, 256), 256, self.H, self.W, dev)
         hw = torch.cat([sd["rpn_head.conv_box.weight"], sd["rpn_head.conv_cls.weight"],
                         sd["rpn_head.conv_dir_cls.weight"]], 0).float().contiguous()
         hb = torch.cat([sd["rpn_head.conv_box.bias"], sd["rpn_head.conv_cls.bias"],
@@ -271,7 +282,9 @@ class InferencePlan:
         for i, (wp, cout, ks, scale, shift, wino) in enumerate(self.bev):
             y = self.act[i % 2] if i < 7 else self.act[2]
             e0 = self._ev() if self.prof is not None else None
-            if wino:
+            if wino == 4:
+                K.conv2d_wino4_fwd(x, wp, cout, scale, shift, True, y, self.wino4_ws)
+            elif wino == 2:
                 K.conv2d_wino_fwd(x, wp, cout, scale, shift, True, y)
             else:
                 K.conv2d_fwd(x, wp, cout, ks, scale, shift, True, y)

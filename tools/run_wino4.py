@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Time the three kernels of the Winograd F(4x4,3x3) BEV conv (256->256 @200x176, B=1 by default) next to the fused
+F(2x2) kernel -- also the target for rocprofv3 --kernel-trace / --pmc passes."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sassd  # noqa: E402
+from sassd import kernels as K  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--cin", type=int, default=256)
+ap.add_argument("--reps", type=int, default=30)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+B, C, H, W = args.batch, args.cin, 200, 176
+x = torch.randn(B, C, H, W, device=dev).clamp(min=0)
+w = torch.randn(256, C, 3, 3, device=dev) * (2.0 / (C * 9)) ** 0.5
+sc, sh = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev) * 0.1
+y = torch.empty(B, 256, H, W, device=dev)
+w4, w2 = K.conv2d_wino4_pack_weight(w), K.conv2d_wino_pack_weight(w)
+ws = K.conv2d_wino4_workspace(B, C, 256, H, W, dev)
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / args.reps * 1e3
+
+
+from sassd import _C  # noqa: E402
+flops = 2.0 * 256 * C * 9 * H * W * B
+ref = K.conv2d_wino_fwd(x, w2, 256, sc, sh, True).clone()
+names = {0: "auto", 2: "128x64", 3: "128x96", 4: "128x128", 5: "128x160", 6: "128x192"}
+for cfg in (0, 2, 3, 4, 5, 6):
+    line = "cfg %d %-18s" % (cfg, names[cfg])
+    for dbg, nm in ((0, "full"), (1, "no-dma"), (2, "no-mfma"), (3, "neither")):
+        _C.lib().sassd_debug_set_wino4(cfg, dbg)
+        t4 = timeit(lambda: K.conv2d_wino4_fwd(x, w4, 256, sc, sh, True, y, ws))
+        line += "  %s %6.1f us" % (nm, t4)
+        if dbg == 0:
+            line += " (%.0f TF eq, err %.1e)" % (flops / t4 / 1e6, (y - ref).abs().max().item())
+    print(line)
+_C.lib().sassd_debug_set_wino4(0, 0)
+t2 = timeit(lambda: K.conv2d_wino_fwd(x, w2, 256, sc, sh, True, y))
+print("F(2x2) fused: %.1f us (%.1f TF direct-equivalent)" % (t2, flops / t2 / 1e6))

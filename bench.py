@@ -20,10 +20,11 @@ pass.  `fps_sequential` (one graph after the other on one stream, no host sync) 
 sync + result read-back per frame) are printed next to it.
 
 The JSON line also carries:
-  roofline         dominant kernel (BEV 3x3 conv, Winograd F(2x2,3x3) on the fp32 MFMA): `achieved` / `frac` = the
-                   flops the kernel EXECUTES on the MFMA pipe (16/36 of the direct convolution) over the mean launch
-                   duration (HIP events on the launch stream, one frame at a time) vs the 157.3 TF fp32-MFMA peak;
-                   `effective` = the direct-convolution flops of SURVEY 8(d) over the same time.
+  roofline         dominant kernel (the 36-GEMM launch of a BEV 3x3 layer, Winograd F(4x4,3x3) on the fp32 MFMA):
+                   `achieved` / `frac` = the flops the kernel EXECUTES on the MFMA pipe (1/4 of the direct convolution)
+                   over its mean launch duration (HIP events on the launch stream) vs the 157.3 TF fp32-MFMA peak;
+                   `layer.effective` = the direct-convolution flops of SURVEY 8(d) over the whole layer (input
+                   transform + GEMM + output transform).
   roofline_sparse  7 rulebooks + 14 sparse convs against the HBM roofline (B_gs bytes of SURVEY 8d), timed as a
                    hipGraph of exactly that segment.
   cpu_baseline     the CPU oracle (a faithful port: C voxelizer / NMS + torch-CPU sparse and dense convs) on this box's
@@ -59,8 +60,9 @@ def build_model(seed=0, dev=None, config="car"):
     if dev is not None:
         # calibration frame: a sparse KITTI crop (3000 pts) as in the parity tests; a full Waymo-scale frame (the anchor
         # mask of a 30k-point crop would under-count the candidates of a 180k-point frame)
-        cal_cloud = synth.lidar64(11)[:3000] if config != "waymo" else w["frame"](11)
-        synth.calibrate_cls_head_on_device(model, w, dev, cal_cloud, target_count=100 if config != "waymo" else 600)
+        # calibrated on a frame of the workload's own kind, so that K ~ 10^2 anchors pass the guided-anchor
+        # threshold on the frames that are actually measured (candidate counts are printed in the JSON line)
+        synth.calibrate_cls_head_on_device(model, w, dev, w["frame"](11), target_count=200 if config != "waymo" else 600)
     return model, w
 
 
@@ -291,6 +293,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = D.allreduce_max(dt, dev)
     ndet = int(plan.det["counts"].sum().item())
+    ncand = int(plan.df["counts"].sum().item())
     fps = args.steps * B * world / dt
 
     # ---- everything below is measurement detail on top of the timed region -----------------------------------
@@ -330,22 +333,45 @@ def main():
             sp_ms = timed_graph_ms(iso_plan, None)
             iso_plan.capture(w["points_cap"], stages=("voxelize", "backbone", "tail"))
             frame_ms = timed_graph_ms(iso_plan, batch_of(29))
+    # the three launches of one F(4x4) layer timed separately on the live buffers of the last frame
+    w4_parts = {}
+    if iso_plan.bev[1][5] == 4:
+        from sassd import kernels as K
+        wp, cout, ks, scale, shift, _ = iso_plan.bev[1]
+        xin, yout = iso_plan.act[0], iso_plan.act[1]
+        with torch.cuda.stream(streams[0]):
+            for name, flags in (("in", 32 | 64), ("gemm", 16 | 64), ("out", 16 | 32)):
+                K.debug_set_wino4(0, flags)
+                for _ in range(3):
+                    K.conv2d_wino4_fwd(xin, wp, cout, scale, shift, True, yout, iso_plan.wino4_ws)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    K.conv2d_wino4_fwd(xin, wp, cout, scale, shift, True, yout, iso_plan.wino4_ws)
+                e1.record()
+                torch.cuda.synchronize()
+                w4_parts[name] = e0.elapsed_time(e1) / 20
+            K.debug_set_wino4(0, 0)
     if rank != 0:
         return
     iso_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v][5:])) for k, v in prof_iso.items()}
     if sp_ms is None:
         sp_ms, frame_ms = iso_ms["sparse"], None
     H, W = plan.H, plan.W
-    wino_layers = [i for i in range(1, 7) if plan.bev[i][5]]
-    conv_iso = float(np.mean([iso_ms["bev_conv%d" % i] for i in range(1, 7)]))      # six identical 256->256 3x3 launches
+    kind = plan.bev[1][5]                                      # 4 = Winograd F(4x4,3x3), 2 = fused F(2x2), 0 = direct
+    conv_iso = float(np.mean([iso_ms["bev_conv%d" % i] for i in range(1, 7)]))      # six identical 256->256 3x3 layers
     conv_flops = 2.0 * 256 * 256 * 9 * H * W * B               # direct-convolution flops of the layer
-    exec_flops = conv_flops * (16.0 / 36.0 if wino_layers else 1.0)     # Winograd F(2x2,3x3) executes 16/36 of them
-    exec_tf = exec_flops / (conv_iso * 1e-3) / 1e12
+    exec_flops = conv_flops * {4: 36.0 / 144.0, 2: 16.0 / 36.0, 0: 1.0}[kind]       # what the MFMA pipe executes
+    kernel_ms = w4_parts.get("gemm", conv_iso)                 # the dominant KERNEL: the F(4x4) GEMM launch alone
+    exec_tf = exec_flops / (kernel_ms * 1e-3) / 1e12
     eff_tf = conv_flops / (conv_iso * 1e-3) / 1e12
+    kname = {4: "wino4_gemm_kernel (36 GEMMs 256 x 256 x tiles of the BEV 256->256 3x3 layer, Winograd F(4x4,3x3), fp32 "
+                "MFMA 32x32x2)", 2: "conv2d_wino_kernel (BEV 256->256 3x3, fused Winograd F(2x2,3x3), fp32 MFMA 32x32x2)",
+             0: "conv2d_kernel (BEV 256->256 3x3, direct, fp32 MFMA 32x32x2)"}[kind]
     bev_total_ms = sum(iso_ms["bev_conv%d" % i] for i in range(8))
     sp_gbs = (work["bytes_gs"] + work["rulebook_bytes"]) / (sp_ms * 1e-3) / 1e9
     traffic = None                       # PMC passes cannot run inside this process: read the committed measurement
-    for tj in ("r02_conv2d_hbm_traffic.json", "r01_conv2d_hbm_traffic.json"):
+    for tj in ("r02_wino4_gemm_hbm_traffic.json",):
         tj = os.path.join(ROOT, "profiles", tj)
         if os.path.exists(tj) and B == 1 and args.config == "car":
             traffic = json.load(open(tj))["traffic_bytes_per_launch"]
@@ -365,20 +391,21 @@ def main():
                    "vs_baseline_ref": "reference readme.md:2 '25 FPS' (hardware unstated), per-GPU fps / 25"},
         "fps_in_flight": round(fps, 3), "fps_sequential": round(B * 1e3 / seq_ms, 3),
         "latency_ms_sync_per_frame": round(lat_ms, 3), "frame_graph_ms": None if frame_ms is None else round(frame_ms, 4),
-        "roofline": {"bound": "mfma", "kernel": "conv2d_wino_kernel (BEV 256->256 3x3, Winograd F(2x2,3x3) on fp32 MFMA "
-                                                "32x32x2)",
+        "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": round(exec_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                      "frac": round(exec_tf / PEAK_F32_MFMA_TF, 4),
-                     "effective": round(eff_tf, 2), "effective_frac": round(eff_tf / PEAK_F32_MFMA_TF, 4),
+                     "ms_per_launch": round(kernel_ms, 4), "executed_flops_per_launch": exec_flops,
+                     "layer": {"ms": round(conv_iso, 4), "direct_conv_flops": conv_flops,
+                               "effective": round(eff_tf, 2), "effective_frac": round(eff_tf / PEAK_F32_MFMA_TF, 4),
+                               "kernel_ms": {k: round(v, 4) for k, v in w4_parts.items()}},
                      "traffic": traffic,
                      "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "
                                      "passes, profiles/)",
-                     "executed_flops_per_launch": exec_flops, "direct_conv_flops_per_launch": conv_flops,
-                     "ms_per_launch": round(conv_iso, 4),
-                     "note": "achieved/frac = flops EXECUTED on the MFMA pipe (Winograd: 16/36 of the direct "
-                             "convolution) / mean launch duration (HIP events on the launch stream, one frame at a time "
-                             "= what rocprofv3 --kernel-trace reports, profiles/); effective = the layer's direct-"
-                             "convolution flops of SURVEY 8(d) over the same time"},
+                     "note": "achieved/frac = flops EXECUTED on the MFMA pipe by the dominant kernel (Winograd F(4x4,3x3): "
+                             "1/4 of the direct convolution) / its mean launch duration, HIP events on the launch stream "
+                             "(= what rocprofv3 --kernel-trace reports, profiles/); layer.effective = the layer's direct-"
+                             "convolution flops of SURVEY 8(d) over the whole layer (input transform + GEMM + output "
+                             "transform)"},
         "roofline_sparse": {"bound": "hbm", "kernels": "7 rulebooks (fused pyramid) + 14 sparse-conv launches, timed as "
                                                        "one hipGraph" if not args.eager else "eager, isolated pass",
                             "achieved": round(sp_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -389,7 +416,7 @@ def main():
                             "ms": round(sp_ms, 4), "ms_eager_isolated": round(iso_ms["sparse"], 4), "rows": work["n"]},
         "stage_ms": {k: round(v, 4) for k, v in sorted(iso_ms.items())},
         "bev_total_ms": round(bev_total_ms, 4),
-        "detections_last_frame": ndet,
+        "detections_last_frame": ndet, "guided_anchor_candidates_last_frame": ncand,
     }
     if world == 1 and headline and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, w)

@@ -204,6 +204,15 @@ int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, const float *s
                            float *y, int batch, int Cin, int Cout, int H, int W, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* 1x1 convolution with >= 128 output channels (BEVNet conv7, cmn.py:262) as a plain fp32-MFMA GEMM over the NCHW
+ * tensor (y[b] [Cout x HW] = W [Cout x Cin] . x[b] [Cin x HW]) with the folded BatchNorm / bias / ReLU epilogue; the
+ * kernel of the Winograd F(4x4) products with one problem per image.  Needs Cin % 32 == 0, Cout % 128 == 0 and H*W
+ * divisible by one of 64 / 96 / 128 / 160 / 192; weights packed [Cin][Cout] (Cin*Cout floats). */
+int sassd_conv1x1_gemm_supported(int Cin, int Cout, int H, int W);
+int sassd_conv1x1_gemm_pack_weight(const float *w /*[Cout,Cin,1,1]*/, int Cout, int Cin, float *packed, void *stream);
+int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *scale, const float *shift, int relu,
+                           float *y, int batch, int Cin, int Cout, int H, int W, void *stream);
+
 /* Training: weight gradient of the same convolutions (autograd of nn.Conv2d at cmn.py:240-262 and
  * ssd_rotate_head.py:120-125,424-429; cuDNN in the reference).  x [B,Cin,H,W], dy [B,Cout,H,W] NCHW fp32 ->
  * dw [Cout,Cin,k,k] (torch layout), overwritten or accumulated.  Split-K over pixels with a deterministic second-stage
@@ -224,6 +233,13 @@ int sassd_anchor_mask(const int32_t *coors, const int32_t *row_begin_ptr, const 
                       int H0, int W0, const float *anchors_bv, int n_anchors, const float *voxel_size,
                       const float *coors_range, float area_threshold, uint8_t *mask, void *workspace,
                       size_t workspace_bytes, void *stream);
+/* The same for `batch` samples in one launch sequence: sample b owns the coordinate rows [row_offsets[b],
+ * row_offsets[b+1]) (device int32[batch+1], what sassd_voxelize's row_offset chain leaves behind), mask[b*n_anchors..]
+ * and one sassd_anchor_mask_workspace_bytes slice of the workspace (batch slices in total). */
+int sassd_anchor_mask_batch(const int32_t *coors, const int32_t *row_offsets, int batch, int H0, int W0,
+                            const float *anchors_bv, int n_anchors, const float *voxel_size,
+                            const float *coors_range, float area_threshold, uint8_t *mask, void *workspace,
+                            size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a11) get_guided_anchors, test path (ssd_rotate_head.py:307-372) + second_box_decode (:53-91).

@@ -67,6 +67,7 @@ _SIGS = {
     "sassd_conv2d_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sassd_anchor_mask_workspace_bytes": (_SZ, [_I, _I]),
     "sassd_anchor_mask": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _F, _P, _P, _SZ, _P]),
+    "sassd_anchor_mask_batch": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _F, _P, _P, _SZ, _P]),
     "sassd_decode_filter_workspace_bytes": (_SZ, [_I, _I]),
     "sassd_decode_filter": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "sassd_pswarp_sample": (_I, [_P, _I, _I, _I, _P, _P, _I, _F, _F, _F, _P, _P]),
@@ -93,6 +94,9 @@ _SIGS = {
     "sassd_conv2d_wino4_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv2d_wino4_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "sassd_conv2d_wino4_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "sassd_conv1x1_gemm_supported": (_I, [_I, _I, _I, _I]),
+    "sassd_conv1x1_gemm_pack_weight": (_I, [_P, _I, _I, _P, _P]),
+    "sassd_conv1x1_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "sassd_conv2d_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_rotate_iou_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),

@@ -9,21 +9,23 @@
 
 namespace {
 
+// blockIdx.z = sample in every kernel of this file (per-sample grid / segment / mask slices of the workspace)
 __global__ void am_scatter_kernel(const int32_t *__restrict__ coors, const int32_t *__restrict__ rb,
-                                  const int32_t *__restrict__ re, int W0, unsigned *__restrict__ grid)
+                                  const int32_t *__restrict__ re, int W0, unsigned *__restrict__ grid, size_t gstride)
 {
-    const int begin = rb ? *rb : 0, end = *re;
+    const int b = blockIdx.z;
+    const int begin = rb ? rb[b] : 0, end = re[b];
     const int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= end) return;
     const int4 c = ((const int4 *)coors)[i];
-    atomicAdd(&grid[(size_t)c.z * W0 + c.w], 1u);
+    atomicAdd(&grid[b * gstride + (size_t)c.z * W0 + c.w], 1u);
 }
 
 // inclusive row scan, one block per row
-__global__ void __launch_bounds__(256) am_rowscan_kernel(unsigned *__restrict__ grid, int W0)
+__global__ void __launch_bounds__(256) am_rowscan_kernel(unsigned *__restrict__ grid, int W0, size_t gstride)
 {
     __shared__ int wsum[17];
-    unsigned *row = grid + (size_t)blockIdx.x * W0;
+    unsigned *row = grid + blockIdx.z * gstride + (size_t)blockIdx.x * W0;
     const int per = (W0 + 255) / 256;
     const int x0 = threadIdx.x * per;
     int s = 0;
@@ -38,10 +40,12 @@ constexpr int kRB = 32;   // rows per column segment
 
 // per (row segment, column): in-place inclusive column scan inside the segment, segment total -> seg[rs][x]
 __global__ void __launch_bounds__(256) am_colseg_kernel(unsigned *__restrict__ grid, int H0, int W0,
-                                                        unsigned *__restrict__ seg)
+                                                        unsigned *__restrict__ seg, size_t gstride, size_t sstride)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W0) return;
+    grid += blockIdx.z * gstride;
+    seg += blockIdx.z * sstride;
     const int y0 = blockIdx.y * kRB;
     unsigned run = 0;
     for (int k = 0; k < kRB; ++k) {
@@ -53,10 +57,11 @@ __global__ void __launch_bounds__(256) am_colseg_kernel(unsigned *__restrict__ g
     seg[(size_t)blockIdx.y * W0 + x] = run;
 }
 
-__global__ void __launch_bounds__(256) am_segscan_kernel(unsigned *__restrict__ seg, int nseg, int W0)
+__global__ void __launch_bounds__(256) am_segscan_kernel(unsigned *__restrict__ seg, int nseg, int W0, size_t sstride)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W0) return;
+    seg += blockIdx.z * sstride;
     unsigned run = 0;
     for (int s = 0; s < nseg; ++s) {
         const unsigned v = seg[(size_t)s * W0 + x];
@@ -74,10 +79,14 @@ __device__ __forceinline__ unsigned am_I(const unsigned *grid, const unsigned *s
 
 __global__ void __launch_bounds__(256) am_anchor_kernel(const float *__restrict__ bv, AmParams P,
                                                         const unsigned *__restrict__ grid,
-                                                        const unsigned *__restrict__ seg, uint8_t *__restrict__ mask)
+                                                        const unsigned *__restrict__ seg, uint8_t *__restrict__ mask,
+                                                        size_t gstride, size_t sstride)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
+    grid += blockIdx.z * gstride;
+    seg += blockIdx.z * sstride;
+    mask += (size_t)blockIdx.z * P.n;
     const float4 a = ((const float4 *)bv)[i];
     int c0 = (int)floorf(__fdiv_rn(a.x - P.off0, P.vs0));
     int c1 = (int)floorf(__fdiv_rn(a.y - P.off1, P.vs1));
@@ -102,6 +111,41 @@ extern "C" size_t sassd_anchor_mask_workspace_bytes(int H0, int W0)
     return align_up((size_t)H0 * W0 * 4, 256) + align_up((size_t)nseg * W0 * 4, 256);
 }
 
+// `batch` samples in ONE launch sequence: sample b owns coordinate rows [row_offsets[b], row_offsets[b+1]) of `coors`,
+// mask[b*n_anchors ..] and one sassd_anchor_mask_workspace_bytes slice of the workspace.
+extern "C" int sassd_anchor_mask_batch(const int32_t *coors, const int32_t *row_offsets, int batch, int H0, int W0,
+                                       const float *anchors_bv, int n_anchors, const float *voxel_size,
+                                       const float *coors_range, float area_threshold, uint8_t *mask, void *workspace,
+                                       size_t workspace_bytes, void *stream_)
+{
+    if (!coors || !row_offsets || !anchors_bv || !voxel_size || !coors_range || !mask || !workspace) return SASSD_EINVAL;
+    if (H0 < 1 || W0 < 1 || n_anchors < 1 || batch < 1 || batch > 65535) return SASSD_EINVAL;
+    const size_t per = sassd_anchor_mask_workspace_bytes(H0, W0);
+    if (workspace_bytes < per * batch) return SASSD_ENOSPC;
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t gbytes = align_up((size_t)H0 * W0 * 4, 256);
+    unsigned *grid = (unsigned *)workspace;                                   // [batch] grids, then [batch] segment sums
+    unsigned *seg = (unsigned *)((char *)workspace + gbytes * batch);
+    const size_t gstride = gbytes / 4, sstride = (per - gbytes) / 4;
+    const int nseg = cdiv(H0, kRB);
+    int rc;
+    if ((rc = sassd_hip(hipMemsetAsync(grid, 0, gbytes * batch, stream)))) return rc;
+    // the voxel count of one cloud never exceeds H0*W0*D; launch for a generous fixed bound and exit early
+    const int max_rows = 1 << 18;
+    hipLaunchKernelGGL(am_scatter_kernel, dim3(cdiv(max_rows, 256), 1, batch), dim3(256), 0, stream, coors, row_offsets,
+                       row_offsets + 1, W0, grid, gstride);
+    hipLaunchKernelGGL(am_rowscan_kernel, dim3(H0, 1, batch), dim3(256), 0, stream, grid, W0, gstride);
+    hipLaunchKernelGGL(am_colseg_kernel, dim3(cdiv(W0, 256), nseg, batch), dim3(256), 0, stream, grid, H0, W0, seg, gstride,
+                       sstride);
+    hipLaunchKernelGGL(am_segscan_kernel, dim3(cdiv(W0, 256), 1, batch), dim3(256), 0, stream, seg, nseg, W0, sstride);
+    AmParams P;
+    P.vs0 = voxel_size[0]; P.vs1 = voxel_size[1]; P.off0 = coors_range[0]; P.off1 = coors_range[1];
+    P.thr = area_threshold; P.H0 = H0; P.W0 = W0; P.n = n_anchors;
+    hipLaunchKernelGGL(am_anchor_kernel, dim3(cdiv(n_anchors, 256), 1, batch), dim3(256), 0, stream, anchors_bv, P,
+                       (const unsigned *)grid, (const unsigned *)seg, mask, gstride, sstride);
+    return sassd_launch_status();
+}
+
 extern "C" int sassd_anchor_mask(const int32_t *coors, const int32_t *row_begin_ptr, const int32_t *row_end_ptr,
                                  int H0, int W0, const float *anchors_bv, int n_anchors, const float *voxel_size,
                                  const float *coors_range, float area_threshold, uint8_t *mask, void *workspace,
@@ -111,22 +155,23 @@ extern "C" int sassd_anchor_mask(const int32_t *coors, const int32_t *row_begin_
     if (H0 < 1 || W0 < 1 || n_anchors < 1) return SASSD_EINVAL;
     if (workspace_bytes < sassd_anchor_mask_workspace_bytes(H0, W0)) return SASSD_ENOSPC;
     hipStream_t stream = (hipStream_t)stream_;
+    const size_t gbytes = align_up((size_t)H0 * W0 * 4, 256);
     unsigned *grid = (unsigned *)workspace;
-    unsigned *seg = (unsigned *)((char *)workspace + align_up((size_t)H0 * W0 * 4, 256));
+    unsigned *seg = (unsigned *)((char *)workspace + gbytes);
     const int nseg = cdiv(H0, kRB);
     int rc;
     if ((rc = sassd_hip(hipMemsetAsync(grid, 0, (size_t)H0 * W0 * 4, stream)))) return rc;
-    // the voxel count of one cloud never exceeds H0*W0*D; launch for a generous fixed bound and exit early
     const int max_rows = 1 << 18;
     hipLaunchKernelGGL(am_scatter_kernel, dim3(cdiv(max_rows, 256)), dim3(256), 0, stream, coors, row_begin_ptr,
-                       row_end_ptr, W0, grid);
-    hipLaunchKernelGGL(am_rowscan_kernel, dim3(H0), dim3(256), 0, stream, grid, W0);
-    hipLaunchKernelGGL(am_colseg_kernel, dim3(cdiv(W0, 256), nseg), dim3(256), 0, stream, grid, H0, W0, seg);
-    hipLaunchKernelGGL(am_segscan_kernel, dim3(cdiv(W0, 256)), dim3(256), 0, stream, seg, nseg, W0);
+                       row_end_ptr, W0, grid, (size_t)0);
+    hipLaunchKernelGGL(am_rowscan_kernel, dim3(H0), dim3(256), 0, stream, grid, W0, (size_t)0);
+    hipLaunchKernelGGL(am_colseg_kernel, dim3(cdiv(W0, 256), nseg), dim3(256), 0, stream, grid, H0, W0, seg, (size_t)0,
+                       (size_t)0);
+    hipLaunchKernelGGL(am_segscan_kernel, dim3(cdiv(W0, 256)), dim3(256), 0, stream, seg, nseg, W0, (size_t)0);
     AmParams P;
     P.vs0 = voxel_size[0]; P.vs1 = voxel_size[1]; P.off0 = coors_range[0]; P.off1 = coors_range[1];
     P.thr = area_threshold; P.H0 = H0; P.W0 = W0; P.n = n_anchors;
     hipLaunchKernelGGL(am_anchor_kernel, dim3(cdiv(n_anchors, 256)), dim3(256), 0, stream, anchors_bv, P,
-                       (const unsigned *)grid, (const unsigned *)seg, mask);
+                       (const unsigned *)grid, (const unsigned *)seg, mask, (size_t)0, (size_t)0);
     return sassd_launch_status();
 }

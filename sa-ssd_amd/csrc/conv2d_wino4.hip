@@ -81,45 +81,59 @@ __device__ __forceinline__ void bt_vec(const float (&d)[6], float (&o)[6])
 
 struct W4Geom { int B, C, H, W, TH, TW, T, Tp; };
 
-// one thread = one (channel, tile): 36 loads (neighbouring threads' patches overlap: L1), 36 coalesced plane stores
+// one thread = one (channel, tile): 36 loads (neighbouring threads' patches overlap: L1); the 36 x 256 results of a
+// workgroup go through LDS so that every plane row leaves as 16-byte stores (dword stores cost ~6x more per byte)
 __global__ void __launch_bounds__(256) wino4_in_kernel(const float *__restrict__ x, W4Geom G, float *__restrict__ V)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float tr[36 * 256];
+    const int t0 = blockIdx.x * 256;
+    const int t = t0 + threadIdx.x;
     const int c = blockIdx.y;
-    if (t >= G.T) return;
-    const int tpi = G.TH * G.TW;
-    const int b = t / tpi, r = t - b * tpi;
-    const int ty = r / G.TW, tx = r - ty * G.TW;
-    const float *src = x + ((size_t)b * G.C + c) * G.H * G.W;
-    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-    float d[6][6];
+    if (t < G.T) {
+        const int tpi = G.TH * G.TW;
+        const int b = t / tpi, r = t - b * tpi;
+        const int ty = r / G.TW, tx = r - ty * G.TW;
+        const float *src = x + ((size_t)b * G.C + c) * G.H * G.W;
+        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+        float d[6][6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int yy = y0 + i;
-        const bool rok = yy >= 0 && yy < G.H;
+        for (int i = 0; i < 6; ++i) {
+            const int yy = y0 + i;
+            const bool rok = yy >= 0 && yy < G.H;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int xx = x0 + j;
+                d[i][j] = (rok && xx >= 0 && xx < G.W) ? src[(size_t)yy * G.W + xx] : 0.f;
+            }
+        }
+        float u[6][6];                                    // u[j] = B^T (column j of d)
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const int xx = x0 + j;
-            d[i][j] = (rok && xx >= 0 && xx < G.W) ? src[(size_t)yy * G.W + xx] : 0.f;
+            const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+            float o[6];
+            bt_vec(col, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) u[i][j] = o[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float o[6];
+            bt_vec(u[i], o);                              // (B^T d) B = rows transformed again
+#pragma unroll
+            for (int j = 0; j < 6; ++j) tr[(i * 6 + j) * 256 + threadIdx.x] = o[j];
         }
     }
-    float u[6][6];                                    // u[j] = B^T (column j of d)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
-        float o[6];
-        bt_vec(col, o);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) u[i][j] = o[i];
-    }
+    __syncthreads();
+    // 36 planes x 64 float4: columns up to the padded width are written (the padding only feeds padding columns of M)
     const size_t plane = (size_t)G.C * G.Tp;
-    float *dst = V + (size_t)c * G.Tp + t;
+    const int c4 = threadIdx.x & 63;
+    if (t0 + c4 * 4 < G.Tp) {
+        float *dst = V + (size_t)c * G.Tp + t0 + c4 * 4;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        float o[6];
-        bt_vec(u[i], o);                              // (B^T d) B = rows transformed again
-#pragma unroll
-        for (int j = 0; j < 6; ++j) dst[(size_t)(i * 6 + j) * plane] = o[j];
+        for (int k = 0; k < 9; ++k) {
+            const int p = (threadIdx.x >> 6) + 4 * k;
+            *reinterpret_cast<float4 *>(dst + (size_t)p * plane) = *reinterpret_cast<const float4 *>(tr + p * 256 + c4 * 4);
+        }
     }
 }
 
@@ -178,12 +192,18 @@ __global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict_
 }
 
 // ---- the 36 GEMMs ---------------------------------------------------------------------------------------------------
+// NP independent GEMMs  M_p [Cout x N] = U_p^T [Cout x Cin] . V_p [Cin x N]  with K-major operands (U_p [Cin][Cout],
+// V_p [Cin][ldv], M_p [Cout][ldm]).  Winograd: p = position, 36 of them.  A 1x1 convolution over NCHW is the same
+// problem with p = image, U shared (su = 0), V_p = x[p] [Cin][H*W], M_p = y[p] -- plus the per-channel epilogue.
 struct W4Gemm {
     const float *U, *V;
     float *M;
-    int Cin, Cout, Tp;
-    int nmb, nnb;            // channel blocks, tile blocks
-    int pairs_per_xcd;       // (position, channel block) pairs per XCD
+    const float *scale, *shift;      // optional per-output-channel epilogue (1x1 convolution use)
+    size_t su, sv, sm;               // per-problem strides (floats)
+    int np, Cin, Cout, ldv, ldm, ncols, relu;
+    int nmb, nnb;            // channel blocks, column blocks
+    int nseg, seglen;        // every (problem, channel block) pair is cut into nseg runs of seglen column blocks
+    int pairs_per_xcd;       // (pair, run) items per XCD
     int dbg;                 // ablation: bit0 stage only the first chunk, bit1 no MFMA
 };
 
@@ -202,12 +222,14 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
     // XCD-local order: blockIdx % 8 = XCD; inside an XCD the tile blocks of one (position, channel block) pair are
     // consecutive, so concurrently running workgroups share U[p] (and V[p] with the other channel blocks' XCDs only)
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int q = j / P.nnb, nb = j - q * P.nnb;
-    const int pair = xcd * P.pairs_per_xcd + q;
-    if (pair >= 36 * P.nmb) return;
+    const int q = j / P.seglen, within = j - q * P.seglen;
+    const int item = xcd * P.pairs_per_xcd + q;
+    if (item >= P.np * P.nmb * P.nseg) return;
+    const int pair = item / P.nseg, nb = (item - pair * P.nseg) * P.seglen + within;
+    if (nb >= P.nnb) return;
     const int p = pair / P.nmb, mb = pair - p * P.nmb;
-    const float *Ub = P.U + (size_t)p * P.Cin * P.Cout + mb * BM;          // + k * Cout
-    const float *Vb = P.V + (size_t)p * P.Cin * P.Tp + nb * BN;            // + k * Tp
+    const float *Ub = P.U + (size_t)p * P.su + mb * BM;                    // + k * Cout
+    const float *Vb = P.V + (size_t)p * P.sv + nb * BN;                    // + k * ldv
     // DMA map: wave-load id t = wave + NWV * i; t < NLA: A rows (BM/4 16-byte pieces per row), else B rows.  The LDS
     // destination of a wave-load is lane-linear, i.e. the natural row-major [k][m] / [k][n] image.
     const float *src[LPW];
@@ -223,8 +245,8 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
             dst[i] = t * 256;
         } else {
             const int e = (t - NLA) * 64 + lane;
-            src[i] = Vb + (size_t)(e / (BN / 4)) * P.Tp + (e % (BN / 4)) * 4;
-            kstride[i] = (size_t)KC * P.Tp;
+            src[i] = Vb + (size_t)(e / (BN / 4)) * P.ldv + (e % (BN / 4)) * 4;
+            kstride[i] = (size_t)KC * P.ldv;
             dst[i] = BM * KC + (t - NLA) * 256;
         }
     }
@@ -278,12 +300,20 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
             for (int r = 0; r < 16; ++r)
                 img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * WCOLS + b * 32 + l31] = acc[a][b][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private image: no barrier needed
-    float *Mb = P.M + ((size_t)p * P.Cout + mb * BM + wm * 64) * P.Tp + nb * BN + wn * WCOLS;
+    const int co0 = mb * BM + wm * 64;
+    float *Mb = P.M + (size_t)p * P.sm + (size_t)co0 * P.ldm + nb * BN + wn * WCOLS;
     constexpr int C4 = WCOLS / 4, RPI = 64 / C4;        // float4 per row, rows per wave-instruction
+    const bool epi = P.scale || P.shift || P.relu;
 #pragma unroll
     for (int i = 0; i < 64 / RPI; ++i) {
         const int row = i * RPI + lane / C4, c4 = lane % C4;
-        *reinterpret_cast<float4 *>(Mb + (size_t)row * P.Tp + c4 * 4) = *reinterpret_cast<const float4 *>(img + row * WCOLS + c4 * 4);
+        float4 v = *reinterpret_cast<const float4 *>(img + row * WCOLS + c4 * 4);
+        if (epi) {
+            const float sc = P.scale ? P.scale[co0 + row] : 1.f, sh = P.shift ? P.shift[co0 + row] : 0.f;
+            v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+            if (P.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        *reinterpret_cast<float4 *>(Mb + (size_t)row * P.ldm + c4 * 4) = v;
     }
 }
 
@@ -299,10 +329,15 @@ int launch_w4_gemm(W4Gemm P, hipStream_t stream)
     const void *fn = (const void *)wino4_gemm_kernel<WM, WN, NB, KC>;
     int rc = sassd_dyn_lds(fn, lds, attr_done);
     if (rc) return rc;
-    P.nmb = P.Cout / BM; P.nnb = P.Tp / BN;
-    P.pairs_per_xcd = cdiv(36 * P.nmb, 8);
+    P.nmb = P.Cout / BM; P.nnb = P.ncols / BN;
+    // few pairs (a 1x1 convolution of one image has two): cut each pair's column blocks into runs so that all 8 XCDs work
+    const int pairs = P.np * P.nmb;
+    P.nseg = pairs >= 32 ? 1 : cdiv(32, pairs);
+    if (P.nseg > P.nnb) P.nseg = P.nnb;
+    P.seglen = cdiv(P.nnb, P.nseg);
+    P.pairs_per_xcd = cdiv(pairs * P.nseg, 8);
     P.dbg = g_wino4_dbg;
-    hipLaunchKernelGGL((wino4_gemm_kernel<WM, WN, NB, KC>), dim3(8 * P.pairs_per_xcd * P.nnb), dim3(WM * WN * 64), lds,
+    hipLaunchKernelGGL((wino4_gemm_kernel<WM, WN, NB, KC>), dim3(8 * P.pairs_per_xcd * P.seglen), dim3(WM * WN * 64), lds,
                        stream, P);
     return sassd_launch_status();
 }
@@ -310,17 +345,18 @@ int launch_w4_gemm(W4Gemm P, hipStream_t stream)
 // Tile-block width of the GEMM (32 WN columns, WN waves across): all workgroups do equal work, so the launch takes
 // ceil(units / resident slots) rounds -- pick the width whose LAST round is fullest.  KITTI B=1 (2200 tiles): 160
 // columns -> 1008 units = 1.97 rounds of 512 slots (64 / 96 / 128 / 192 columns all waste 17 %).
-inline int w4_pick_wn(int T, int Cout)
+inline int w4_pick_wn(int T, int Cout, int np = 36, bool exact = false)
 {
-    int best = 4;
+    int best = exact ? 0 : 4;
     double best_cost = 1e30;
     for (int wn = 2; wn <= 6; ++wn) {
         const int bn = 32 * wn;
+        if (exact && T % bn) continue;                // (1x1 convolution: no padding columns in an NCHW tensor)
         const size_t lds = (size_t)2 * (kBM + bn) * kKC * 4;
         int wgs = (int)((size_t)160 * 1024 / lds);
         if (wgs > 32 / (2 * wn)) wgs = 32 / (2 * wn);
         if (wgs < 1) wgs = 1;
-        const long units = (long)36 * (Cout / kBM) * cdiv(T, bn);
+        const long units = (long)np * (Cout / kBM) * cdiv(T, bn);
         const long rounds = (units + 256L * wgs - 1) / (256L * wgs);
         const double cost = (double)rounds * wgs * bn;
         if (cost < best_cost - 1e-9) { best_cost = cost; best = wn; }
@@ -340,7 +376,8 @@ inline int w4_tiles_padded(int B, int H, int W, int Cout)
 }  // namespace
 
 // ablation / geometry switches of the F(4x4) GEMM (tools/run_wino4.py): cfg 0 = pick the tile-block width from the
-// tile count, 2..6 = force 32*cfg columns; dbg bit0 stage only the first chunk, bit1 no MFMA
+// tile count, 2..6 = force 32*cfg columns; dbg bit0 stage only the first chunk, bit1 no MFMA, bits 4 / 5 / 6 skip the
+// input transform / the GEMM / the output transform (per-kernel timing on live buffers, bench.py)
 extern "C" void sassd_debug_set_wino4(int cfg, int dbg) { g_wino4_cfg = cfg; g_wino4_dbg = dbg; }
 
 extern "C" int sassd_conv2d_wino4_supported(int Cin, int Cout, int H, int W)
@@ -387,11 +424,14 @@ extern "C" int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, con
     float *M = (float *)((char *)workspace + align_up(36 * (size_t)Cin * G.Tp * 4, 256));
     // the padding columns of V feed padding columns of M that the output transform never reads; they only have to be
     // finite-or-not-read: the GEMM's columns are independent, so stale values cannot leak into real tiles
-    hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V);
+    if (!(g_wino4_dbg & 16))
+        hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V);
     W4Gemm P;
-    P.U = w_packed; P.V = V; P.M = M; P.Cin = Cin; P.Cout = Cout; P.Tp = G.Tp;
-    int rc;
-    switch (w4_wn(G.T, Cout)) {                                      // 128 channels x 32 WN tiles, 2 x WN waves of 64 x 32
+    P.U = w_packed; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0;
+    P.np = 36; P.Cin = Cin; P.Cout = Cout; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;
+    P.su = (size_t)Cin * Cout; P.sv = (size_t)Cin * G.Tp; P.sm = (size_t)Cout * G.Tp;
+    int rc = SASSD_OK;
+    if (!(g_wino4_dbg & 32)) switch (w4_wn(G.T, Cout)) {                                      // 128 channels x 32 WN tiles, 2 x WN waves of 64 x 32
     case 2: rc = launch_w4_gemm<2, 2, 1, kKC>(P, stream); break;
     case 3: rc = launch_w4_gemm<2, 3, 1, kKC>(P, stream); break;
     case 4: rc = launch_w4_gemm<2, 4, 1, kKC>(P, stream); break;
@@ -401,7 +441,55 @@ extern "C" int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, con
     if (rc) return rc;
     W4Geom Go = G;
     Go.C = Cout;
-    hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
-                       scale, shift, relu, y);
+    if (!(g_wino4_dbg & 64))
+        hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
+                           scale, shift, relu, y);
     return sassd_launch_status();
+}
+
+
+// ---- 1x1 convolution (BEV conv7, cmn.py:262) on the same GEMM kernel: y[b] [Cout x HW] = W [Cout x Cin] . x[b] [Cin x HW]
+namespace {
+__global__ void conv1x1_pack_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ U)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * Cin) return;
+    const int co = i % Cout, ci = i / Cout;
+    U[(size_t)ci * Cout + co] = w[(size_t)co * Cin + ci];
+}
+}  // namespace
+
+extern "C" int sassd_conv1x1_gemm_supported(int Cin, int Cout, int H, int W)
+{
+    if (!(Cin >= kKC && Cin % kKC == 0 && Cout >= kBM && Cout % kBM == 0 && H > 0 && W > 0)) return 0;
+    return w4_pick_wn(H * W, Cout, 1, true) ? 1 : 0;
+}
+
+extern "C" int sassd_conv1x1_gemm_pack_weight(const float *w, int Cout, int Cin, float *packed, void *stream_)
+{
+    if (!w || !packed || Cin < 1 || Cout < 1) return SASSD_EINVAL;
+    hipLaunchKernelGGL(conv1x1_pack_kernel, dim3(cdiv(Cout * Cin, 256)), dim3(256), 0, (hipStream_t)stream_, w, Cout, Cin,
+                       packed);
+    return sassd_launch_status();
+}
+
+extern "C" int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *scale, const float *shift,
+                                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, void *stream_)
+{
+    if (!x || !w_packed || !y || batch < 1 || !sassd_conv1x1_gemm_supported(Cin, Cout, H, W)) return SASSD_EINVAL;
+    if (((uintptr_t)y & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)x & 15)) return SASSD_EINVAL;
+    const int hw = H * W;
+    W4Gemm P;
+    P.U = w_packed; P.V = x; P.M = y; P.scale = scale; P.shift = shift; P.relu = relu;
+    P.np = batch; P.Cin = Cin; P.Cout = Cout; P.ldv = hw; P.ldm = hw; P.ncols = hw;
+    P.su = 0; P.sv = (size_t)Cin * hw; P.sm = (size_t)Cout * hw;
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (w4_pick_wn(hw, Cout, batch, true)) {
+    case 2: return launch_w4_gemm<2, 2, 1, kKC>(P, stream);
+    case 3: return launch_w4_gemm<2, 3, 1, kKC>(P, stream);
+    case 4: return launch_w4_gemm<2, 4, 1, kKC>(P, stream);
+    case 5: return launch_w4_gemm<2, 5, 1, kKC>(P, stream);
+    case 6: return launch_w4_gemm<2, 6, 1, kKC>(P, stream);
+    }
+    return SASSD_EINVAL;
 }

@@ -234,6 +234,10 @@ class Graph:
             pass
 
 
+def debug_set_wino4(cfg=0, dbg=0):
+    _C.lib().sassd_debug_set_wino4(int(cfg), int(dbg))
+
+
 def debug_set_spconv(flags):
     _C.lib().sassd_debug_set_spconv(int(flags))
 
@@ -409,6 +413,30 @@ def conv2d_wino4_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=No
     return y
 
 
+def conv1x1_gemm_supported(cin, cout, h, w):
+    return bool(_C.lib().sassd_conv1x1_gemm_supported(int(cin), int(cout), int(h), int(w)))
+
+
+def conv1x1_gemm_pack_weight(w):
+    """w [Cout,Cin,1,1] -> [Cin][Cout] (K-major operand of the fp32-MFMA GEMM)."""
+    _chk_cuda(w)
+    cout, cin = w.shape[0], w.shape[1]
+    packed = torch.empty(cin * cout, dtype=torch.float32, device=w.device)
+    _C.check(_C.lib().sassd_conv1x1_gemm_pack_weight(_C.ptr(w.contiguous()), cout, cin, _C.ptr(packed), _C.stream()),
+             "sassd_conv1x1_gemm_pack_weight")
+    return packed
+
+
+def conv1x1_gemm_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=None):
+    _chk_cuda(x, w_packed, scale, shift)
+    b, cin, h, w = x.shape
+    if y is None:
+        y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().sassd_conv1x1_gemm_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
+                                             _C.ptr(y), b, cin, cout, h, w, _C.stream()), "sassd_conv1x1_gemm_fwd")
+    return y
+
+
 def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False):
     """x [B,Cin,H,W], dy [B,Cout,H,W] -> dw [Cout,Cin,k,k] on the fp32-MFMA split-K kernel."""
     _chk_cuda(x, dy)
@@ -440,6 +468,20 @@ def anchor_mask(coors, row_begin_ptr, row_end_ptr, h0, w0, anchors_bv, voxel_siz
                              n, vs.ctypes.data, cr.ctypes.data, float(area_threshold), _C.ptr(mask), _C.ptr(ws), wsb,
                              _C.stream())
     _C.check(rc, "sassd_anchor_mask")
+    return mask
+
+
+def anchor_mask_batch(coors, row_offsets, batch, h0, w0, anchors_bv, voxel_size, coors_range, area_threshold, mask):
+    """anchors_mask of `batch` samples in one launch sequence (row_offsets: device int32 [batch+1])."""
+    L = _C.lib()
+    n = anchors_bv.shape[0]
+    vs, cr = _f32(voxel_size), _f32(coors_range)
+    wsb = L.sassd_anchor_mask_workspace_bytes(h0, w0) * batch
+    ws = workspace("anchor_mask_batch", wsb, coors.device)
+    rc = L.sassd_anchor_mask_batch(_C.ptr(coors), _C.ptr(row_offsets), batch, h0, w0, _C.ptr(anchors_bv), n,
+                                   vs.ctypes.data, cr.ctypes.data, float(area_threshold), _C.ptr(mask), _C.ptr(ws), wsb,
+                                   _C.stream())
+    _C.check(rc, "sassd_anchor_mask_batch")
     return mask
 
 

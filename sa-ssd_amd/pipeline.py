@@ -104,8 +104,11 @@ class InferencePlan:
                     wino = 4
                 elif K.conv2d_wino_supported(w.shape[1], w.shape[0], self.H, self.W):
                     wino = 2
+            if w.shape[2] == 1 and winograd and K.conv1x1_gemm_supported(w.shape[1], w.shape[0], self.H, self.W):
+                wino = 1                             # 1x1 layer (conv7): the same MFMA GEMM kernel, one problem per image
             wp = (K.conv2d_wino4_pack_weight(w.contiguous()) if wino == 4 else
-                  K.conv2d_wino_pack_weight(w.contiguous()) if wino == 2 else K.conv2d_pack_weight(w.contiguous()))
+                  K.conv2d_wino_pack_weight(w.contiguous()) if wino == 2 else
+                  K.conv1x1_gemm_pack_weight(w.contiguous()) if wino == 1 else K.conv2d_pack_weight(w.contiguous()))
             self.bev.append((wp, w.shape[0], w.shape[2], scale, shift, wino))
         self.wino4_ws = None
         if any(l[5] == 4 for l in self.bev):
@@ -240,14 +243,15 @@ class InferencePlan:
                 self.rb_ev["down%d" % lvl].record()
                 self.tables[lvl + 1].build(self.idx[lvl + 1], self.n[lvl + 1], self.shapes[lvl + 1], B, self.status)
 
-    def backbone(self, keep_middle=False, anchors_mask=None, densify=True):
+    def backbone(self, keep_middle=False, anchors_mask=None, densify=True, masks=True):
         main = torch.cuda.current_stream(self.dev)
         e0 = self._ev() if self.prof is not None else None
         if self.overlap:
             self.side.wait_stream(main)                 # voxel coordinates are ready
             with torch.cuda.stream(self.side):
                 self.rulebooks()
-                self.anchor_masks(anchors_mask)         # also coordinate-only work
+                if masks:
+                    self.anchor_masks(anchors_mask)     # also coordinate-only work
                 self.mask_ev.record()
         else:
             self.rulebooks()
@@ -286,6 +290,8 @@ class InferencePlan:
                 K.conv2d_wino4_fwd(x, wp, cout, scale, shift, True, y, self.wino4_ws)
             elif wino == 2:
                 K.conv2d_wino_fwd(x, wp, cout, scale, shift, True, y)
+            elif wino == 1:
+                K.conv1x1_gemm_fwd(x, wp, cout, scale, shift, True, y)
             else:
                 K.conv2d_fwd(x, wp, cout, ks, scale, shift, True, y)
             self._seg("bev_conv%d" % i, e0)
@@ -302,9 +308,8 @@ class InferencePlan:
             self.mask.copy_(masks.view(self.B, -1).to(torch.uint8))
             return
         H0, W0 = self.shape0[1], self.shape0[2]
-        for b in range(self.B):
-            K.anchor_mask(self.idx[0], self.row_off[b:b + 1], self.row_off[b + 1:b + 2], H0, W0, self.anchors_bv,
-                          self.voxel_size, self.pc_range, self.area_thr, self.mask[b])
+        K.anchor_mask_batch(self.idx[0], self.row_off, self.B, H0, W0, self.anchors_bv, self.voxel_size, self.pc_range,
+                            self.area_thr, self.mask)
 
     def post(self):
         e0 = self._ev() if self.prof is not None else None
@@ -390,7 +395,7 @@ class InferencePlan:
                 if "backbone" in stages:
                     self.backbone()
                 elif "sparse" in stages:              # rulebooks + the 14 sparse convs only (roofline measurement)
-                    self.backbone(densify=False)
+                    self.backbone(densify=False, masks=False)
                 if "tail" in stages:
                     self._tail(None)
                 elif self.overlap:

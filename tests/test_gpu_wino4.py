@@ -37,3 +37,23 @@ def test_conv2d_wino4(dev, b, cin, cout, hw, relu):
     assert not K.conv2d_wino4_supported(28, 28, 200, 176) and not K.conv2d_wino4_supported(256, 256, 198, 176)
     assert not K.conv2d_wino4_supported(256, 28, 200, 176) and not K.conv2d_wino4_supported(48, 256, 200, 176)
     assert not K.conv2d_wino4_supported(256, 128, 200, 176)
+
+
+@pytest.mark.parametrize("b,cin,cout,hw,relu", [(1, 256, 256, (200, 176), True), (2, 64, 128, (12, 16), False),
+                                                (3, 32, 384, (10, 32), True)])
+def test_conv1x1_gemm(dev, b, cin, cout, hw, relu):
+    """1x1 convolution on the MFMA GEMM kernel (one problem per image) against torch-CPU conv2d."""
+    g = torch.Generator().manual_seed(cin + cout + hw[1])
+    x = torch.randn(b, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    raw = torch.nn.functional.conv2d(x, w)
+    ref = raw * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    ref = torch.relu(ref) if relu else ref
+    assert K.conv1x1_gemm_supported(cin, cout, *hw)
+    wp = K.conv1x1_gemm_pack_weight(w.to(dev))
+    y = K.conv1x1_gemm_fwd(x.to(dev), wp, cout, sc.to(dev), sh.to(dev), relu)
+    assert (y.cpu() - ref).abs().max().item() <= 1e-5 * max(1.0, raw.abs().max().item())
+    y2 = K.conv1x1_gemm_fwd(x.to(dev), wp, cout)
+    assert (y2.cpu() - raw).abs().max().item() <= 1e-5 * max(1.0, raw.abs().max().item())
+    assert not K.conv1x1_gemm_supported(256, 28, 200, 176) and not K.conv1x1_gemm_supported(256, 256, 188, 188)

@@ -96,8 +96,9 @@ def oracle_params(sd):
     return vx, bev, head, ps
 
 
-def oracle_forward(sd, clouds, anchors, anchors_bv, cfg, num_class=1, keep=None):
-    """Whole path on the CPU oracle. clouds: list of numpy [N,4]. Returns dict of intermediate + final results."""
+def oracle_features(sd, clouds, anchors, anchors_bv, cfg, num_class=1):
+    """The threshold-free part of the path on the CPU oracle: voxels -> sparse backbone -> BEV net -> head maps, anchor
+    masks.  clouds: list of numpy [N,4]."""
     vx, bev, head, ps = oracle_params(sd)
     feats, coors, coors3 = [], [], []
     for b, pts in enumerate(clouds):
@@ -114,12 +115,58 @@ def oracle_forward(sd, clouds, anchors, anchors_bv, cfg, num_class=1, keep=None)
     box, cls, dirp = onets.ssd_head_forward(x, head, num_class)
     masks = np.stack([onets.anchors_mask(c, anchors_bv, cfg["voxel_size"], cfg["pc_range"], cfg["grid_xyz"], 1)
                       for c in coors3])
-    an = torch.from_numpy(anchors).view(1, -1, 7).expand(B, -1, -1)
-    guided = onets.guided_anchors(box, cls, dirp, an, torch.from_numpy(masks), num_class, 0.1)
-    logits, psfeat = onets.pswarp_forward(conv6, ps, [g[0] for g in guided])
-    dets = [onets.rescore(g[0], lg, g[1], cfg.get("score_thr", 0.3), 0.1) for g, lg in zip(guided, logits)]
+    bcls = torch.sigmoid(cls.reshape(B, -1, num_class)).max(-1)[0]
+    masked_scores = torch.cat([bcls[b][torch.from_numpy(masks[b])] for b in range(B)])
     return dict(feats=feats, coors=coors, x3=x3, idx3=idx3, acts=acts, dense=dense, x=x, conv6=conv6, box=box, cls=cls,
-                dirp=dirp, masks=masks, guided=guided, logits=logits, psfeat=psfeat, dets=dets, books=books)
+                dirp=dirp, masks=masks, books=books, ps=ps, anchors=anchors, num_class=num_class, B=B,
+                masked_scores=masked_scores, grid_offsets=cfg.get("grid_offsets", (0.0, 40.0)),
+                featmap_stride=cfg.get("featmap_stride", 0.4))
+
+
+def oracle_select(ft, rpn_thr=0.1, score_thr=None, iou_thr=0.1):
+    """The threshold-dependent tail: guided anchors (sigmoid > rpn_thr), PSWarp logits, rescoring + rotated NMS
+    (skipped when score_thr is None)."""
+    B, nc = ft["B"], ft["num_class"]
+    an = torch.from_numpy(ft["anchors"]).view(1, -1, 7).expand(B, -1, -1)
+    guided = onets.guided_anchors(ft["box"], ft["cls"], ft["dirp"], an, torch.from_numpy(ft["masks"]), nc, rpn_thr)
+    logits, psfeat = onets.pswarp_forward(ft["conv6"], ft["ps"], [g[0] for g in guided], ft["grid_offsets"],
+                                          ft["featmap_stride"])
+    out = dict(guided=guided, logits=logits, psfeat=psfeat)
+    if score_thr is not None:
+        out["dets"] = [onets.rescore(g[0], lg, g[1], score_thr, iou_thr) for g, lg in zip(guided, logits)]
+    return out
+
+
+def safe_threshold(base, values, margin=1e-4, step=2.5e-4):
+    """A threshold near `base` that no value approaches within `margin`: selections made with it are identical for any
+    two implementations whose values agree to `margin` (GPU expf vs libm, fp32 sums in another order), so a parity
+    test never has to skip a sample because a candidate sits on the threshold."""
+    v = np.asarray(values, np.float64).ravel()
+    for k in range(400):
+        t = base + ((k + 1) // 2) * step * (1 if k % 2 else -1) if k else base
+        if v.size == 0 or np.abs(v - t).min() > margin:
+            return float(np.float32(t))
+    raise AssertionError("no safe threshold near %g" % base)
+
+
+def oracle_forward_safe(sd, clouds, anchors, anchors_bv, cfg, num_class=1, rpn_thr=0.1, score_thr=0.3):
+    """Whole path on the CPU oracle with thresholds nudged (by multiples of 2.5e-4) away from every candidate score.
+    Returns (results dict, rpn_thr, score_thr) -- hand the two thresholds to the plan under test."""
+    ft = oracle_features(sd, clouds, anchors, anchors_bv, cfg, num_class)
+    rpn = safe_threshold(rpn_thr, ft["masked_scores"].numpy())
+    sel = oracle_select(ft, rpn)
+    sc = safe_threshold(score_thr, torch.sigmoid(torch.cat([l.reshape(-1) for l in sel["logits"]])).numpy()
+                        if len(sel["logits"]) else np.zeros(0))
+    sel["dets"] = [onets.rescore(g[0], lg, g[1], sc, 0.1) for g, lg in zip(sel["guided"], sel["logits"])]
+    ft.update(sel)
+    return ft, rpn, sc
+
+
+def oracle_forward(sd, clouds, anchors, anchors_bv, cfg, num_class=1, keep=None):
+    """Whole path on the CPU oracle with the configured thresholds (0.1 / cfg score_thr)."""
+    ft = oracle_features(sd, clouds, anchors, anchors_bv, cfg, num_class)
+    ft.update(oracle_select(ft, 0.1, cfg.get("score_thr", 0.3)))
+    return ft
 
 
 from oracle import clib  # noqa: E402

@@ -32,17 +32,51 @@ def _model(cfgfile="configs/car_cfg.py", seed=0):
     return m, c
 
 
-def _close(a, b, tol=1e-4):
-    """|a - b| <= tol * max(1, |b|): 1e-4 absolute for O(1) quantities (north_star), fp32-relative for box
-    dimensions / coordinates of magnitude 10-70 (a 22 m long random-weight box carries 2e-6 * 22 of rounding)."""
-    a, b = np.asarray(a), np.asarray(b)
-    return bool(np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))))
+def _abs_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max()) if a.size else 0.0
 
 
-def _match_sets(got_boxes, got_scores, ref_boxes, ref_scores, atol=1e-4):
-    assert len(got_boxes) == len(ref_boxes), (len(got_boxes), len(ref_boxes))
-    assert _close(got_boxes, ref_boxes, atol), np.abs(got_boxes - ref_boxes).max()
-    assert np.abs(got_scores - ref_scores).max() < atol
+def _box_ok(got, want, unbounded):
+    """1e-4 ABSOLUTE on every box field (north_star).  `unbounded` (the Waymo-scale random-weight model only, whose
+    activations grow with the 37 % BEV occupancy until regressions decode to 1e13 m boxes): fp32-relative 2e-5 on
+    fields larger than 5 m."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    tol = np.maximum(1e-4, 2e-5 * np.abs(want)) if unbounded else 1e-4
+    return bool(np.all(np.abs(got - want) <= tol))
+
+
+def _check_sample(tag, plan, res, ref, b, errs, unbounded=False):
+    """One sample against the oracle: guided anchors (same order), PSWarp logits, final boxes / scores / labels.
+    ABSOLUTE 1e-4 on every box field and score (north_star), no skipped cases: the thresholds handed to the plan were
+    chosen away from every oracle score (helpers.oracle_forward_safe)."""
+    gb, gl, gs = ref["guided"][b]
+    k = int(plan.df["counts"][b].item())
+    assert k == len(gb), (tag, b, k, len(gb))
+    got = plan.df["guided"][b, :k].cpu().numpy()
+    if k:
+        fe = np.abs(got.astype(np.float64) - gb.numpy()).max(0)
+        errs["guided_by_field(x,y,z,w,l,h,r)"] = np.maximum(errs.get("guided_by_field(x,y,z,w,l,h,r)", 0.0), fe)
+    e = _abs_err(got, gb.numpy())
+    errs["guided_boxes"] = max(errs.get("guided_boxes", 0.0), e)
+    assert _box_ok(got, gb.numpy(), unbounded), (tag, "guided anchors", e)
+    assert np.array_equal(plan.df["labels"][b, :k].cpu().numpy(), gl.numpy())
+    e = _abs_err(plan.logits[b, :k].cpu().numpy(), ref["logits"][b].numpy())
+    errs["pswarp_logits"] = max(errs.get("pswarp_logits", 0.0), e)
+    # part-sensitive logits average 28 samples of a feature map whose values reach |f| ~ 10 with random weights:
+    # 1e-4 absolute for O(1) features, fp32-relative to the sampled map otherwise
+    assert e <= max(1e-4, 2e-5 * float(ref["psfeat"].abs().max())), (tag, "logits", e)
+    d = ref["dets"][b]
+    if d is None:
+        assert res[b][0] is None, (tag, b)
+        return 0
+    assert res[b][0] is not None and len(res[b][0]) == len(d[0]), (tag, b, None if res[b][0] is None else len(res[b][0]), len(d[0]))
+    eb, es = _abs_err(res[b][0], d[0]), _abs_err(res[b][1], d[1])
+    errs["det_boxes"] = max(errs.get("det_boxes", 0.0), eb)
+    errs["det_scores"] = max(errs.get("det_scores", 0.0), es)
+    assert _box_ok(res[b][0], d[0], unbounded) and es <= 1e-4, (tag, "detections", eb, es)
+    assert np.array_equal(res[b][2], d[2])
+    return len(d[0])
 
 
 @pytest.mark.parametrize("frames,seed,score_thr", [(("k21",), 0, 0.3), (("small", "k17"), 1, 0.6)])
@@ -51,9 +85,9 @@ def test_pipeline_vs_oracle(dev, frames, seed, score_thr):
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     an, bv = _anchors()
     clouds = [H.frame(f, seed + i) for i, f in enumerate(frames)]
-    ref = H.oracle_forward(sd, clouds, an, bv, dict(CFG, score_thr=score_thr))
+    ref, rpn_thr, score_thr = H.oracle_forward_safe(sd, clouds, an, bv, CFG, score_thr=score_thr)
     B = len(clouds)
-    plan = InferencePlan(sd, batch_size=B, anchors=an, anchors_bv=bv, device=dev, score_thr=score_thr)
+    plan = InferencePlan(sd, batch_size=B, anchors=an, anchors_bv=bv, device=dev, rpn_thr=rpn_thr, score_thr=score_thr)
     plan.run_from_points([torch.from_numpy(p).to(dev) for p in clouds])
     torch.cuda.synchronize()
     assert int(plan.status.item()) == 0
@@ -68,40 +102,19 @@ def test_pipeline_vs_oracle(dev, frames, seed, score_thr):
     sp = plan.sp_out[:n3].cpu()
     e = (sp - ref["x3"]).abs().max().item()
     assert e < 1e-4 * max(1.0, ref["x3"].abs().max().item()), e
+    errs = {"sparse_features": e}
     # -- dense BEV stack
     for name, got in (("conv6", plan.conv6), ("x", plan.x)):
         r = ref[name]
         e = (got.cpu() - r).abs().max().item()
+        errs["bev_" + name] = e
         assert e < 2e-4 * max(1.0, r.abs().max().item()), (name, e)
     # -- anchors mask exact
     assert np.array_equal(plan.mask.cpu().numpy().astype(bool), ref["masks"])
-    # -- guided anchors: same order, boxes within 1e-4
-    cnt = plan.df["counts"].cpu().numpy()
-    for b in range(B):
-        gb, gl, gs = ref["guided"][b]
-        near = np.abs(gs.numpy() - 0.1) < 1e-5
-        if near.any():
-            continue                      # a candidate sits on the threshold: selection may legitimately differ
-        assert cnt[b] == len(gb), (cnt[b], len(gb))
-        k = cnt[b]
-        assert _close(plan.df["guided"][b, :k].cpu().numpy(), gb.numpy())
-        # part-sensitive logits average 28 samples of a feature map whose values reach |f| ~ 10 with random weights:
-        # budget 1e-4 absolute for O(1) features, fp32-relative to the sampled map otherwise
-        ltol = max(1e-4, 2e-5 * float(ref["psfeat"].abs().max()))
-        assert np.abs(plan.logits[b, :k].cpu().numpy() - ref["logits"][b].numpy()).max() < ltol
-    # -- final detections
     res = plan.results()
-    for b in range(B):
-        d = ref["dets"][b]
-        if d is None:
-            assert res[b][0] is None
-            continue
-        sc = torch.sigmoid(ref["logits"][b]).numpy()
-        if (np.abs(sc - score_thr) < 1e-5).any():
-            continue
-        _match_sets(res[b][0], res[b][1], d[0], d[1])
-        assert np.array_equal(res[b][2], d[2])
-    assert sum(1 for r in res if r[0] is not None) >= 1, "test vector produced no detections at all"
+    ndet = sum(_check_sample("car", plan, res, ref, b, errs) for b in range(B))
+    print("max abs errors vs the CPU oracle (%s): %s" % ("+".join(frames), {k: (["%.1e" % x for x in v] if isinstance(v, np.ndarray) else "%.2e" % v) for k, v in errs.items()}))
+    assert ndet >= 1, "test vector produced no detections at all"
 
 
 def test_reference_style_forward_test_api(dev):
@@ -129,7 +142,8 @@ def test_reference_style_forward_test_api(dev):
         if d is None:
             assert out[b]["boxes_lidar"] is None
         else:
-            _match_sets(out[b]["boxes_lidar"], out[b]["scores"], d[0], d[1])
+            assert len(out[b]["boxes_lidar"]) == len(d[0])
+            assert _abs_err(out[b]["boxes_lidar"], d[0]) <= 1e-4 and _abs_err(out[b]["scores"], d[1]) <= 1e-4
 
 
 def test_spconv_facade_matches_fused_plan(dev):
@@ -151,79 +165,77 @@ def test_spconv_facade_matches_fused_plan(dev):
     assert (conv6 - plan.conv6).abs().max().item() < 2e-4 * max(1.0, plan.conv6.abs().max().item())
 
 
-def test_multi_class_batch(dev):
-    """configs[3] shape: multi_cfg (Car + Pedestrian + Cyclist, 211200 anchors), batch > 1."""
+@pytest.mark.parametrize("frames", [("small", "small"), ("k21",) * 8])
+def test_multi_class_batch(dev, frames):
+    """configs[3]: multi_cfg (Car + Pedestrian + Cyclist, 211200 anchors) -- a two-sample batch of sparse frames and the
+    stated size, batch 8 of K21 frames."""
     model, c = _model("configs/multi_cfg.py", seed=4)
     names = c.data.val.class_names
     assert len(names) == 3 and model.rpn_head.conv_cls.out_channels == 18
-    sd = {k: v.clone() for k, v in model.state_dict().items()}
     an, bv = _anchors(names)
     assert an.shape[0] == 211200
-    clouds = [H.frame("small", 20), H.frame("small", 21)]
-    ref = H.oracle_forward(sd, clouds, an, bv, dict(CFG, score_thr=0.3), num_class=3)
-    plan = InferencePlan(sd, batch_size=2, num_class=3, anchors=an, anchors_bv=bv, device=dev, cap_k=4096, cap_d=1024)
+    B = len(frames)
+    clouds = [H.frame(f, 20 + i) for i, f in enumerate(frames)]
+    if frames[0] == "k21":                       # keep K ~ 10^2 per sample on full frames (capK 4096)
+        H.calibrate_cls_head(model, clouds[0], _anchors(names)[1], CFG, target_count=300)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref, rpn_thr, score_thr = H.oracle_forward_safe(sd, clouds, an, bv, CFG, num_class=3)
+    plan = InferencePlan(sd, batch_size=B, num_class=3, anchors=an, anchors_bv=bv, device=dev, cap_k=4096, cap_d=1024,
+                         rpn_thr=rpn_thr, score_thr=score_thr)
     plan.run_from_points([torch.from_numpy(p).to(dev) for p in clouds])
     res = plan.results()
+    assert int(plan.status.item()) == 0
     assert np.array_equal(plan.mask.cpu().numpy().astype(bool), ref["masks"])
-    cnt = plan.df["counts"].cpu().numpy()
-    got_any = False
-    for b in range(2):
-        gb, gl, gs = ref["guided"][b]
-        if (np.abs(gs.numpy() - 0.1) < 1e-5).any():
-            continue
-        assert cnt[b] == len(gb)
-        k = cnt[b]
-        assert _close(plan.df["guided"][b, :k].cpu().numpy(), gb.numpy())
-        assert np.array_equal(plan.df["labels"][b, :k].cpu().numpy(), gl.numpy())
-        d = ref["dets"][b]
-        if d is None:
-            assert res[b][0] is None
-            continue
-        if (np.abs(torch.sigmoid(ref["logits"][b]).numpy() - 0.3) < 1e-5).any():
-            continue
-        _match_sets(res[b][0], res[b][1], d[0], d[1])
-        assert np.array_equal(res[b][2], d[2])
-        got_any = True
-    assert got_any
+    n3 = int(plan.n[3].item())
+    assert n3 == len(ref["idx3"]) and np.array_equal(plan.idx[3][:n3].cpu().numpy(), ref["idx3"])
+    errs = {}
+    ndet = sum(_check_sample("multi", plan, res, ref, b, errs) for b in range(B))
+    print("max abs errors vs the CPU oracle (multi_cfg, batch %d): %s" % (B, {k: (["%.1e" % x for x in v] if isinstance(v, np.ndarray) else "%.2e" % v) for k, v in errs.items()}))
+    assert ndet >= 1
 
 
 WAYMO = dict(voxel_size=synth.WAYMO_VOXEL, pc_range=synth.WAYMO_RANGE, max_points=5, max_voxels=150000,
              sparse_shape=(40, 1504, 1504), grid_xyz=(1504, 1504, 40))
 
 
-def test_waymo_scale_frame(dev):
+@pytest.mark.parametrize("batch", [1, 4])
+def test_waymo_scale_frame(dev, batch):
     """configs[4] shape on one GPU, inference side: 180k points, 0.1 x 0.1 x 0.15 m voxels (grid 40x1504x1504,
-    ~79k active voxels, BEV 188x188).  Stresses the hash tables / bitmaps at 5x the KITTI row counts."""
+    ~79k active voxels per frame, BEV 188x188), batch 1 and the stated batch 4.  Stresses the hash / bitmap-rank tables
+    at 5-20x the KITTI row counts."""
     c = Config.fromfile("configs/car_cfg.py")
     mcfg = dict(c.model)
     mcfg["neck"] = dict(mcfg["neck"], output_shape=[40, 1504, 1504])
     mcfg["extra_head"] = dict(mcfg["extra_head"], grid_offsets=(75.2, 75.2), featmap_stride=0.8)
-    model = H.randomize_detector(build_detector(mcfg, c.train_cfg, c.test_cfg).eval(), 7)
+    model = H.randomize_detector(build_detector(mcfg, c.train_cfg, c.test_cfg).eval(), 7, sparse_fan_div=1)
     an = A.AnchorGeneratorStride(sizes=[1.6, 3.9, 1.56], anchor_strides=[.8, .8, 1.], anchor_offsets=[-74.8, -74.8, -1.0],
                                  rotations=[0, 1.57])([1, 188, 188]).reshape(-1, 7)
     bv = A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]]).astype(np.float32)
-    pts = synth.waymo_synth(0)[:180000]
-    H.calibrate_cls_head(model, pts, bv, WAYMO, target_count=600)
+    clouds = [synth.waymo_synth(s)[:180000] for s in range(batch)]
+    H.calibrate_cls_head(model, clouds[0], bv, WAYMO, target_count=600)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    ref = H.oracle_forward(sd, [pts], an, bv, dict(WAYMO, score_thr=0.3))
-    plan = InferencePlan(sd, batch_size=1, anchors=an, anchors_bv=bv, device=dev, voxel_size=WAYMO["voxel_size"],
+    wcfg = dict(WAYMO, grid_offsets=(75.2, 75.2), featmap_stride=0.8)
+    ref, rpn_thr, score_thr = H.oracle_forward_safe(sd, clouds, an, bv, wcfg)
+    plan = InferencePlan(sd, batch_size=batch, anchors=an, anchors_bv=bv, device=dev, voxel_size=WAYMO["voxel_size"],
                          point_cloud_range=WAYMO["pc_range"], max_voxels=150000, sparse_shape=WAYMO["sparse_shape"],
-                         grid_offsets=(75.2, 75.2), featmap_stride=0.8, cap_k=4096, cap_d=2048)
-    plan.run_from_points([torch.from_numpy(pts).to(dev)])
+                         grid_offsets=(75.2, 75.2), featmap_stride=0.8, cap_k=4096, cap_d=2048, rpn_thr=rpn_thr,
+                         score_thr=score_thr)
+    plan.run_from_points([torch.from_numpy(p).to(dev) for p in clouds])
     torch.cuda.synchronize()
     assert int(plan.status.item()) == 0
     n0, n3 = int(plan.n[0].item()), int(plan.n[3].item())
-    assert n0 == 79302 == len(ref["coors"])
+    assert n0 == len(ref["coors"]) and (batch > 1 or n0 == 79302)
     assert np.array_equal(plan.idx[0][:n0].cpu().numpy(), ref["coors"])
     assert np.array_equal(plan.mean[:n0].cpu().numpy(), ref["feats"])
     assert n3 == len(ref["idx3"]) and np.array_equal(plan.idx[3][:n3].cpu().numpy(), ref["idx3"])
     e = (plan.sp_out[:n3].cpu() - ref["x3"]).abs().max().item()
     assert e < 1e-4 * max(1.0, ref["x3"].abs().max().item()), e
+    errs = {"sparse_features": e}
     e = (plan.x.cpu() - ref["x"]).abs().max().item()
+    errs["bev_x"] = e
     assert e < 2e-4 * max(1.0, ref["x"].abs().max().item()), e
     assert np.array_equal(plan.mask.cpu().numpy().astype(bool), ref["masks"])
-    gb, gl, gs = ref["guided"][0]
-    if not (np.abs(gs.numpy() - 0.1) < 1e-5).any():
-        k = int(plan.df["counts"][0].item())
-        assert k == len(gb)
-        assert _close(plan.df["guided"][0, :k].cpu().numpy(), gb.numpy())
+    res = plan.results()
+    ndet = sum(_check_sample("waymo", plan, res, ref, b, errs, unbounded=True) for b in range(batch))
+    print("max abs errors vs the CPU oracle (waymo-scale, batch %d): %s" % (batch, {k: (["%.1e" % x for x in v] if isinstance(v, np.ndarray) else "%.2e" % v) for k, v in errs.items()}))
+    assert ndet >= 1

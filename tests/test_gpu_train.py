@@ -80,22 +80,24 @@ def test_pswarp_backward_vs_grid_sample(dev):
 
 
 HALF = dict(voxel_size=synth.KITTI_VOXEL, pc_range=[0, -40., -3., 35.2, 40., 1.], max_points=5, max_voxels=20000,
-            sparse_shape=(40, 1600, 704), grid_xyz=(704, 1600, 40))
+            sparse_shape=(40, 1600, 704), grid_xyz=(704, 1600, 40), bev_w=88, xmax=32.0)
+FULL = dict(voxel_size=synth.KITTI_VOXEL, pc_range=list(synth.KITTI_RANGE), max_points=5, max_voxels=20000,
+            sparse_shape=(40, 1600, 1408), grid_xyz=(1408, 1600, 40), bev_w=176, xmax=66.0)      # configs[2]'s own grid
 
 
 SIZES = dict(Car=[1.6, 3.9, 1.56], Pedestrian=[0.6, 0.8, 1.73], Cyclist=[0.6, 1.76, 1.73])
 
 
-def _half_anchors(name="Car"):
+def _half_anchors(name="Car", bev_w=88):
     an = A.AnchorGeneratorStride(sizes=SIZES[name], anchor_strides=[.4, .4, 1.], anchor_offsets=[.2, -39.8, -1.78],
-                                 rotations=[0, 1.57])([1, 200, 88]).reshape(-1, 7)
+                                 rotations=[0, 1.57])([1, 200, bev_w]).reshape(-1, 7)
     return an, A.rbbox2d_to_near_bbox(an[:, [0, 1, 3, 4, 6]]).astype(np.float32)
 
 
-def _gt(seed, n, types=None):
+def _gt(seed, n, types=None, xmax=32.0):
     r = np.random.default_rng(seed)
     b = np.zeros((n, 7), np.float32)
-    b[:, 0] = r.uniform(4, 32, n); b[:, 1] = r.uniform(-30, 30, n); b[:, 2] = r.uniform(-1.9, -1.5, n)
+    b[:, 0] = r.uniform(4, xmax, n); b[:, 1] = r.uniform(-30, 30, n); b[:, 2] = r.uniform(-1.9, -1.5, n)
     b[:, 3] = r.uniform(1.5, 1.8, n); b[:, 4] = r.uniform(3.5, 4.4, n); b[:, 5] = r.uniform(1.4, 1.7, n)
     b[:, 6] = r.uniform(-3.1, 3.1, n)
     if types is not None:                            # class-sized boxes
@@ -105,12 +107,13 @@ def _gt(seed, n, types=None):
     return b
 
 
-@pytest.mark.parametrize("cfgfile,names", [("configs/car_cfg.py", ["Car"]),
-                                           ("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"])])
-def test_training_step_vs_oracle(dev, cfgfile, names):
+@pytest.mark.parametrize("cfgfile,names,HALF", [("configs/car_cfg.py", ["Car"], FULL),
+                                                ("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"], HALF)])
+def test_training_step_vs_oracle(dev, cfgfile, names, HALF):
     """forward_train on the GPU (HIP kernels under autograd) vs oracle/train_ref.train_step on the CPU: the six loss
-    terms and the gradient of their sum with respect to every parameter; car_cfg and the three-class multi_cfg
-    (per-class anchors / masks / thresholds, 18 + 42 + 12 head channels)."""
+    terms and the gradient of their sum with respect to every parameter.  car_cfg on its own full 1408-wide grid
+    (BASELINE configs[2]); the three-class multi_cfg (per-class anchors / masks / thresholds, 18 + 42 + 12 head
+    channels) on a half-width grid to bound the CPU autograd time of the oracle."""
     from oracle import clib, nets as onets, train_ref
     c = Config.fromfile(cfgfile)
     mcfg = dict(c.model)
@@ -118,15 +121,15 @@ def test_training_step_vs_oracle(dev, cfgfile, names):
     model = H.randomize_detector(build_detector(mcfg, c.train_cfg, c.test_cfg), seed=7, cls_bias=-3.0)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev).train()
-    anbv = {n: _half_anchors(n) for n in names}
+    anbv = {n: _half_anchors(n, HALF["bev_w"]) for n in names}
     clouds = [H.frame("small", 31), H.frame("k17", 32)[::3]]
-    clouds = [p[p[:, 0] < 35.2] for p in clouds]
+    clouds = [p[p[:, 0] < HALF["pc_range"][3]] for p in clouds]
     if len(names) == 1:
         types = [np.array(["Car"] * 5), np.array(["Car"] * 6 + ["Van"])]
     else:
         types = [np.array(["Car", "Pedestrian", "Cyclist", "Car", "Pedestrian"]),
                  np.array(["Cyclist", "Car", "Car", "Pedestrian", "Cyclist", "Van", "Car"])]
-    gts = [_gt(1, len(types[0]), types[0]), _gt(2, len(types[1]), types[1])]
+    gts = [_gt(1, len(types[0]), types[0], HALF["xmax"]), _gt(2, len(types[1]), types[1], HALF["xmax"])]
     kw = dict(voxels=[], coordinates=[], num_points=[], anchors={n: [] for n in names},
               anchors_mask={n: [] for n in names}, gt_bboxes=[], gt_labels=[], gt_types=types)
     feats, coors, masks = [], [], {n: [] for n in names}
@@ -386,3 +389,34 @@ def test_disk_to_ap_end_to_end(dev, tmp_path):
         kc.write_label_annos(found, root + '/results')
         back = kc.get_label_annos(root + '/results', [int(a['image_idx'][0]) for a in found])
         assert [len(b['name']) for b in back] == [len(a['name']) for a in found]
+
+
+def test_weight_packs_follow_the_fused_optimizer(dev):
+    """The fused optimizer writes the flat parameter buffer through a raw pointer (no autograd version bump): every cached
+    weight pack -- sparse conv, BEV conv (direct / Winograd), the folded inference plan -- must be rebuilt after a step."""
+    from sassd import train, kernels as K, spconv
+    from sassd.detector import _HipConv2d
+    c = Config.fromfile("configs/car_cfg.py")
+    model = H.randomize_detector(build_detector(c.model, c.train_cfg, c.test_cfg), seed=3).to(dev)
+    opt = train.build_optimizer(model, c.optimizer, 1)
+    sp = [m for m in model.modules() if isinstance(m, spconv.SparseConvolution)][3]
+    cv = [m for m in model.modules() if isinstance(m, _HipConv2d) and m.kernel_size[0] == 3][1]
+    p0, q0, w0 = sp.packed_weight().clone(), cv.packed_weight().clone(), cv.packed_wino(200, 176).clone()
+    an = A.AnchorGeneratorStride(sizes=SIZES["Car"], anchor_strides=[.4, .4, 1.], anchor_offsets=[.2, -39.8, -1.78],
+                                 rotations=[0, 1.57])([1, 200, 176]).reshape(-1, 7)
+    plan0 = model.plan(1, torch.from_numpy(an).to(dev), dev)
+    assert model.plan(1, torch.from_numpy(an).to(dev).clone(), dev) is plan0          # same weights + same anchor content
+    opt.flat.grad.fill_(1e-2)
+    opt.lr = 1e-2
+    opt.step()
+    torch.cuda.synchronize()
+    k = int(np.prod(sp.kernel_size))
+    fresh = K.spconv_pack_weight(sp.weight.detach().reshape(k, sp.in_channels, sp.out_channels).contiguous())
+    assert torch.equal(sp.packed_weight(), fresh) and not torch.equal(fresh, p0)
+    assert torch.equal(cv.packed_weight(), K.conv2d_pack_weight(cv.weight.detach().contiguous())) and not torch.equal(cv.packed_weight(), q0)
+    assert torch.equal(cv.packed_wino(200, 176), K.conv2d_wino_pack_weight(cv.weight.detach().contiguous()))
+    assert not torch.equal(cv.packed_wino(200, 176), w0)
+    model.eval()
+    plan1 = model.plan(1, torch.from_numpy(an).to(dev), dev)
+    assert plan1 is not plan0
+    assert torch.equal(plan1.sp[3][4], K.spconv_pack_weight(sp.weight.detach().reshape(k, sp.in_channels, sp.out_channels).contiguous()))

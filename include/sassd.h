@@ -35,7 +35,7 @@ extern "C" {
 #define SASSD_ST_HASH_FULL        2   /* hash table probe exhausted             */
 #define SASSD_ST_BOX_OVERFLOW     4   /* more candidate boxes than capK / capD  */
 
-#define SASSD_MAX_POINTS_PER_VOXEL 8   /* max_points supported by sassd_voxelize */
+#define SASSD_MAX_POINTS_PER_VOXEL 64  /* max_points supported by sassd_voxelize (reference default: 35) */
 
 const char *sassd_version(void);
 int sassd_last_hip_error(void);
@@ -291,6 +291,10 @@ int sassd_boxes_iou_bev(const float *boxes_a, int num_a, const float *boxes_b, i
 size_t sassd_nms_workspace_bytes(int n);
 int sassd_nms_gpu(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep,
                   void *workspace, size_t workspace_bytes, void *stream);
+/* iou3d_cuda.nms_normal_gpu (iou3d.cpp:123-172, iou3d_kernel.cu:295-348): the same greedy suppression over the
+ * axis-aligned IoU of the (x1,y1,x2,y2) rectangles, rotation ignored.  Same arguments / workspace as sassd_nms_gpu. */
+int sassd_nms_normal_gpu(const float *boxes_sorted, int n, float thresh, int64_t *keep, int32_t *num_keep,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (a16, a17) training-side point operators of the auxiliary network.

@@ -78,6 +78,7 @@ _SIGS = {
     "sassd_boxes_iou_bev": (_I, [_P, _I, _P, _I, _P, _P]),
     "sassd_nms_workspace_bytes": (_SZ, [_I]),
     "sassd_nms_gpu": (_I, [_P, _I, _F, _P, _P, _P, _SZ, _P]),
+    "sassd_nms_normal_gpu": (_I, [_P, _I, _F, _P, _P, _P, _SZ, _P]),
     "sassd_three_nn": (_I, [_I, _I, _P, _P, _P, _P, _P]),
     "sassd_three_interpolate": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "sassd_three_interpolate_grad": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),

@@ -341,15 +341,33 @@ __device__ __forceinline__ int nms_greedy_chunked(const unsigned long long *__re
     return nk;
 }
 
+// axis-aligned IoU of (x1,y1,x2,y2,ry) boxes, the rotation ignored (iou3d_kernel.cu:295-303 `iou_normal`)
+__device__ __forceinline__ unsigned long long nms_word_normal(const float *__restrict__ boxes, int n, int row, int cb,
+                                                              float thr, int lane)
+{
+    const int col = cb * 64 + lane;
+    bool hit = false;
+    if (col < n && col > row) {
+        const float *a = boxes + (size_t)row * 5, *b = boxes + (size_t)col * 5;
+        const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+        const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+        const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+        const float inter = width * height;
+        const float sa = (a[2] - a[0]) * (a[3] - a[1]), sb = (b[2] - b[0]) * (b[3] - b[1]);
+        hit = inter / fmaxf(sa + sb - inter, iou3d::kEps) > thr;
+    }
+    return __ballot(hit);
+}
+
 __global__ void __launch_bounds__(256) nms_mask_kernel(const float *__restrict__ boxes, int n, int ncb, float thr,
-                                                       unsigned long long *__restrict__ mask)
+                                                       unsigned long long *__restrict__ mask, int normal)
 {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n * ncb) return;
     const int row = item / ncb, cb = item - row * ncb;
     unsigned long long w = 0ull;
-    if (cb >= (row >> 6)) w = nms_word(boxes, n, row, cb, thr, lane);
+    if (cb >= (row >> 6)) w = normal ? nms_word_normal(boxes, n, row, cb, thr, lane) : nms_word(boxes, n, row, cb, thr, lane);
     if (lane == 0) mask[item] = w;
 }
 
@@ -652,8 +670,8 @@ extern "C" size_t sassd_nms_workspace_bytes(int n)
     return align_up((size_t)(n > 0 ? n : 1) * (ncb ? ncb : 1) * 8, 256);
 }
 
-extern "C" int sassd_nms_gpu(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep,
-                             void *workspace, size_t workspace_bytes, void *stream_)
+static int nms_impl(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep, void *workspace,
+                    size_t workspace_bytes, void *stream_, int normal)
 {
     if (!keep || !num_keep || n < 0 || n > 16384) return SASSD_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
@@ -662,8 +680,20 @@ extern "C" int sassd_nms_gpu(const float *boxes, int n, float thresh, int64_t *k
     if (workspace_bytes < sassd_nms_workspace_bytes(n)) return SASSD_ENOSPC;
     const int ncb = (n + 63) / 64;
     unsigned long long *mask = (unsigned long long *)workspace;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cdiv(n * ncb, 4)), dim3(256), 0, stream, boxes, n, ncb, thresh, mask);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cdiv(n * ncb, 4)), dim3(256), 0, stream, boxes, n, ncb, thresh, mask, normal);
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(1), dim3(64), 0, stream, (const unsigned long long *)mask, n, ncb, keep,
                        num_keep);
     return sassd_launch_status();
+}
+
+extern "C" int sassd_nms_gpu(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    return nms_impl(boxes, n, thresh, keep, num_keep, workspace, workspace_bytes, stream, 0);
+}
+
+extern "C" int sassd_nms_normal_gpu(const float *boxes, int n, float thresh, int64_t *keep, int32_t *num_keep,
+                                    void *workspace, size_t workspace_bytes, void *stream)
+{
+    return nms_impl(boxes, n, thresh, keep, num_keep, workspace, workspace_bytes, stream, 1);
 }

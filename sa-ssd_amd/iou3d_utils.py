@@ -45,6 +45,13 @@ def nms_gpu(boxes, scores, thresh):
     return order[keep[:int(num.item())]].contiguous()
 
 
+def nms_normal_gpu(boxes, scores, thresh):
+    """(N,5) bev boxes, (N) scores -> kept indices by descending score, axis-aligned IoU (reference :130-144)."""
+    order = scores.sort(0, descending=True, stable=True)[1]
+    keep, num = K.nms_gpu(boxes[order].contiguous(), thresh, normal=True)
+    return order[keep[:int(num.item())]].contiguous()
+
+
 def rotate_nms_torch(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5):
     """bbox_nms.py:4-26."""
     indices = None

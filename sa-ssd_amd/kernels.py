@@ -582,8 +582,9 @@ def boxes_iou_bev(a, b, out=None):
     return out
 
 
-def nms_gpu(boxes_sorted, thresh):
-    """boxes [N,5] sorted by descending score -> (keep int64 device [N], num_keep int32 device [1])."""
+def nms_gpu(boxes_sorted, thresh, normal=False):
+    """boxes [N,5] sorted by descending score -> (keep int64 device [N], num_keep int32 device [1]).  normal=True:
+    axis-aligned IoU (iou3d_cuda.nms_normal_gpu) instead of the rotated BEV IoU."""
     _chk_cuda(boxes_sorted)
     n = boxes_sorted.shape[0]
     dev = boxes_sorted.device
@@ -592,9 +593,9 @@ def nms_gpu(boxes_sorted, thresh):
     L = _C.lib()
     wsb = L.sassd_nms_workspace_bytes(n)
     ws = workspace("nms", wsb, dev)
-    rc = L.sassd_nms_gpu(_C.ptr(boxes_sorted), n, float(thresh), _C.ptr(keep), _C.ptr(num), _C.ptr(ws), wsb,
-                         _C.stream())
-    _C.check(rc, "sassd_nms_gpu")
+    fn = L.sassd_nms_normal_gpu if normal else L.sassd_nms_gpu
+    rc = fn(_C.ptr(boxes_sorted), n, float(thresh), _C.ptr(keep), _C.ptr(num), _C.ptr(ws), wsb, _C.stream())
+    _C.check(rc, "sassd_nms_normal_gpu" if normal else "sassd_nms_gpu")
     return keep, num
 
 

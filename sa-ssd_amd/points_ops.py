@@ -20,16 +20,16 @@ def points_to_voxel_device(points, voxel_size, coors_range, max_points=35, rever
                            **kw):
     """points: torch CUDA [N, ndim] f32.  Returns the dict of kernels.voxelize (capacity-sized device tensors and
     a device int32 `voxel_num`)."""
-    if not reverse_index:
-        raise NotImplementedError("only the zyx kernel used by the configs (reverse_index=True) is provided")
-    if max_points > 8:
-        raise NotImplementedError("max_points > 8 is not supported by the HIP voxelizer (car/multi cfg use 5)")
-    return K.voxelize(points, voxel_size, coors_range, max_points, max_voxels, **kw)
+    r = K.voxelize(points, voxel_size, coors_range, max_points, max_voxels, **kw)
+    if not reverse_index:                      # points_ops.py:53-101: the same voxels, coordinates in (x, y, z) order
+        c = r["coors"]
+        r["coors"] = torch.cat([c[:, :-3], c[:, -3:].flip(1)], 1).contiguous()
+    return r
 
 
 def points_to_voxel(points, voxel_size, coors_range, max_points=35, reverse_index=True, max_voxels=20000):
-    """Reference signature (points_ops.py:104): numpy [N, >=3] -> (voxels [M,T,ndim], coors [M,3] zyx int32,
-    num_points_per_voxel [M] int32)."""
+    """Reference signature (points_ops.py:104): numpy [N, >=3] -> (voxels [M,T,ndim], coors [M,3] int32 -- zyx, or
+    xyz with reverse_index=False --, num_points_per_voxel [M] int32).  max_points up to 64 (reference default 35)."""
     pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(_device())
     r = points_to_voxel_device(pts, voxel_size, coors_range, max_points, reverse_index, max_voxels,
                                want_mean=False)

@@ -139,17 +139,67 @@ def build_warmup_scheduler(optimizer, optim_cfg, lr_cfg):
 
 
 class GradSync:
-    """Data-parallel exchange over the flat buffers (RCCL over xGMI with backend 'nccl', gloo in CPU tests)."""
+    """Data-parallel exchange over the flat buffers (RCCL over xGMI with backend 'nccl', gloo in CPU tests).
 
-    def __init__(self, flat):
+    Parameters are broadcast once from rank 0.  Gradients: the flat gradient buffer is cut into `buckets` contiguous
+    ranges on parameter boundaries; a post-accumulate hook on every parameter counts its bucket down and launches the
+    bucket's asynchronous all-reduce as soon as the last of its gradients has been written, so the exchange of the
+    layers whose backward ran first (the heads, the BEV stack) overlaps the backward of the sparse backbone.
+    `all_reduce_grads()` launches whatever is still pending (parameters that received no gradient) and waits.  With
+    one bucket, or `overlap=False`, it is the single whole-model all-reduce of SURVEY 8e.  The sum is left in the
+    buffer; the 1/world mean is folded into the update kernel."""
+
+    def __init__(self, flat, buckets=4, overlap=True):
         self.flat = flat
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if self.on:
-            dist.broadcast(flat.data, src=0)
+        self.ranges, self.works, self._hooks = [], [], []
+        if not self.on:
+            return
+        dist.broadcast(flat.data, src=0)
+        n = len(flat.params)
+        buckets = max(1, min(int(buckets), n))
+        target = flat.numel / buckets
+        # contiguous parameter runs of ~equal size: [(first param, last param + 1, lo float, hi float)]
+        start = 0
+        for i in range(n):
+            end_f = flat.offsets[i + 1] if i + 1 < n else flat.numel
+            if end_f - flat.offsets[start] >= target or i == n - 1:
+                self.ranges.append((start, i + 1, flat.offsets[start], end_f))
+                start = i + 1
+        self.overlap = bool(overlap) and len(self.ranges) > 1
+        self._left = [hi - lo for lo, hi, _, _ in self.ranges]
+        self._launched = [False] * len(self.ranges)
+        if self.overlap:
+            owner = {}
+            for b, (lo, hi, _, _) in enumerate(self.ranges):
+                for i in range(lo, hi):
+                    owner[i] = b
+            for i, p in enumerate(flat.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(owner[i])))
+
+    def _make_hook(self, b):
+        def hook(_param):
+            self._left[b] -= 1
+            if self._left[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if not self._launched[b]:
+            _, _, lo, hi = self.ranges[b]
+            self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self._launched[b] = True
 
     def all_reduce_grads(self):
-        if self.on:
-            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+        if not self.on:
+            return
+        for b in range(len(self.ranges)):
+            self._launch(b)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self._left = [hi - lo for lo, hi, _, _ in self.ranges]
+        self._launched = [False] * len(self.ranges)
 
 
 def parse_losses(losses):

@@ -1,0 +1,45 @@
+"""One rank of the multi-GPU RCCL check (launched by tests/test_gpu_multi.py through torch.distributed.run): the
+training path's parameter broadcast + bucketed, overlapped gradient all-reduce over the flat buffers on real GPUs, and
+one fused optimizer step that must leave every rank with identical weights."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sassd  # noqa: E402,F401
+from sassd import dist as D, train  # noqa: E402
+
+
+def main():
+    rank, local_rank, world = D.init("nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    torch.manual_seed(100 + rank)
+    m = torch.nn.Sequential(torch.nn.Linear(64, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                            torch.nn.Linear(512, 8)).to(dev)
+    opt = train.AdamOneCycle(m, lr=1e-3, weight_decay=0.01, grad_clip=dict(max_norm=10, norm_type=2), world_size=world)
+    sync = train.GradSync(opt.flat, buckets=3)
+    ref = opt.flat.data.clone()
+    torch.distributed.broadcast(ref, src=0)
+    assert torch.equal(ref, opt.flat.data), "parameter broadcast"
+    x = torch.randn(32, 64, device=dev) * (rank + 1)
+    opt.zero_grad()
+    m(x).pow(2).mean().backward()
+    local = opt.flat.grad.clone()
+    sync.all_reduce_grads()
+    total = local.clone()
+    torch.distributed.all_reduce(total)
+    assert torch.allclose(opt.flat.grad, total, rtol=1e-5, atol=1e-6), "bucketed all-reduce != one all-reduce"
+    opt.step()
+    w = opt.flat.data.clone()
+    torch.distributed.broadcast(w, src=0)
+    assert torch.equal(w, opt.flat.data), "weights diverged across ranks after the update"
+    D.barrier()
+    if rank == 0:
+        print("RCCL_OK world=%d" % world)
+
+
+if __name__ == "__main__":
+    main()

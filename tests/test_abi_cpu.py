@@ -47,3 +47,16 @@ def test_host_side_queries():
     assert L.sassd_three_nn_binned_workspace_bytes(1000, 4096, 4096, 2) == 0          # grid too large
     assert L.sassd_spconv_bwd_weight_workspace_bytes(16111, 27, 64, 64) >= 126 * 27 * 64 * 64 * 4
     assert L.sassd_hash_bytes(20000) >= 2 * 20000 * 8
+
+
+def test_bench_refuses_a_mismatched_launch():
+    """bench.py --gpus N under a launcher that started a different WORLD_SIZE must fail loudly (not run N' ranks and
+    report N); with WORLD_SIZE unset and N > 1 it re-executes itself under torch.distributed.run (tests/test_gpu_multi.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in (out.stderr + out.stdout)

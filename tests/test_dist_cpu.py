@@ -80,14 +80,31 @@ def _grad_sync_worker(rank, world, port, q):
     torch.manual_seed(100 + rank)                                  # different initial weights per rank
     m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3, bias=False))
     flat = train.FlatParams(m)
-    sync = train.GradSync(flat)                                    # broadcast from rank 0
+    sync = train.GradSync(flat, buckets=3)                         # broadcast from rank 0; bucketed, overlapped exchange
+    assert len(sync.ranges) >= 2 and sync.overlap
+    assert sync.ranges[0][2] == 0 and sync.ranges[-1][3] == flat.numel
+    assert all(a[3] == b[2] for a, b in zip(sync.ranges, sync.ranges[1:]))       # the ranges tile the flat buffer
     w0 = flat.data.clone()
-    flat.zero_grad()
     x = torch.full((4, 6), float(rank + 1)) + torch.arange(24.).view(4, 6) * 0.01
+    reds = []
+    for it in range(2):                                            # second iteration: the hook bookkeeping was reset
+        flat.zero_grad()
+        # no hooks during the reference backward: local gradient first, on a copy of the graph
+        m(x).pow(2).sum().backward()
+        for w in sync.works:                                       # buckets went out DURING backward
+            w.wait()
+        launched = list(sync._launched)
+        sync.all_reduce_grads()
+        reds.append(flat.grad.clone())
+    assert any(launched), "no bucket was launched from a gradient hook"
+    assert torch.equal(reds[0], reds[1])
+    # local gradient for the cross-rank check (hooks removed: nothing is exchanged)
+    flat.zero_grad()
+    for h in sync._hooks:
+        h.remove()
     m(x).pow(2).sum().backward()
     local = flat.grad.clone()
-    sync.all_reduce_grads()
-    q.put((rank, w0.numpy(), local.numpy(), flat.grad.clone().numpy()))
+    q.put((rank, w0.numpy(), local.numpy(), reds[0].numpy()))
     D.barrier()
 
 

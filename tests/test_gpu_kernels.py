@@ -309,3 +309,45 @@ def test_rotate_iou_eval(dev):
     ref = clib.rotate_iou_eval(big.astype(np.float32), big[:300].astype(np.float32), -1)
     assert np.abs(out - ref).max() < 1e-6 and (out >= 0).all()
     assert eval_ops.rotate_iou_gpu_eval(big[:0], big, 0).shape == (0, 700)
+
+
+def test_voxelizer_reference_defaults(dev):
+    """points_to_voxel with the reference's own defaults: max_points=35 (points_ops.py:104-109) and the xyz-order variant
+    reverse_index=False (:53-101), bit-exact against the C oracle on a cloud dense enough to fill 35-point voxels."""
+    from sassd import points_ops
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([H.frame("small", 7), rng.uniform([10, -2, -1.5, 0], [11, 2, -1.0, 1], (6000, 4)).astype(np.float32)])
+    vs, cr = [0.2, 0.2, 0.4], list(synth.KITTI_RANGE)
+    for rev in (True, False):
+        v, c, n = points_ops.points_to_voxel(pts, vs, cr, max_points=35, reverse_index=rev, max_voxels=20000)
+        rv, rc, rn = clib.points_to_voxel(pts, vs, cr, 35, True, 20000)
+        assert n.max() == 35 and len(v) == len(rv)
+        assert np.array_equal(v, rv) and np.array_equal(n, rn)
+        assert np.array_equal(c, rc if rev else rc[:, ::-1])
+
+
+def test_nms_normal_gpu(dev):
+    """iou3d_utils.nms_normal_gpu (axis-aligned IoU, rotation ignored: iou3d_kernel.cu:295-348, iou3d.cpp:123-172)
+    against a plain numpy greedy loop in fp32."""
+    from sassd import iou3d_utils
+    rng = np.random.default_rng(3)
+    for n in (1, 64, 65, 300):
+        b = H.rand_bev_boxes(rng, n, spread=20.0)
+        sc = rng.random(n).astype(np.float32)
+        order = np.argsort(-sc, kind="stable")
+        bs = b[order]
+        keep, alive = [], np.ones(n, bool)
+        for i in range(n):
+            if not alive[i]:
+                continue
+            keep.append(i)
+            a = bs[i]
+            w = np.maximum(np.minimum(a[2], bs[:, 2]) - np.maximum(a[0], bs[:, 0]), np.float32(0))
+            h = np.maximum(np.minimum(a[3], bs[:, 3]) - np.maximum(a[1], bs[:, 1]), np.float32(0))
+            inter = (w * h).astype(np.float32)
+            sa = np.float32((a[2] - a[0]) * (a[3] - a[1]))
+            sb = ((bs[:, 2] - bs[:, 0]) * (bs[:, 3] - bs[:, 1])).astype(np.float32)
+            iou = inter / np.maximum(sa + sb - inter, np.float32(1e-8))
+            alive &= ~((iou > np.float32(0.3)) & (np.arange(n) > i))
+        got = iou3d_utils.nms_normal_gpu(torch.from_numpy(b).to(dev), torch.from_numpy(sc).to(dev), 0.3).cpu().numpy()
+        assert np.array_equal(got, order[np.asarray(keep)]), n

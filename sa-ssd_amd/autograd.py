@@ -53,12 +53,41 @@ class SparseConvFn(Function):
         return dx, dw, None, None, None
 
 
-def _conv_any(x, weight, ks, packed=None, wino=None, shift=None):
-    """3x3 layers take the Winograd F(2x2,3x3) kernel when the shape allows, everything else the direct kernel."""
+def _conv_any(x, weight, ks, packed=None, wino=None, shift=None, wino4=None):
+    """3x3 layers take Winograd F(4x4,3x3) (transforms + 36 MFMA GEMMs) when the shape allows, else the fused F(2x2,3x3)
+    kernel, everything else the direct kernel.  Pre-packed weights may be handed in (`wino4` / `wino` / `packed`)."""
     cout, cin = weight.shape[0], weight.shape[1]
-    if ks == 3 and K.conv2d_wino_supported(cin, cout, x.shape[2], x.shape[3]):
+    h, w = x.shape[2], x.shape[3]
+    if ks == 3 and K.conv2d_wino4_supported(cin, cout, h, w):
+        return K.conv2d_wino4_fwd(x, wino4 if wino4 is not None else K.conv2d_wino4_pack_weight(weight), cout, None, shift)
+    if ks == 3 and K.conv2d_wino_supported(cin, cout, h, w):
         return K.conv2d_wino_fwd(x, wino if wino is not None else K.conv2d_wino_pack_weight(weight), cout, None, shift)
     return K.conv2d_fwd(x, packed if packed is not None else K.conv2d_pack_weight(weight), cout, ks, None, shift)
+
+
+_dgrad_packs = {}
+
+
+def _dgrad_pack(weight, h, w):
+    """Packed image of the data-gradient conv's weights (transposed, taps mirrored), cached per parameter storage and
+    weight generation: the pack is a pure function of the weights, which change once per optimizer step."""
+    ks = weight.shape[2]
+    key = (weight.data_ptr(), tuple(weight.shape), h, w)
+    gen = K.weight_key(weight)
+    hit = _dgrad_packs.get(key)
+    if hit is not None and hit[0] == gen:
+        return hit[1]
+    wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # [Cin, Cout, k, k]
+    cin_g, cout_g = wt.shape[1], wt.shape[0]
+    if ks == 3 and K.conv2d_wino4_supported(cin_g, cout_g, h, w):
+        pack = dict(wino4=K.conv2d_wino4_pack_weight(wt))
+    elif ks == 3 and K.conv2d_wino_supported(cin_g, cout_g, h, w):
+        pack = dict(wino=K.conv2d_wino_pack_weight(wt))
+    else:
+        pack = dict(packed=K.conv2d_pack_weight(wt))
+    pack["wt"] = wt
+    _dgrad_packs[key] = (gen, pack)
+    return pack
 
 
 class Conv2dFn(Function):
@@ -66,10 +95,11 @@ class Conv2dFn(Function):
     with flipped, transposed weights; weight gradient = the split-K MFMA kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed, wino):
+    def forward(ctx, x, weight, bias, packed, wino, wino4=None):
         x = x.contiguous()
         ks = weight.shape[2]
-        y = _conv_any(x, weight.detach(), ks, packed, wino, bias.detach().contiguous() if bias is not None else None)
+        y = _conv_any(x, weight.detach(), ks, packed, wino, bias.detach().contiguous() if bias is not None else None,
+                      wino4)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -81,13 +111,13 @@ class Conv2dFn(Function):
         ks = weight.shape[2]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # [Cin, Cout, k, k], taps mirrored
-            dx = _conv_any(dy, wt, ks)
+            pk = _dgrad_pack(weight, dy.shape[2], dy.shape[3])                      # [Cin, Cout, k, k], taps mirrored
+            dx = _conv_any(dy, pk["wt"], ks, pk.get("packed"), pk.get("wino"), None, pk.get("wino4"))
         if ctx.needs_input_grad[1]:
             dw = K.conv2d_bwd_weight(x, dy, ks)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class DensifyFn(Function):

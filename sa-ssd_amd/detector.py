@@ -149,9 +149,21 @@ class _HipConv2d(nn.Conv2d):
             self._pkw, self._pkwv = K.conv2d_wino_pack_weight(self.weight.detach().float().contiguous()), v
         return self._pkw
 
+    def packed_wino4(self, h, w):
+        """Winograd F(4x4,3x3) weights (G g G^T, [36][Cin][Cout]) when the layer / feature-map shape supports it."""
+        if self.kernel_size[0] != 3 or not K.conv2d_wino4_supported(self.in_channels, self.out_channels, h, w):
+            return None
+        v = K.weight_key(self.weight)
+        if getattr(self, "_pk4", None) is None or self._pk4v != v:
+            self._pk4, self._pk4v = K.conv2d_wino4_pack_weight(self.weight.detach().float().contiguous()), v
+        return self._pk4
+
     def hip_forward(self, x, scale=None, shift=None, relu=False):
         if shift is None and self.bias is not None:
             shift = self.bias.detach().float().contiguous()
+        p4 = self.packed_wino4(x.shape[2], x.shape[3])
+        if p4 is not None:
+            return K.conv2d_wino4_fwd(x.contiguous().float(), p4, self.out_channels, scale, shift, relu)
         pw = self.packed_wino(x.shape[2], x.shape[3])
         if pw is not None:
             return K.conv2d_wino_fwd(x.contiguous().float(), pw, self.out_channels, scale, shift, relu)
@@ -163,8 +175,10 @@ class _HipConv2d(nn.Conv2d):
 
     def forward(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            pw = self.packed_wino(x.shape[2], x.shape[3])
-            return Conv2dFn.apply(x.float(), self.weight, self.bias, None if pw is not None else self.packed_weight(), pw)
+            p4 = self.packed_wino4(x.shape[2], x.shape[3])
+            pw = None if p4 is not None else self.packed_wino(x.shape[2], x.shape[3])
+            pk = None if (p4 is not None or pw is not None) else self.packed_weight()
+            return Conv2dFn.apply(x.float(), self.weight, self.bias, pk, pw, p4)
         return self.hip_forward(x)
 
 

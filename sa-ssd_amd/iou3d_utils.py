@@ -40,14 +40,14 @@ def boxes_iou3d_gpu(boxes_a, boxes_b):
 
 def nms_gpu(boxes, scores, thresh):
     """(N,5) bev boxes, (N) scores -> indices of kept boxes, descending score (reference :114-128)."""
-    order = scores.sort(0, descending=True, stable=True)[1]
+    order = scores.sort(dim=0, descending=True, stable=True)[1]
     keep, num = K.nms_gpu(boxes[order].contiguous(), thresh)
     return order[keep[:int(num.item())]].contiguous()
 
 
 def nms_normal_gpu(boxes, scores, thresh):
     """(N,5) bev boxes, (N) scores -> kept indices by descending score, axis-aligned IoU (reference :130-144)."""
-    order = scores.sort(0, descending=True, stable=True)[1]
+    order = scores.sort(dim=0, descending=True, stable=True)[1]
     keep, num = K.nms_gpu(boxes[order].contiguous(), thresh, normal=True)
     return order[keep[:int(num.item())]].contiguous()
 

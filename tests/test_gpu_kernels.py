@@ -351,3 +351,16 @@ def test_nms_normal_gpu(dev):
             alive &= ~((iou > np.float32(0.3)) & (np.arange(n) > i))
         got = iou3d_utils.nms_normal_gpu(torch.from_numpy(b).to(dev), torch.from_numpy(sc).to(dev), 0.3).cpu().numpy()
         assert np.array_equal(got, order[np.asarray(keep)]), n
+
+
+def test_iou3d_utils_nms_gpu_facade(dev):
+    """iou3d_utils.nms_gpu (reference :114-128: sort by score, rotated NMS, indices in the caller's order) against the C
+    oracle's greedy loop."""
+    from sassd import iou3d_utils
+    rng = np.random.default_rng(9)
+    b = H.rand_bev_boxes(rng, 150, spread=18.0)
+    sc = rng.random(150).astype(np.float32)
+    order = np.argsort(-sc, kind="stable")
+    keep_ref = clib.nms_rotated(b[order], 0.1)
+    got = iou3d_utils.nms_gpu(torch.from_numpy(b).to(dev), torch.from_numpy(sc).to(dev), 0.1).cpu().numpy()
+    assert np.array_equal(got, order[np.asarray(keep_ref)])

@@ -147,14 +147,31 @@ def test_training_step_vs_oracle(dev, cfgfile, names, HALF):
         kw["gt_bboxes"].append(torch.from_numpy(gts[b]).to(dev))
         lab = [names.index(t) + 1 if t in names else 0 for t in types[b]]
         kw["gt_labels"].append(torch.tensor(lab, dtype=torch.int64, device=dev))
+    acfg = {n: (c.train_cfg.rpn.assigner[n].pos_iou_thr, c.train_cfg.rpn.assigner[n].neg_iou_thr) for n in names}
+    ref_args = (sd, np.concatenate(feats), np.concatenate(coors), 2, HALF["sparse_shape"], gts, types, names,
+                {n: np.stack([anbv[n][0]] * 2) for n in names}, {n: np.stack(masks[n]) for n in names}, acfg)
+    ref_l, ref_g, ex = train_ref.train_step(*ref_args)
+    # threshold-safe guided-anchor selection: move train_cfg.rpn.anchor_thr (0.1) to a nearby value that no masked
+    # anchor score of the oracle approaches, so that GPU and CPU select the same anchors (a different selection would put
+    # a PSWarp-sampling gradient of a borderline box into the box head of one side only)
+    top = torch.sigmoid(ex["cls"]).reshape(2, -1, len(names)).max(-1)[0]
+    msk = torch.from_numpy(np.concatenate([np.stack(masks[n]) for n in names], 1)).reshape(2, -1)
+    vals = top[msk].numpy()
+    thr = None
+    for margin in (1e-4, 5e-5, 2e-5, 1e-5):
+        try:
+            thr = H.safe_threshold(0.1, vals, margin=margin, step=2.5 * margin)
+            break
+        except AssertionError:
+            continue
+    assert thr is not None
+    if abs(thr - 0.1) > 1e-9:
+        ref_l, ref_g, ex = train_ref.train_step(*ref_args, anchor_thr=thr)
+    model.train_cfg.rpn.anchor_thr = thr
     losses = model(None, [dict(sample_idx=0), dict(sample_idx=1)], return_loss=True, **kw)
     total = sum(v.sum() for v in losses.values())
     total.backward()
     torch.cuda.synchronize()
-    acfg = {n: (c.train_cfg.rpn.assigner[n].pos_iou_thr, c.train_cfg.rpn.assigner[n].neg_iou_thr) for n in names}
-    ref_l, ref_g, ex = train_ref.train_step(
-        sd, np.concatenate(feats), np.concatenate(coors), 2, HALF["sparse_shape"], gts, types, names,
-        {n: np.stack([anbv[n][0]] * 2) for n in names}, {n: np.stack(masks[n]) for n in names}, acfg)
     assert set(losses) == set(ref_l) == {"aux_loss_cls", "aux_loss_reg", "rpn_loc_loss", "rpn_cls_loss",
                                         "rpn_dir_loss", "loss_cls"}
     assert int((ex["labels"] > 0).sum()) > 10 and int((ex["ext_labels"] > 0).sum()) >= len(types[0]) + len(types[1])
@@ -175,9 +192,9 @@ def test_training_step_vs_oracle(dev, cfgfile, names, HALF):
             continue
         worst[name] = _rel(p.grad, rg)
         checked += 1
-    # three classes: 3x the anchors pass through the 0.1 guided-anchor threshold, so a few more borderline selections differ
-    # between the GPU and CPU logits; their PSWarp-sampling gradient lands in the box head (measured 2.2e-3 there)
-    tol = 2e-3 if len(names) == 1 else 5e-3
+    # (three classes: the box-head BIAS gradient sums 42 channels over 105 600 anchors with heavy cancellation -- measured
+    # 2.6e-3 there, every other tensor < 2e-3)
+    tol = 2e-3 if len(names) == 1 else 3e-3
     bad = {k: v for k, v in worst.items() if not v < tol}
     assert checked >= 60 and not bad, (checked, bad)
 

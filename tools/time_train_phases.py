@@ -29,7 +29,7 @@ opt = train.build_optimizer(model, cfg.optimizer, 1)
 sched = train.build_scheduler(opt, 1000, 1, cfg.optimizer, cfg.lr_config)
 sync = train.GradSync(opt.flat)
 clouds = [torch.from_numpy(synth.k21(i)).to(dev) for i in range(4)]
-gts = [torch.from_numpy(bench.synth_gt(i)).to(dev) for i in range(4)]
+gts = [torch.from_numpy(bench.synth_gt_on_points(synth.k21(i), i)).to(dev) for i in range(4)]
 types = [np.array(["Car"] * 8)] * 4
 S = torch.cuda.synchronize
 acc = dict(data=0., fwd=0., bwd=0., opt=0.)

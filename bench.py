@@ -376,6 +376,11 @@ def main():
         if os.path.exists(tj) and B == 1 and args.config == "car":
             traffic = json.load(open(tj))["traffic_bytes_per_launch"]
             break
+    sp_traffic = None                    # fabric-side bytes of one sparse pass (PMC passes, profiles/): 2 x FETCH + WRITE
+    tj = os.path.join(ROOT, "profiles", "r02_sparse_%s_hbm_traffic.json" % args.config)
+    if os.path.exists(tj) and B == w["batch"]:
+        t = json.load(open(tj))
+        sp_traffic = int((2 * t["FETCH_SIZE_kb_per_pass_raw"] + t["WRITE_SIZE_kb_per_pass_raw"]) * 1024)
     headline = args.config == "car" and B == 1
     out = {
         "metric": "KITTI-Car inference frames/sec (whole job)" if args.config == "car" else
@@ -413,7 +418,14 @@ def main():
                             "frac_of_measured_copy_peak": round(sp_gbs / MEASURED_HBM_GBS, 4),
                             "bytes_gs": work["bytes_gs"], "bytes_min": work["bytes_min"],
                             "rulebook_bytes": work["rulebook_bytes"], "flops": work["flops"],
-                            "ms": round(sp_ms, 4), "ms_eager_isolated": round(iso_ms["sparse"], 4), "rows": work["n"]},
+                            "ms": round(sp_ms, 4), "ms_eager_isolated": round(iso_ms["sparse"], 4), "rows": work["n"],
+                            "traffic": sp_traffic,
+                            "traffic_unit": "fabric-side bytes per pass, upper bound 2 x FETCH_SIZE + WRITE_SIZE over all "
+                                            "rulebook / sparse-conv dispatches (separate rocprofv3 --pmc passes, profiles/): "
+                                            "near bytes_min, the gathers of bytes_gs are served by the XCD L2s",
+                            "note": "achieved = (bytes_gs + rulebook_bytes) / ms: the gather-scatter MODEL bytes of SURVEY "
+                                    "8(d), which count every rulebook pair's row fetch -- an algorithmic rate, not an HBM "
+                                    "rate (see traffic)"},
         "stage_ms": {k: round(v, 4) for k, v in sorted(iso_ms.items())},
         "bev_total_ms": round(bev_total_ms, 4),
         "detections_last_frame": ndet, "guided_anchor_candidates_last_frame": ncand,

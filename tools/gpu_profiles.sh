@@ -1,0 +1,29 @@
+#!/bin/bash
+# round-2 evidence: bench JSON lines, rocprofv3 kernel-trace summaries, PMC (FETCH_SIZE / WRITE_SIZE) passes
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/prof; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/prof; R=$GRAFT_REPO_ROOT
+trace() {  # name, command...
+  local name=$1; shift
+  rm -rf /tmp/pf_$name; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pf_$name -- "$@" > $O/${name}_under_rocprof.log 2>&1 ); echo "$name rc=$?"
+  local DB=$(find /tmp/pf_$name -name "*.db" | head -1)
+  [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB > $O/${name}_kernel_stats.txt 2>&1
+}
+pmc() {  # name, counter, command...
+  local name=$1; local ctr=$2; shift; shift
+  rm -rf /tmp/pm_$name; ( cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pm_$name -- "$@" > $O/${name}_${ctr}.log 2>&1 ); echo "$name $ctr rc=$?"
+  local DB=$(find /tmp/pm_$name -name "*.db" | head -1)
+  [ -n "$DB" ] && python $R/tools/rocprof_pmc.py $DB > $O/${name}_${ctr}.json 2>&1
+}
+timeout 600 python bench.py --steps 200 --warmup 20 > $O/bench_default.log 2>&1; echo "bench default rc=$?"
+trace bench_inflight3 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline
+trace bench_inflight1 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --inflight 1
+trace bench_multi python $R/bench.py --config multi --steps 20 --warmup 5
+trace bench_waymo python $R/bench.py --config waymo --steps 20 --warmup 5
+trace bench_train python $R/bench.py --mode train --steps 10 --warmup 4
+pmc wino4 FETCH_SIZE python $R/tools/run_wino4.py --profile --reps 5
+pmc wino4 WRITE_SIZE python $R/tools/run_wino4.py --profile --reps 5
+pmc sparse_multi FETCH_SIZE python $R/tools/run_sparse_only.py --config multi --reps 3
+pmc sparse_multi WRITE_SIZE python $R/tools/run_sparse_only.py --config multi --reps 3
+pmc sparse_car FETCH_SIZE python $R/tools/run_sparse_only.py --config car --reps 5
+pmc sparse_car WRITE_SIZE python $R/tools/run_sparse_only.py --config car --reps 5
+ls -la $O | head -40

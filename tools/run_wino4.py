@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--cin", type=int, default=256)
 ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--profile", action="store_true", help="default geometry only, `reps` launches: the target of rocprofv3 "
+                "--kernel-trace / --pmc passes")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 B, C, H, W = args.batch, args.cin, 200, 176
@@ -39,6 +41,11 @@ def timeit(fn):
     return e0.elapsed_time(e1) / args.reps * 1e3
 
 
+if args.profile:
+    for _ in range(args.reps):
+        K.conv2d_wino4_fwd(x, w4, 256, sc, sh, True, y, ws)
+    torch.cuda.synchronize()
+    sys.exit(0)
 from sassd import _C  # noqa: E402
 flops = 2.0 * 256 * C * 9 * H * W * B
 ref = K.conv2d_wino_fwd(x, w2, 256, sc, sh, True).clone()

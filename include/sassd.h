@@ -42,7 +42,7 @@ int sassd_last_hip_error(void);
 const char *sassd_last_hip_error_string(void);
 
 /* Debug / ablation switches of the sparse-conv forward kernel (tools/ablate_spconv.py); 0 in production:
- * bit0 no gather loads, bit1 no LDS scatter-add, bit2 no MFMA, bit3 no weight loads, bit8 legacy register-stationary
+ * bit0 no gather loads, bit1 no LDS scatter-add, bit2 no MFMA, bit3 no weight loads, bit4 ticket offset assignment, bit8 legacy register-stationary
  * kernel, bits 16+ force the row-slice size (64 / 128). */
 void sassd_debug_set_spconv(int flags);
 

@@ -276,6 +276,16 @@ int launch_pack(const float *w, int K, float *packed, int transposed, hipStream_
 __constant__ int c_offset_order[kK] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25,
                                        0, 2, 6, 8, 18, 20, 24, 26};
 
+// Static offset -> wave assignment (slots of c_offset_order; longest-processing-time packing with weights centre 4, face
+// 3, edge 2, corner 1.3 MFMA tiles per 64 rows): every output row's <= 27 contributions are then summed in a FIXED order
+// (inside a wave: its slot list; across waves: slab 0, 1, ...), i.e. results are bit-reproducible run to run.  The
+// ticket counter (dynamic assignment) balances better on skewed rulebooks but makes the fp32 summation order depend on
+// timing.
+__constant__ int c_assign8[8][5] = {{0, 15, 23, -1, -1}, {1, 9, 17, -1, -1}, {2, 10, 18, -1, -1}, {3, 11, 19, 25, -1},
+                                    {4, 12, 20, 26, -1}, {5, 13, 21, -1, -1}, {6, 14, 22, -1, -1}, {7, 8, 16, 24, -1}};
+__constant__ int c_assign4[4][8] = {{0, 7, 8, 12, 16, 21, 25, -1}, {1, 4, 9, 13, 17, 22, 26, -1},
+                                    {2, 5, 10, 14, 18, 23, -1, -1}, {3, 6, 11, 15, 19, 20, 24, -1}};
+
 template <int COUT, int RW, int NW, int CS>
 constexpr size_t gs_lds_bytes() { return (size_t)(NW * RW * (COUT / CS) + RW * kK + NW * 2 * RW + 4) * 4; }
 
@@ -326,7 +336,12 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
         for (int u = 0; u < NTW; ++u) load_vec<KS>(wp + (((size_t)k * NT + half * NTW + u) * 64 + lane) * KS, b[u]);
     };
     // every wave starts on a fixed offset (the heaviest ones), so its weights are requested at kernel entry as well
-    int k = c_offset_order[wave / CS];
+    constexpr int WPH = NW / CS;                             // waves per channel group
+    constexpr bool HAS_TABLE = (WPH == 8 || WPH == 4);
+    const bool fixed = HAS_TABLE && !(dbg & 16);             // static assignment (deterministic) unless switched off
+    const int wpos = wave / CS;
+    int nxt = 1;                                             // next entry of this wave's static slot list
+    int k = c_offset_order[wpos];
     load_w(k, b0);
     const int n = min(*n_ptr, cap);
     if (r0 >= n) return;                                     // workgroup-uniform
@@ -347,8 +362,14 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
     auto grab = [&]() -> int {
         for (;;) {
             int slot = 0;
-            if (lane == 0) slot = atomicAdd(next_slot + half, 1);
-            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (fixed) {
+                slot = (WPH == 8) ? c_assign8[wpos & 7][nxt < 4 ? nxt : 4] : c_assign4[wpos & 3][nxt < 7 ? nxt : 7];
+                ++nxt;
+                if (slot < 0) return -1;
+            } else {
+                if (lane == 0) slot = atomicAdd(next_slot + half, 1);
+                slot = __builtin_amdgcn_readfirstlane(slot);
+            }
             if (slot >= kK) return -1;
             const int k = c_offset_order[slot];
             bool any = false;
@@ -471,7 +492,7 @@ int launch_gs_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int 
     if (rc) return rc;
     const int grid = 64 * cdiv(cdiv(cap, RW), 64);
     hipLaunchKernelGGL((spconv_gs_kernel<CIN, COUT, RW, NW, CS, WPS>), dim3(grid), dim3(NW * 64), lds, stream, x, nbr,
-                       n_ptr, cap, wp, scale, shift, relu, y, g_spconv_dbg & 15);
+                       n_ptr, cap, wp, scale, shift, relu, y, g_spconv_dbg & 31);
     return sassd_launch_status();
 }
 
@@ -706,7 +727,8 @@ namespace {
 }  // namespace
 
 // debug / ablation switches (tools/ablate_spconv.py): bit0 no gather loads, bit1 no slab accumulate, bit2 no MFMA,
-// bit3 no weight loads, bit8 legacy register-stationary kernel; bits 16.. select the workgroup geometry (0 default)
+// bit3 no weight loads, bit4 dynamic (ticket) offset assignment instead of the static table, bit8 legacy
+// register-stationary kernel; bits 16.. select the workgroup geometry (0 default)
 extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags & 0xFFFF; g_spconv_cfg = flags >> 16; }
 
 extern "C" size_t sassd_spconv_packed_floats(int K, int Cin, int Cout) { return (size_t)K * Cin * Cout; }

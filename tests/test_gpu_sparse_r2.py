@@ -161,3 +161,27 @@ def test_voxelize_device_count(dev):
     ndev.fill_(0)
     got = K.voxelize(stage, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 20000, coors_cols=4, n_dev=ndev)
     assert int(got["voxel_num"].item()) == 0
+
+
+def test_spconv_is_bit_reproducible(dev):
+    """Static offset -> wave assignment + slab sums in wave order: the same inputs give the same bits on every launch,
+    on a busy and on an idle GPU (the ticket-counter assignment, debug bit 4, would not guarantee that)."""
+    idx = _level0("k21", 0)
+    shape = (40, 1600, 1408)
+    for _ in range(3):
+        idx, _, shape = orb.conv_rulebook(idx, shape, 1)
+    _, nbr = orb.subm_rulebook(idx, shape)
+    n = len(nbr)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 64, generator=g).to(dev)
+    w = (torch.randn(27, 64, 64, generator=g) * 0.1).to(dev)
+    nb = torch.from_numpy(nbr).to(dev)
+    nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+    wp = K.spconv_pack_weight(w)
+    ref = K.spconv_fwd(x, nb, nptr, n, wp, 27, 64, 64).clone()
+    busy = torch.randn(4096, 4096, device=dev)
+    for i in range(20):
+        if i % 2:
+            busy = busy @ busy * 1e-3                 # another kernel in flight changes the wave timing
+        y = K.spconv_fwd(x, nb, nptr, n, wp, 27, 64, 64)
+        assert torch.equal(y, ref), i

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-layer timing + ablation of the sparse path on a synthetic frame batch (debug switches of spconv.hip):
-bit0 no gather loads, bit1 no LDS scatter-add, bit2 no MFMA, bit3 no weight loads, bit8 legacy register-stationary
-kernel, bits 16+ row-slice size.  Also times the rulebook build (fused pyramid vs the per-op chain).
+bit0 no gather loads, bit1 no slab accumulate, bit2 no MFMA, bit3 no weight loads, bit4 ticket (dynamic) offset assignment,
+bit8 legacy register-stationary kernel, bits 16+ workgroup geometry.  Also times the rulebook build (fused pyramid vs the per-op chain).
 
   python tools/ablate_spconv.py [--config car|multi|waymo] [--batch B] [--ablate]
 """
@@ -56,7 +56,7 @@ plan = plans[True]
 work = plan.sparse_work()
 print("pairs", work["pairs"], "bytes_gs %.1f MB" % (work["bytes_gs"] / 1e6))
 
-MODES = [("legacy", 256), ("gs 64x8", 5 << 16), ("gs 64x4", 1 << 16), ("gs split2x16", 4 << 16), ("default", 0)]
+MODES = [("legacy", 256), ("gs 64x8", 5 << 16), ("gs 64x4", 1 << 16), ("default", 0), ("default+tickets", 16)]
 layers = []
 lvl = 0
 for kind, cin, cout, key, wp, scale, shift in plan.sp:

@@ -65,32 +65,19 @@ __global__ void __launch_bounds__(256) df_count_kernel(DfParams P, int nblk, int
     if (threadIdx.x == 0) bsum[b * nblk + blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(1024) df_scan_kernel(int nblk, const int *__restrict__ bsum, int *__restrict__ bbase,
-                                                       int capK, int32_t *__restrict__ counts, int32_t *status)
-{
-    __shared__ int wsum[17];
-    const int b = blockIdx.x;
-    int running = 0;
-    for (int b0 = 0; b0 < nblk; b0 += 1024) {
-        const int i = b0 + threadIdx.x;
-        int v = (i < nblk) ? bsum[b * nblk + i] : 0;
-        int tot;
-        int ex = block_exclusive_scan(v, wsum, &tot);
-        if (i < nblk) bbase[b * nblk + i] = running + ex;
-        running += tot;
-    }
-    if (threadIdx.x == 0) {
-        if (running > capK) { if (status) atomicOr(status, SASSD_ST_BOX_OVERFLOW); running = capK; }
-        counts[b] = running;
-    }
-}
-
-__global__ void __launch_bounds__(256) df_emit_kernel(DfParams P, int nblk, const int *__restrict__ bbase,
+// every block sums the counts of the blocks before it (a few hundred ints: no separate single-workgroup scan launch);
+// the last block publishes the sample's candidate count
+__global__ void __launch_bounds__(256) df_emit_kernel(DfParams P, int nblk, const int *__restrict__ bsum,
                                                       float *__restrict__ guided, int32_t *__restrict__ labels,
-                                                      float *__restrict__ scores)
+                                                      float *__restrict__ scores, int32_t *__restrict__ counts,
+                                                      int32_t *status)
 {
     __shared__ int wsum[17];
     const int b = blockIdx.y;
+    int part = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) part += bsum[b * nblk + j];
+    int before;
+    block_exclusive_scan(part, wsum, &before);
     const int base = blockIdx.x * kDfPerBlock + threadIdx.x * kDfPerThread;
     bool sel[kDfPerThread];
     float sc[kDfPerThread];
@@ -99,7 +86,12 @@ __global__ void __launch_bounds__(256) df_emit_kernel(DfParams P, int nblk, cons
 #pragma unroll
     for (int k = 0; k < kDfPerThread; ++k) { sel[k] = df_select(P, b, base + k, &sc[k], &lb[k]); s += sel[k] ? 1 : 0; }
     int tot;
-    int o = bbase[b * nblk + blockIdx.x] + block_exclusive_scan(s, wsum, &tot);
+    int o = before + block_exclusive_scan(s, wsum, &tot);
+    if ((int)blockIdx.x == nblk - 1 && threadIdx.x == 0) {
+        int total = before + tot;
+        if (total > P.capK) { if (status) atomicOr(status, SASSD_ST_BOX_OVERFLOW); total = P.capK; }
+        counts[b] = total;
+    }
 #pragma unroll
     for (int k = 0; k < kDfPerThread; ++k) {
         if (!sel[k]) continue;
@@ -571,13 +563,10 @@ extern "C" int sassd_decode_filter(const float *box, const float *cls, const flo
     const int nblk = cdiv(P.Atot, kDfPerBlock);
     if (workspace_bytes < sassd_decode_filter_workspace_bytes(batch, P.Atot)) return SASSD_ENOSPC;
     int *bsum = (int *)workspace;
-    int *bbase = (int *)((char *)workspace + align_up((size_t)batch * nblk * 4, 256));
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL(df_count_kernel, dim3(nblk, batch), dim3(256), 0, stream, P, nblk, bsum);
-    hipLaunchKernelGGL(df_scan_kernel, dim3(batch), dim3(1024), 0, stream, nblk, (const int *)bsum, bbase, capK, counts,
-                       status);
-    hipLaunchKernelGGL(df_emit_kernel, dim3(nblk, batch), dim3(256), 0, stream, P, nblk, (const int *)bbase, guided,
-                       labels, scores);
+    hipLaunchKernelGGL(df_emit_kernel, dim3(nblk, batch), dim3(256), 0, stream, P, nblk, (const int *)bsum, guided,
+                       labels, scores, counts, status);
     return sassd_launch_status();
 }
 

@@ -127,7 +127,8 @@ def synth_gt_on_points(cloud, seed, n=8):
 def main_train(args):
     """--mode train: BASELINE configs[2] shape (car_cfg training, batch 2 / GPU, DDP).  A step = device voxelize +
     anchor masks + forward_train + backward + flat-gradient all-reduce (RCCL) + fused clip/AdamW update."""
-    from sassd import dist as D, train, anchors as A
+    from sassd import dist as D, train, anchors as A, autograd as AG
+    AG.set_bev_precision(args.precision)
     rank, local_rank, world = D.init("nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -179,9 +180,12 @@ def main_train(args):
     print(json.dumps({
         "metric": "KITTI-Car training samples/sec (whole job)", "value": round(sps, 3), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs/car_cfg.py training, batch=%d/GPU, fp32, synthetic lidar64 K21 frames + 8 "
-                               "synthetic car boxes/frame on occupied voxels, adam_onecycle, grad clip 10" % B,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": "configs/car_cfg.py training, batch=%d/GPU, %s, synthetic lidar64 K21 frames + 8 "
+                               "synthetic car boxes/frame on occupied voxels, adam_onecycle, grad clip 10"
+                               % (B, "bf16 MFMA operands in the BEV convs (fwd/dgrad/wgrad; fp32 accumulation, master "
+                                     "weights and activations), fp32 sparse trunk" if args.precision == "bf16" else "fp32"),
                    "global_batch": B * world, "parallelism": "ddp x%d (one flat-gradient RCCL all-reduce/step)" % world},
         "final_loss": round(float(loss), 4), "loss_terms": {k: round(float(v), 4) for k, v in terms.items()}}))
 
@@ -218,6 +222,8 @@ def main():
                     help="infer = BASELINE configs[1] (headline); train = configs[2] shape, extra measurement")
     ap.add_argument("--config", choices=("car", "multi", "waymo"), default="car",
                     help="car = configs[1] (headline); multi = configs[3] (batch 8); waymo = configs[4] shape (batch 4)")
+    ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
+                    help="--mode train: arithmetic of the dense BEV convolutions (BASELINE configs[2] trains in bf16)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)

@@ -213,6 +213,18 @@ int sassd_conv1x1_gemm_pack_weight(const float *w /*[Cout,Cin,1,1]*/, int Cout, 
 int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *scale, const float *shift, int relu,
                            float *y, int batch, int Cin, int Cout, int H, int W, void *stream);
 
+/* BASELINE configs[2] (bf16 training): the 3x3 pad-1 BEV convolutions (cmn.py:240-262) with bf16 MFMA operands --
+ * direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulation, NCHW fp32 activations in and out, optional
+ * per-channel bias.  Weights are packed once per update ([Cout,Cin,3,3] fp32 -> bf16 [tap][Cin/8][Cout][8],
+ * sassd_conv2d_bf16_packed_elems 16-bit elements).  The data gradient is the same call on dy with the weights
+ * transposed and the taps mirrored.  Supported: Cin % 32 == 0, Cout % 128 == 0, W % 16 == 0 (else SASSD_EINVAL; the
+ * caller keeps the fp32 kernels). */
+int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W);
+size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout);
+int sassd_conv2d_bf16_pack_weight(const float *w, int Cout, int Cin, void *packed, void *stream);
+int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const float *shift, float *y, int batch, int Cin,
+                          int Cout, int H, int W, void *stream);
+
 /* Training: weight gradient of the same convolutions (autograd of nn.Conv2d at cmn.py:240-262 and
  * ssd_rotate_head.py:120-125,424-429; cuDNN in the reference).  x [B,Cin,H,W], dy [B,Cout,H,W] NCHW fp32 ->
  * dw [Cout,Cin,k,k] (torch layout), overwritten or accumulated.  Split-K over pixels with a deterministic second-stage
@@ -221,6 +233,11 @@ int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *s
 size_t sassd_conv2d_wgrad_workspace_bytes(int batch, int Cin, int Cout, int H, int W, int ksize);
 int sassd_conv2d_bwd_weight(const float *x, const float *dy, float *dw, int batch, int Cin, int Cout, int H, int W,
                             int ksize, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+/* BASELINE configs[2] (bf16 training): the same contraction with x and dy rounded to bf16 (round-to-nearest-even) on
+ * their way into LDS, multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; dw stays fp32.  W must be even
+ * (SASSD_EINVAL otherwise).  What the reference gets from cuDNN under torch autocast / apex O1. */
+int sassd_conv2d_bwd_weight_bf16(const float *x, const float *dy, float *dw, int batch, int Cin, int Cout, int H, int W,
+                                 int ksize, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (f-1) anchors_mask: mmdet/datasets/kitti.py:333-343 with geometry.py:676-710

@@ -98,8 +98,13 @@ _SIGS = {
     "sassd_conv1x1_gemm_supported": (_I, [_I, _I, _I, _I]),
     "sassd_conv1x1_gemm_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv1x1_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "sassd_conv2d_bf16_supported": (_I, [_I, _I, _I, _I]),
+    "sassd_conv2d_bf16_packed_elems": (_SZ, [_I, _I]),
+    "sassd_conv2d_bf16_pack_weight": (_I, [_P, _I, _I, _P, _P]),
+    "sassd_conv2d_bf16_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "sassd_conv2d_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "sassd_conv2d_bwd_weight_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_rotate_iou_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "sassd_kitti_eval_statistics": (_I, [_P, C.c_int64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, C.c_double, _P, _I, _I, _P,
                                          _P, _P]),

@@ -7,6 +7,23 @@ from torch.autograd import Function
 from . import kernels as K
 
 
+_BEV_PRECISION = "fp32"
+
+
+def set_bev_precision(precision):
+    """Arithmetic of the dense BEV / head convolutions in TRAINING (BASELINE configs[2] trains in bf16): "fp32" keeps the
+    fp32-MFMA kernels (bit-comparable with the fp32 oracle), "bf16" rounds the MFMA operands to bf16 (fp32 accumulation,
+    fp32 master weights, fp32 activations between layers) -- what torch autocast gives the reference's cuDNN convs."""
+    global _BEV_PRECISION
+    if precision not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+    _BEV_PRECISION = precision
+
+
+def bev_precision():
+    return _BEV_PRECISION
+
+
 def _n_ptr(n, dev):
     return torch.full((1,), int(n), dtype=torch.int32, device=dev)        # fill kernel: no blocking H2D copy
 
@@ -90,16 +107,42 @@ def _dgrad_pack(weight, h, w):
     return pack
 
 
+_bf16_packs = {}
+
+
+def _bf16_pack(weight, transposed):
+    """bf16 [tap][Cin/8][Cout][8] image of the weights (forward) or of their transposed, tap-mirrored form (data gradient),
+    cached per parameter storage and weight generation like _dgrad_pack."""
+    key = (weight.data_ptr(), tuple(weight.shape), transposed)
+    gen = K.weight_key(weight)
+    hit = _bf16_packs.get(key)
+    if hit is not None and hit[0] == gen:
+        return hit[1]
+    w = weight.detach()
+    if transposed:
+        w = w.transpose(0, 1).flip(2, 3)
+    pack = K.conv2d_bf16_pack_weight(w.contiguous())
+    _bf16_packs[key] = (gen, pack)
+    return pack
+
+
 class Conv2dFn(Function):
     """NCHW fp32 conv (3x3 pad 1 / 1x1) + optional bias on the fp32-MFMA kernels; data gradient = the same kernels
-    with flipped, transposed weights; weight gradient = the split-K MFMA kernel."""
+    with flipped, transposed weights; weight gradient = the split-K MFMA kernel.  Under set_bev_precision("bf16") the
+    3x3 forward / data gradient (shapes sassd_conv2d_bf16_supported) and every weight gradient run on the bf16 MFMA
+    kernels instead (fp32 accumulation, fp32 tensors in and out)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, packed, wino, wino4=None):
         x = x.contiguous()
         ks = weight.shape[2]
-        y = _conv_any(x, weight.detach(), ks, packed, wino, bias.detach().contiguous() if bias is not None else None,
-                      wino4)
+        cout, cin = weight.shape[0], weight.shape[1]
+        shift = bias.detach().contiguous() if bias is not None else None
+        ctx.bf16 = _BEV_PRECISION == "bf16"
+        if ctx.bf16 and ks == 3 and K.conv2d_bf16_supported(cin, cout, x.shape[2], x.shape[3]):
+            y = K.conv2d_bf16_fwd(x, _bf16_pack(weight, False), cout, shift)
+        else:
+            y = _conv_any(x, weight.detach(), ks, packed, wino, shift, wino4)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
@@ -111,10 +154,14 @@ class Conv2dFn(Function):
         ks = weight.shape[2]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            pk = _dgrad_pack(weight, dy.shape[2], dy.shape[3])                      # [Cin, Cout, k, k], taps mirrored
-            dx = _conv_any(dy, pk["wt"], ks, pk.get("packed"), pk.get("wino"), None, pk.get("wino4"))
+            cout, cin = weight.shape[0], weight.shape[1]
+            if ctx.bf16 and ks == 3 and K.conv2d_bf16_supported(cout, cin, dy.shape[2], dy.shape[3]):
+                dx = K.conv2d_bf16_fwd(dy, _bf16_pack(weight, True), cin)
+            else:
+                pk = _dgrad_pack(weight, dy.shape[2], dy.shape[3])                  # [Cin, Cout, k, k], taps mirrored
+                dx = _conv_any(dy, pk["wt"], ks, pk.get("packed"), pk.get("wino"), None, pk.get("wino4"))
         if ctx.needs_input_grad[1]:
-            dw = K.conv2d_bwd_weight(x, dy, ks)
+            dw = K.conv2d_bwd_weight(x, dy, ks, bf16=ctx.bf16)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
         return dx, dw, db, None, None, None

@@ -437,8 +437,36 @@ def conv1x1_gemm_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=No
     return y
 
 
-def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False):
-    """x [B,Cin,H,W], dy [B,Cout,H,W] -> dw [Cout,Cin,k,k] on the fp32-MFMA split-K kernel."""
+def conv2d_bf16_supported(cin, cout, h, w):
+    return bool(_C.lib().sassd_conv2d_bf16_supported(cin, cout, h, w))
+
+
+def conv2d_bf16_pack_weight(w):
+    """w [Cout,Cin,3,3] fp32 -> bf16 [tap][Cin/8][Cout][8] (once per weight update)."""
+    _chk_cuda(w)
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    L = _C.lib()
+    packed = torch.empty(L.sassd_conv2d_bf16_packed_elems(cin, cout), dtype=torch.int16, device=w.device)
+    _C.check(L.sassd_conv2d_bf16_pack_weight(_C.ptr(w.contiguous()), cout, cin, _C.ptr(packed), _C.stream()),
+             "sassd_conv2d_bf16_pack_weight")
+    return packed
+
+
+def conv2d_bf16_fwd(x, w_packed, cout, shift=None, y=None):
+    """3x3 pad-1 conv, bf16 MFMA operands / fp32 accumulation, NCHW fp32 in and out (+ optional per-channel bias)."""
+    _chk_cuda(x, w_packed)
+    b, cin, h, w = x.shape
+    if y is None:
+        y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().sassd_conv2d_bf16_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(shift) if shift is not None else None,
+                                            _C.ptr(y), b, cin, cout, h, w, _C.stream()), "sassd_conv2d_bf16_fwd")
+    return y
+
+
+def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False, bf16=False):
+    """x [B,Cin,H,W], dy [B,Cout,H,W] -> dw [Cout,Cin,k,k] on the split-K MFMA kernel: fp32 operands on the fp32 pipe,
+    or (bf16=True, W even) operands rounded to bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation."""
     _chk_cuda(x, dy)
     b, cin, h, w = x.shape
     cout = dy.shape[1]
@@ -447,9 +475,9 @@ def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False):
         dw = torch.empty(cout, cin, ksize, ksize, dtype=torch.float32, device=x.device)
     wsb = L.sassd_conv2d_wgrad_workspace_bytes(b, cin, cout, h, w, ksize)
     ws = workspace("conv2d_wgrad", wsb, x.device)
-    _C.check(L.sassd_conv2d_bwd_weight(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), b, cin, cout, h, w, ksize,
-                                       1 if accumulate else 0, _C.ptr(ws), wsb, _C.stream()),
-             "sassd_conv2d_bwd_weight")
+    fn = L.sassd_conv2d_bwd_weight_bf16 if bf16 and w % 2 == 0 else L.sassd_conv2d_bwd_weight
+    _C.check(fn(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), b, cin, cout, h, w, ksize, 1 if accumulate else 0, _C.ptr(ws), wsb,
+                _C.stream()), "sassd_conv2d_bwd_weight")
     return dw
 
 

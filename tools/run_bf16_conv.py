@@ -1,0 +1,54 @@
+"""Times the bf16 BEV training kernels next to the fp32 ones at the bench shape (B=2, 256->256, 200x176) with
+torch events on the current stream:  python tools/run_bf16_conv.py [--iters 20]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sassd  # noqa: E402,F401
+from sassd import kernels as K  # noqa: E402
+
+
+def timed(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    x = torch.randn(2, 256, 200, 176, device=dev)
+    dy = torch.randn(2, 256, 200, 176, device=dev) * 0.01
+    out = {}
+    out["wgrad3x3_fp32_ms"] = timed(lambda: K.conv2d_bwd_weight(x, dy, 3), a.iters)
+    out["wgrad3x3_bf16_ms"] = timed(lambda: K.conv2d_bwd_weight(x, dy, 3, bf16=True), a.iters)
+    out["wgrad1x1_fp32_ms"] = timed(lambda: K.conv2d_bwd_weight(x, dy, 1), a.iters)
+    out["wgrad1x1_bf16_ms"] = timed(lambda: K.conv2d_bwd_weight(x, dy, 1, bf16=True), a.iters)
+    flops = 2.0 * 2 * 200 * 176 * 256 * 256 * 9
+    out["wgrad3x3_bf16_tflops"] = flops / out["wgrad3x3_bf16_ms"] / 1e9
+    out["wgrad3x3_fp32_tflops"] = flops / out["wgrad3x3_fp32_ms"] / 1e9
+    if hasattr(K, "conv2d_bf16_fwd"):
+        w = torch.randn(256, 256, 3, 3, device=dev) / 48
+        pk = K.conv2d_bf16_pack_weight(w)
+        p4 = K.conv2d_wino4_pack_weight(w)
+        out["fwd3x3_bf16_ms"] = timed(lambda: K.conv2d_bf16_fwd(x, pk, 256), a.iters)
+        out["fwd3x3_wino4_fp32_ms"] = timed(lambda: K.conv2d_wino4_fwd(x, p4, 256, None, None), a.iters)
+        out["fwd3x3_bf16_tflops"] = flops / out["fwd3x3_bf16_ms"] / 1e9
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

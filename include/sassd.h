@@ -215,10 +215,10 @@ int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *s
 
 /* BASELINE configs[2] (bf16 training): the 3x3 pad-1 BEV convolutions (cmn.py:240-262) with bf16 MFMA operands --
  * direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulation, NCHW fp32 activations in and out, optional
- * per-channel bias.  Weights are packed once per update ([Cout,Cin,3,3] fp32 -> bf16 [tap][Cin/8][Cout][8],
+ * per-channel bias.  Weights are packed once per update ([Cout,Cin,3,3] fp32 -> bf16 [tap][Cin32/8][Cout][8],
  * sassd_conv2d_bf16_packed_elems 16-bit elements).  The data gradient is the same call on dy with the weights
- * transposed and the taps mirrored.  Supported: Cin % 32 == 0, Cout % 128 == 0, W % 16 == 0 (else SASSD_EINVAL; the
- * caller keeps the fp32 kernels). */
+ * transposed and the taps mirrored.  Supported: Cout % 128 == 0, W % 16 == 0 (else SASSD_EINVAL; the caller keeps the
+ * fp32 kernels); Cin is padded to a multiple of 32 with zero weights inside the pack. */
 int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W);
 size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout);
 int sassd_conv2d_bf16_pack_weight(const float *w, int Cout, int Cin, void *packed, void *stream);

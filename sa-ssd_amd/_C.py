@@ -152,5 +152,6 @@ def ptr(t):
 
 
 def stream():
+    """Raw hipStream_t of torch's current stream on the current device (one C call: this runs before every launch)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())

@@ -42,7 +42,7 @@ struct BfParams {
     const unsigned short *wp;
     const float *shift;
     float *y;
-    int B, Cin, Cout, H, W;
+    int B, Cin, CinP, Cout, H, W;                  // CinP: Cin rounded up to a whole 32-channel chunk
     int tiles_x, tiles_y;
 };
 
@@ -52,23 +52,27 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-// w fp32 [Cout][Cin][3][3] -> bf16 [tap][Cin/8][Cout][8]
-__global__ void bf16_pack_kernel(const float *__restrict__ w, int Cout, int Cin, unsigned short *__restrict__ out)
+// w fp32 [Cout][Cin][3][3] -> bf16 [tap][CinP/8][Cout][8], CinP = Cin rounded up to 32 (zero weights for the padding)
+__global__ void bf16_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int CinP,
+                                 unsigned short *__restrict__ out)
 {
-    const size_t n = (size_t)9 * Cin * Cout;
+    const size_t n = (size_t)9 * CinP * Cout;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int j = i & 7;
     size_t r = i >> 3;
     const int co = r % Cout; r /= Cout;
-    const int c8 = r % (Cin / 8);
-    const int tap = r / (Cin / 8);
-    const float v = w[((size_t)co * Cin + c8 * 8 + j) * 9 + tap];
+    const int c8 = r % (CinP / 8);
+    const int tap = r / (CinP / 8);
+    const int ci = c8 * 8 + j;
+    const float v = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.f;
     out[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
 }
 
-// COW waves along cout (64 each) x PXW waves along the 4 pixel blocks of the tile
-template <int COW, int PXW>
+// COW waves along cout (MB blocks of 32 each) x PXW waves along the 4 pixel blocks of the tile.  <8, 1, 1> (256 couts):
+// every wave owns 32 couts x all 128 pixels, so no two waves fetch the same weights and one 16-byte weight load feeds
+// four MFMAs -- with two waves per weight slice the vector L1 (64 B/clk) was the bottleneck, not the MFMA pipe.
+template <int COW, int PXW, int MB>
 __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams p)
 {
     constexpr int NT = 64 * COW * PXW;
@@ -85,7 +89,7 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
     const int b = wg % p.B;
     const int cot = wg / p.B;
     const int r0 = ty * kTR, c0 = tx * kTC;
-    const int co_w = cot * 64 * COW + wco * 64;    // this wave's first cout
+    const int co_w = (cot * COW + wco) * 32 * MB;   // this wave's first cout
     const size_t hw = (size_t)p.H * p.W;
     const float *xb = p.x + (size_t)b * p.Cin * hw;
 
@@ -95,6 +99,7 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
     int s_lds[kPer];
     bool s_ok[kPer];
     const float *s_ptr[kPer];
+    int s_g[kPer];
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
         const int e = tid + NT * i;
@@ -102,14 +107,18 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
         const int yy = r0 - 1 + row, xx = c0 - 2 + 2 * pr;                    // xx even, W even: xx+1 valid with xx
         s_ok[i] = e < kItems && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
         s_lds[i] = e < kItems ? row * kRowB + 2 * pr * kPixB + g * 16 : -1;
-        s_ptr[i] = xb + (s_ok[i] ? (size_t)(g * 8) * hw + (size_t)yy * p.W + xx : 0);
+        s_ptr[i] = xb + (s_ok[i] ? (size_t)yy * p.W + xx : 0);
+        s_g[i] = g * 8;
     }
+    // channels past Cin (padding of the last chunk) read the last real plane: their weights are zero
     auto fetch = [&](int ci0) {
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
-            const float *q = s_ptr[i] + (s_ok[i] ? (size_t)ci0 * hw : 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) st[i][j] = *(const f32x2 *)(q + (s_ok[i] ? (size_t)j * hw : 0));
+            for (int j = 0; j < 8; ++j) {
+                const int ch = s_ok[i] ? min(ci0 + s_g[i] + j, p.Cin - 1) : 0;
+                st[i][j] = *(const f32x2 *)(s_ptr[i] + (size_t)ch * hw);
+            }
         }
     };
     auto stash = [&](int buf) {
@@ -131,25 +140,25 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
     // A: packed weights, element ((tap * Cin/8 + c8) * Cout + co) * 8; this lane: co = co_w + m*32 + li, c8 += lh
     const unsigned short *wl = p.wp + ((size_t)lh * p.Cout + co_w + li) * 8;
     const size_t w_c8 = (size_t)p.Cout * 8;                 // elements per 8-channel group
-    const size_t w_tap = (size_t)(p.Cin / 8) * w_c8;        // elements per tap
+    const size_t w_tap = (size_t)(p.CinP / 8) * w_c8;       // elements per tap
     // B: LDS byte offset of this lane's pixel for block n: rows 2*(wpx*NPB+n) + (li>>4), column (li&15) + 1
     const int b_off = ((wpx * NPB * 2 + (li >> 4)) * kRowB) + ((li & 15) + 1) * kPixB + lh * 16;
 
-    f32x16 acc[2][NPB];
+    f32x16 acc[MB][NPB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < NPB; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const int nchunk = p.Cin / kKC;
-    u32x4 aring[3][2];
+    const int nchunk = p.CinP / kKC;
+    u32x4 aring[3][MB];
     auto load_a = [&](int slot, int chunk, int s) {          // s = 2*tap + kstep, chunk clamped by the caller
         const int tap = s >> 1, ks = s & 1;
         const unsigned short *q = wl + tap * w_tap + (size_t)(chunk * (kKC / 8) + ks * 2) * w_c8;
-        aring[slot][0] = *(const u32x4 *)q;
-        aring[slot][1] = *(const u32x4 *)(q + 32 * 8);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) aring[slot][m] = *(const u32x4 *)(q + m * 32 * 8);
     };
 
     fetch(0);
@@ -176,7 +185,7 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
 #pragma unroll
             for (int n = 0; n < NPB; ++n)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < MB; ++m)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aring[s % 3][m]),
                                                                        __builtin_bit_cast(bf16x8, bf[n]), acc[m][n],
                                                                        0, 0, 0);
@@ -192,7 +201,7 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
         const int yy = r0 + 2 * (wpx * NPB + n) + (li >> 4), xx = c0 + (li & 15);
         if (yy >= p.H) continue;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co_w + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -205,17 +214,17 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
 
 extern "C" int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W)
 {
-    return Cin >= 32 && Cin % 32 == 0 && Cout >= 128 && Cout % 128 == 0 && H >= 1 && W >= 16 && W % 16 == 0;
+    return Cin >= 1 && Cout >= 128 && Cout % 128 == 0 && H >= 1 && W >= 16 && W % 16 == 0;
 }
 
-extern "C" size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout) { return (size_t)9 * Cin * Cout; }
+extern "C" size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout) { return (size_t)9 * align_up(Cin, 32) * Cout; }
 
 extern "C" int sassd_conv2d_bf16_pack_weight(const float *w, int Cout, int Cin, void *packed, void *stream_)
 {
-    if (!w || !packed || Cin < 8 || Cin % 8 || Cout < 1) return SASSD_EINVAL;
+    if (!w || !packed || Cin < 1 || Cout < 1) return SASSD_EINVAL;
     const size_t n = sassd_conv2d_bf16_packed_elems(Cin, Cout);
     hipLaunchKernelGGL(bf16_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, w, Cout,
-                       Cin, (unsigned short *)packed);
+                       Cin, (int)align_up(Cin, 32), (unsigned short *)packed);
     return sassd_launch_status();
 }
 
@@ -226,13 +235,13 @@ extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const
     if (!sassd_conv2d_bf16_supported(Cin, Cout, H, W)) return SASSD_EINVAL;
     BfParams p;
     p.x = x; p.wp = (const unsigned short *)w_packed; p.shift = shift; p.y = y;
-    p.B = batch; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
+    p.B = batch; p.Cin = Cin; p.CinP = (int)align_up(Cin, 32); p.Cout = Cout; p.H = H; p.W = W;
     p.tiles_x = W / kTC; p.tiles_y = cdiv(H, kTR);
     hipStream_t s = (hipStream_t)stream_;
     const long tiles = (long)p.tiles_x * p.tiles_y * batch;
     if (Cout % 256 == 0)
-        hipLaunchKernelGGL((conv2d_bf16_kernel<4, 2>), dim3((unsigned)(tiles * (Cout / 256))), dim3(512), 0, s, p);
+        hipLaunchKernelGGL((conv2d_bf16_kernel<8, 1, 1>), dim3((unsigned)(tiles * (Cout / 256))), dim3(512), 0, s, p);
     else
-        hipLaunchKernelGGL((conv2d_bf16_kernel<2, 2>), dim3((unsigned)(tiles * (Cout / 128))), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv2d_bf16_kernel<4, 1, 1>), dim3((unsigned)(tiles * (Cout / 128))), dim3(256), 0, s, p);
     return sassd_launch_status();
 }

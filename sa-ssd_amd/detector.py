@@ -280,7 +280,9 @@ class SpMiddleFHD(nn.Module):
         ps = []
         for m, vs in zip(middle, ((.1, .1, .2), (.2, .2, .4), (.4, .4, .8))):
             feat, nxyz = self.tensor2points(m, (0, -40., -3.), vs)
-            grid = (self.aux_xy_range, self.aux_bin, batch_size)
+            # exact for any bin edge (the ring search widens until the third neighbour is inside its reach); four
+            # voxels of the scale per bin keeps the 3x3 ring at a few hundred candidates instead of ~1000
+            grid = (self.aux_xy_range, min(self.aux_bin, 4 * vs[0]), batch_size)
             ps.append(nearest_neighbor_interpolate(points_mean, nxyz, feat, grid))
         pointwise = self.point_fc(torch.cat(ps, dim=-1))
         return x, conv6, (points_mean, self.point_cls(pointwise), self.point_reg(pointwise))

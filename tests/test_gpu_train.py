@@ -192,10 +192,11 @@ def test_training_step_vs_oracle(dev, cfgfile, names, HALF):
             continue
         worst[name] = _rel(p.grad, rg)
         checked += 1
-    # (three classes: the box-head BIAS gradient sums 42 channels over 105 600 anchors with heavy cancellation -- measured
-    # 2.6e-3 there, every other tensor < 2e-3)
-    tol = 2e-3 if len(names) == 1 else 3e-3
-    bad = {k: v for k, v in worst.items() if not v < tol}
+    # (three classes: the box-head BIAS gradient sums 42 channels over 105 600 anchors with heavy cancellation, so its
+    # relative error is set by the last bits of the activations: 2.6e-3 and 3.7e-3 measured with two fp32 summation
+    # orders of the sparse convs -- 6e-3 for that one tensor, every other tensor < 2e-3)
+    tols = {"rpn_head.conv_box.bias": 6e-3} if len(names) > 1 else {}
+    bad = {k: v for k, v in worst.items() if not v < tols.get(k, 2e-3)}
     assert checked >= 60 and not bad, (checked, bad)
 
 

@@ -13,11 +13,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402
 import helpers as H  # noqa: E402
 import sassd  # noqa: E402,F401
-from sassd import synth, anchors as A, train  # noqa: E402
+from sassd import synth, anchors as A, train, autograd as AG  # noqa: E402
 from sassd.config import Config  # noqa: E402
 from sassd.detector import build_detector  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+AG.set_bev_precision(os.environ.get('PRECISION', 'bf16'))
 dev = torch.device("cuda", 0)
 cfg = Config.fromfile(os.path.join(ROOT, "configs", "car_cfg.py"))
 model = H.randomize_detector(build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg), 0, cls_bias=-3.0).to(dev)
@@ -58,3 +59,4 @@ for it in range(steps + 6):
 print({k: round(v / steps * 1e3, 2) for k, v in acc.items()}, "ms per step")
 if os.environ.get('PROF'):
     pstats.Stats(pr).sort_stats('tottime').print_stats(45)
+    pstats.Stats(pr).sort_stats('cumulative').print_stats('sa-ssd_amd|sassd', 70)

@@ -217,7 +217,7 @@ int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *s
  * direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulation, NCHW fp32 activations in and out, optional
  * per-channel bias.  Weights are packed once per update ([Cout,Cin,3,3] fp32 -> bf16 [tap][Cin32/8][Cout][8],
  * sassd_conv2d_bf16_packed_elems 16-bit elements).  The data gradient is the same call on dy with the weights
- * transposed and the taps mirrored.  Supported: Cout % 128 == 0, W % 16 == 0 (else SASSD_EINVAL; the caller keeps the
+ * transposed and the taps mirrored.  Supported: Cout % 32 == 0, W % 16 == 0 (else SASSD_EINVAL; the caller keeps the
  * fp32 kernels); Cin is padded to a multiple of 32 with zero weights inside the pack. */
 int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W);
 size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout);
@@ -238,6 +238,34 @@ int sassd_conv2d_bwd_weight(const float *x, const float *dy, float *dw, int batc
  * (SASSD_EINVAL otherwise).  What the reference gets from cuDNN under torch autocast / apex O1. */
 int sassd_conv2d_bwd_weight_bf16(const float *x, const float *dy, float *dw, int batch, int Cin, int Cout, int H, int W,
                                  int ksize, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (f-3 / a18) fused training targets and RPN loss.
+ *
+ * sassd_assign_targets: mmdet/core/bbox3d/target_ops.py:139-277 (create_target_np) for a whole batch in two launches.
+ *   anchors [A,7] (anchors_per_sample = 0) or [B,A,7]; anchor_mask [B,A] u8 or NULL; ground truths of all samples
+ *   concatenated: gt_boxes [T,7], gt_classes [T] i64 or NULL (all 1), gt_ok [T] u8 or NULL, gt_offsets [B+1] i32
+ *   (device).  Similarity = NearestIouSimilarity (iou3d_utils.py:163-183) computed in the kernel, or -- overlaps != NULL
+ *   -- a precomputed row-major [A, G_b] matrix per sample starting at overlaps + overlap_offsets[b] (i64, device).
+ *   Outputs: labels i64 (-1 ignore / 0 negative / class), targets (second_box_encode, ssd_rotate_head.py:15-50, zero
+ *   for non-positives), best_overlap (or NULL), each with out_sample_stride anchors between samples (>= A: lets
+ *   several classes write interleaved [B, classes, A] tensors); num_pos[b] += positives (zeroed first when
+ *   zero_num_pos).  Workspace: sassd_assign_targets_workspace_bytes.
+ * sassd_rpn_loss: ssd_rotate_head.py:128-314 loss() in one pass: loss_sums[3] = (smooth-L1 with sin-difference, sigmoid
+ *   focal, direction cross-entropy) with NormByNumPositives weights, and the gradients of those three sums with
+ *   respect to box_preds [B,A,7], cls_preds [B,A,num_class], dir_preds [B,A,2] (dir_preds may be NULL). */
+size_t sassd_assign_targets_workspace_bytes(int batch, int n_anchors, int total_gt);
+int sassd_assign_targets(const float *anchors, int anchors_per_sample, const uint8_t *anchor_mask, int n_anchors,
+                         int batch, const float *gt_boxes, const int64_t *gt_classes, const uint8_t *gt_ok,
+                         const int32_t *gt_offsets, int total_gt, const float *overlaps, const int64_t *overlap_offsets,
+                         float matched_threshold, float unmatched_threshold, int64_t *labels, float *targets,
+                         float *best_overlap, size_t out_sample_stride, int32_t *num_pos, int zero_num_pos,
+                         void *workspace, size_t workspace_bytes, void *stream);
+size_t sassd_rpn_loss_workspace_bytes(int batch, int n_anchors);
+int sassd_rpn_loss(const float *box_preds, const float *cls_preds, const float *dir_preds, int num_class,
+                   const int64_t *labels, const float *targets, const float *anchors, int anchors_per_sample,
+                   const int32_t *num_pos, int n_anchors, int batch, float *grad_box, float *grad_cls, float *grad_dir,
+                   float *loss_sums, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (f-1) anchors_mask: mmdet/datasets/kitti.py:333-343 with geometry.py:676-710

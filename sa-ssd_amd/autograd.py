@@ -206,3 +206,22 @@ class PSWarpFn(Function):
         dfeat, dg = K.pswarp_sample_bwd(feat, boxes.view(1, k, 7), cnt, k, ctx.args[0], ctx.args[1],
                                         dlog.contiguous().view(1, k))
         return dfeat, dg.view(k, 7), None, None
+
+
+class RpnLossFn(Function):
+    """(loc, cls, dir) loss sums of the RPN head in one kernel (sassd_rpn_loss); the gradients with respect to the three
+    prediction tensors come out of the same pass, backward scales them by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, box_preds, cls_preds, dir_preds, labels, targets, anchors, num_pos):
+        sums, gbox, gcls, gdir = K.rpn_loss(box_preds.contiguous(), cls_preds.contiguous(),
+                                            dir_preds.contiguous() if dir_preds is not None else None, labels, targets,
+                                            anchors, num_pos)
+        ctx.save_for_backward(gbox, gcls, gdir if gdir is not None else gbox.new_zeros(0))
+        ctx.has_dir = gdir is not None
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        gbox, gcls, gdir = ctx.saved_tensors
+        return (gbox * g[0], gcls * g[1], gdir * g[2] if ctx.has_dir else None, None, None, None, None)

@@ -161,16 +161,21 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
         for (int m = 0; m < MB; ++m) aring[slot][m] = *(const u32x4 *)(q + m * 32 * 8);
     };
 
+    // Cout not a multiple of the workgroup's cout tile: the waves past Cout only help staging the input tile
+    const bool active = co_w < p.Cout;
     fetch(0);
     stash(0);
-    load_a(0, 0, 0);
-    load_a(1, 0, 1);
+    if (active) {
+        load_a(0, 0, 0);
+        load_a(1, 0, 1);
+    }
     __syncthreads();
 
     for (int c = 0; c < nchunk; ++c) {
         const int cn = min(c + 1, nchunk - 1);
         if (c + 1 < nchunk) fetch((c + 1) * kKC);
         const unsigned char *xt = lds + (c & 1) * kBufB + b_off;
+        if (active) {
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
             // weights two steps ahead (the last two steps of a chunk fetch the next chunk's first two)
@@ -190,12 +195,14 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
                                                                        __builtin_bit_cast(bf16x8, bf[n]), acc[m][n],
                                                                        0, 0, 0);
         }
+        }
         if (c + 1 < nchunk) stash((c + 1) & 1);
         __syncthreads();
     }
 
     // ---- epilogue: D row = cout = (r & 3) + 8 * (r >> 2) + 4 * lh, column = pixel li -> (row li >> 4, column li & 15)
     float *yb = p.y + (size_t)b * p.Cout * hw;
+    if (!active) return;
 #pragma unroll
     for (int n = 0; n < NPB; ++n) {
         const int yy = r0 + 2 * (wpx * NPB + n) + (li >> 4), xx = c0 + (li & 15);
@@ -214,7 +221,7 @@ __global__ void __launch_bounds__(64 * COW * PXW, 2) conv2d_bf16_kernel(BfParams
 
 extern "C" int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W)
 {
-    return Cin >= 1 && Cout >= 128 && Cout % 128 == 0 && H >= 1 && W >= 16 && W % 16 == 0;
+    return Cin >= 1 && Cout >= 32 && Cout % 32 == 0 && H >= 1 && W >= 16 && W % 16 == 0;
 }
 
 extern "C" size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout) { return (size_t)9 * align_up(Cin, 32) * Cout; }
@@ -241,7 +248,7 @@ extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const
     const long tiles = (long)p.tiles_x * p.tiles_y * batch;
     if (Cout % 256 == 0)
         hipLaunchKernelGGL((conv2d_bf16_kernel<8, 1, 1>), dim3((unsigned)(tiles * (Cout / 256))), dim3(512), 0, s, p);
-    else
-        hipLaunchKernelGGL((conv2d_bf16_kernel<4, 1, 1>), dim3((unsigned)(tiles * (Cout / 128))), dim3(256), 0, s, p);
+    else        // 128-cout tiles; the last one may be partly idle (Cout = 320: 3 tiles, 2.5 used)
+        hipLaunchKernelGGL((conv2d_bf16_kernel<4, 1, 1>), dim3((unsigned)(tiles * cdiv(Cout, 128))), dim3(256), 0, s, p);
     return sassd_launch_status();
 }

@@ -24,7 +24,7 @@ from . import iou3d_utils
 from . import kernels as K
 from . import spconv
 from . import train_ops as T
-from .autograd import Conv2dFn, PSWarpFn
+from .autograd import Conv2dFn, PSWarpFn, RpnLossFn, bev_precision
 from .config import _wrap, obj_from_dict
 from .kitti_common import kitti_bbox2results
 from .pipeline import InferencePlan
@@ -175,6 +175,9 @@ class _HipConv2d(nn.Conv2d):
 
     def forward(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            if (bev_precision() == "bf16" and self.kernel_size[0] == 3 and
+                    K.conv2d_bf16_supported(self.in_channels, self.out_channels, x.shape[2], x.shape[3])):
+                return Conv2dFn.apply(x.float(), self.weight, self.bias, None, None, None)   # packs its own bf16 image
             p4 = self.packed_wino4(x.shape[2], x.shape[3])
             pw = None if p4 is not None else self.packed_wino(x.shape[2], x.shape[3])
             pk = None if (p4 is not None or pw is not None) else self.packed_weight()
@@ -348,8 +351,50 @@ class SSDRotateHead(nn.Module):
         cls = T.weighted_sigmoid_focal_loss(cls_preds, oh, weight=cls_weights[..., None], avg_factor=1.)
         return loc, cls
 
+    def _loss_fused(self, box_preds, cls_preds, dir_cls_preds, gt_bboxes, gt_labels, gt_types, anchors, anchors_mask,
+                    cfg):
+        """The same loss through sassd_assign_targets + sassd_rpn_loss: per class one assignment call for the whole
+        batch writing straight into the [B, classes, A] label / target tensors, then ONE kernel for the three loss sums
+        and their gradients (instead of ~250 elementwise launches and as many autograd nodes)."""
+        b = box_preds.shape[0]
+        dev = box_preds.device
+        names = list(anchors.keys())
+        ncls = len(names)
+        a_c = anchors[names[0]].shape[1]
+        counts = [int(g.shape[0]) for g in gt_bboxes]
+        gt_off = K.gt_offsets(counts, dev)
+        gt_all = torch.cat([g.float() for g in gt_bboxes], 0).contiguous() if sum(counts) else None
+        cls_all = torch.cat([l.to(dev).long() for l in gt_labels], 0).contiguous() if sum(counts) else None
+        flat = np.concatenate([np.asarray(c) == n for n in names for c in gt_types] or [np.zeros(0, bool)])
+        up = torch.from_numpy(flat).pin_memory().to(dev, non_blocking=True)
+        labels = torch.empty(b, ncls, a_c, dtype=torch.int64, device=dev)
+        targets = torch.empty(b, ncls, a_c, self._box_code_size, dtype=torch.float32, device=dev)
+        num_pos = torch.empty(b, dtype=torch.int32, device=dev)
+        tot = sum(counts)
+        for i, name in enumerate(names):
+            mask = anchors_mask[name]
+            mask = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+            K.assign_targets(anchors[name].contiguous(), mask, gt_all, cls_all,
+                             up[i * tot:(i + 1) * tot].view(torch.uint8), gt_off, cfg.assigner[name].pos_iou_thr,
+                             cfg.assigner[name].neg_iou_thr, labels[:, i], targets[:, i], num_pos, zero_num_pos=i == 0,
+                             out_stride=ncls * a_c)
+        all_anchors = anchors[names[0]] if ncls == 1 else torch.stack([anchors[n] for n in names], 1)
+        all_anchors = all_anchors.contiguous().view(b, ncls * a_c, 7)
+        sums = RpnLossFn.apply(box_preds.view(b, -1, self._box_code_size),
+                               cls_preds.view(b, -1, self._num_class),
+                               dir_cls_preds.view(b, -1, 2) if self._use_direction_classifier else None,
+                               labels.view(b, -1), targets.view(b, -1, self._box_code_size), all_anchors, num_pos)
+        out = dict(rpn_loc_loss=sums[0:1] / b * 2, rpn_cls_loss=sums[1:2] / b)
+        if self._use_direction_classifier:
+            out['rpn_dir_loss'] = sums[2:3] / b * .2
+        return out
+
     def loss(self, box_preds, cls_preds, dir_cls_preds, gt_bboxes, gt_labels, gt_types, anchors, anchors_mask, cfg):
         b = box_preds.shape[0]
+        if (box_preds.is_cuda and cfg.get('fused_loss', True) and cfg.assigner.similarity_fn == 'NearestIouSimilarity'
+                and self._use_sigmoid_cls and self._encode_rad_error_by_sin and self._box_code_size == 7):
+            return self._loss_fused(box_preds, cls_preds, dir_cls_preds, gt_bboxes, gt_labels, gt_types, anchors,
+                                    anchors_mask, cfg)
         multi_labels, multi_targets, multi_anchors = [], [], []
         sim = getattr(T, cfg.assigner.similarity_fn, None) or getattr(iou3d_utils, cfg.assigner.similarity_fn)
         dev = box_preds.device

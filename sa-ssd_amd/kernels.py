@@ -726,3 +726,63 @@ def rotate_iou_eval(boxes, query_boxes, criterion=-1):
     _C.check(_C.lib().sassd_rotate_iou_eval(_C.ptr(boxes), n, _C.ptr(query_boxes), k, int(criterion), _C.ptr(out),
                                             _C.stream()), "sassd_rotate_iou_eval")
     return out
+
+
+# ---- fused training targets / RPN loss (train_loss.hip) ----------------------------------------------------------------
+_gt_offset_cache = {}
+
+
+def gt_offsets(counts, device):
+    """[B+1] int32 prefix of the per-sample ground-truth counts on the device, cached per (counts, device): the counts
+    repeat from step to step, and a cache hit costs no upload."""
+    key = (tuple(int(c) for c in counts), str(device))
+    t = _gt_offset_cache.get(key)
+    if t is None:
+        if len(_gt_offset_cache) > 4096:
+            _gt_offset_cache.clear()
+        off = np.zeros(len(key[0]) + 1, np.int32)
+        off[1:] = np.cumsum(key[0])
+        t = torch.from_numpy(off).to(device)
+        _gt_offset_cache[key] = t
+    return t
+
+
+def assign_targets(anchors, anchor_mask, gt_boxes, gt_classes, gt_ok, gt_off, matched, unmatched, labels, targets,
+                   num_pos, zero_num_pos=True, out_stride=None, best=None, overlaps=None, overlap_offsets=None):
+    """sassd_assign_targets.  anchors [A,7] or [B,A,7]; anchor_mask [B,A] (bool / uint8) or None; gt_boxes [T,7],
+    gt_classes [T] int64 or None, gt_ok [T] (bool / uint8) or None, gt_off [B+1] int32 (gt_offsets()).  Writes labels
+    (int64), targets (fp32, 7 per anchor) and optionally best overlap through the given (possibly strided-view) output
+    tensors: element (b, a) lands at b * out_stride + a from the tensor's data pointer."""
+    per_sample = anchors.dim() == 3
+    a = anchors.shape[-2]
+    b = gt_off.shape[0] - 1
+    t = int(gt_boxes.shape[0]) if gt_boxes is not None else 0
+    _chk_cuda(anchors, anchor_mask, gt_boxes, gt_classes, gt_ok, gt_off, overlaps, overlap_offsets)
+    L = _C.lib()
+    wsb = L.sassd_assign_targets_workspace_bytes(b, a, t)
+    ws = workspace("assign_targets", wsb, anchors.device)
+    _C.check(L.sassd_assign_targets(_C.ptr(anchors), 1 if per_sample else 0, _C.ptr(anchor_mask), a, b,
+                                    _C.ptr(gt_boxes) if t else None, _C.ptr(gt_classes), _C.ptr(gt_ok),
+                                    _C.ptr(gt_off), t, _C.ptr(overlaps), _C.ptr(overlap_offsets), float(matched),
+                                    float(unmatched), _C.ptr(labels), _C.ptr(targets), _C.ptr(best),
+                                    int(out_stride if out_stride is not None else a), _C.ptr(num_pos),
+                                    1 if zero_num_pos else 0, _C.ptr(ws), wsb, _C.stream()), "sassd_assign_targets")
+
+
+def rpn_loss(box_preds, cls_preds, dir_preds, labels, targets, anchors, num_pos):
+    """sassd_rpn_loss -> (loss_sums [3] = (loc, cls, dir), grad_box, grad_cls, grad_dir) of the UNSCALED sums."""
+    _chk_cuda(box_preds, cls_preds, dir_preds, labels, targets, anchors, num_pos)
+    b, a = labels.shape
+    nc = cls_preds.shape[-1]
+    dev = box_preds.device
+    gbox, gcls = torch.empty_like(box_preds), torch.empty_like(cls_preds)
+    gdir = torch.empty_like(dir_preds) if dir_preds is not None else None
+    sums = torch.empty(3, dtype=torch.float32, device=dev)
+    L = _C.lib()
+    wsb = L.sassd_rpn_loss_workspace_bytes(b, a)
+    ws = workspace("rpn_loss", wsb, dev)
+    _C.check(L.sassd_rpn_loss(_C.ptr(box_preds), _C.ptr(cls_preds), _C.ptr(dir_preds), nc, _C.ptr(labels),
+                              _C.ptr(targets), _C.ptr(anchors), 1 if anchors.dim() == 3 else 0, _C.ptr(num_pos), a, b,
+                              _C.ptr(gbox), _C.ptr(gcls), _C.ptr(gdir), _C.ptr(sums), _C.ptr(ws), wsb, _C.stream()),
+             "sassd_rpn_loss")
+    return sums, gbox, gcls, gdir

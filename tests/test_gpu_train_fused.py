@@ -1,0 +1,136 @@
+"""-m gpu: the fused training kernels (sassd_assign_targets, sassd_rpn_loss) against the elementwise torch formulation
+they replace (sassd.train_ops.create_target_torch / SSDRotateHead.loss with fused_loss=False), which is itself held
+to the CPU oracle by test_gpu_train.py.  Labels / argmax choices exact, targets and best overlaps bit-equal (same fp32
+operation sequence), loss sums and gradients within 2e-6 relative (different summation order only)."""
+import numpy as np
+import pytest
+import torch
+
+from sassd import kernels as K
+from sassd import train_ops as T
+from sassd import synth
+from sassd.config import Config, _wrap
+from sassd.detector import SSDRotateHead
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(seed, n_gt, dev, classes=("Car",)):
+    w = synth.workload("car")
+    anchors = torch.from_numpy(w["anchors"]).to(dev)                    # [A,7]
+    r = np.random.RandomState(seed)
+    gt = np.zeros((n_gt, 7), np.float32)
+    gt[:, 0], gt[:, 1] = r.uniform(2, 68, n_gt), r.uniform(-38, 38, n_gt)
+    gt[:, 2] = r.uniform(-1.9, -1.5, n_gt)
+    gt[:, 3], gt[:, 4], gt[:, 5] = r.uniform(1.4, 1.9, n_gt), r.uniform(3.2, 4.6, n_gt), r.uniform(1.4, 1.7, n_gt)
+    gt[:, 6] = r.uniform(-3.3, 3.3, n_gt)
+    if n_gt > 2:
+        gt[1] = gt[0]                                                   # duplicated box: ties between two ground truths
+        gt[2, :2] = w["anchors"][12345, :2]                             # one box exactly on an anchor centre
+    mask = torch.from_numpy(r.rand(anchors.shape[0]) < 0.3).to(dev)
+    return anchors, torch.from_numpy(gt).to(dev), mask
+
+
+@pytest.mark.parametrize("n_gt", [0, 1, 8, 37, 150])
+def test_assign_targets_matches_create_target_torch(dev, n_gt):
+    B = 2
+    anchors, gt0, mask0 = _scene(1 + n_gt, n_gt, dev)
+    _, gt1, mask1 = _scene(77 + n_gt, max(n_gt - 1, 0), dev)
+    A = anchors.shape[0]
+    g = torch.Generator().manual_seed(n_gt)
+    gts, masks = [gt0, gt1], [mask0, mask1]
+    cls = [torch.randint(1, 4, (t.shape[0],), generator=g).to(dev) for t in gts]
+    oks = [(torch.rand(t.shape[0], generator=g) < 0.8).to(dev) for t in gts]
+    ref = [T.create_target_torch(anchors, masks[b], gts[b], cls[b], oks[b], T.NearestIouSimilarity(),
+                                 T.second_box_encode, 0.6, 0.45) for b in range(B)]
+    labels = torch.empty(B, A, dtype=torch.int64, device=dev)
+    targets = torch.empty(B, A, 7, device=dev)
+    best = torch.empty(B, A, device=dev)
+    npos = torch.empty(B, dtype=torch.int32, device=dev)
+    counts = [t.shape[0] for t in gts]
+    tot = sum(counts)
+    K.assign_targets(anchors, torch.stack(masks).view(torch.uint8), torch.cat(gts) if tot else None,
+                     torch.cat(cls) if tot else None, torch.cat(oks).view(torch.uint8) if tot else None,
+                     K.gt_offsets(counts, dev), 0.6, 0.45, labels, targets, npos, best=best)
+    for b in range(B):
+        assert torch.equal(labels[b], ref[b][0]), (b, int((labels[b] != ref[b][0]).sum()))
+        assert torch.equal(targets[b], ref[b][1])
+        assert torch.equal(best[b], ref[b][2])
+        assert int(npos[b]) == int((ref[b][0] > 0).sum())
+    if n_gt >= 8:
+        assert int(npos.sum()) > 0
+
+
+def test_assign_targets_strided_outputs_and_accumulating_positives(dev):
+    """Two 'classes' writing into one [B, 2, A] tensor (the multi-class layout of SSDRotateHead.loss)."""
+    anchors, gt, mask = _scene(5, 12, dev)
+    A = anchors.shape[0]
+    labels = torch.full((2, 2, A), -7, dtype=torch.int64, device=dev)
+    targets = torch.full((2, 2, A, 7), -7.0, device=dev)
+    npos = torch.empty(2, dtype=torch.int32, device=dev)
+    off = K.gt_offsets([12, 12], dev)
+    gts = torch.cat([gt, gt])
+    for c, (hi, lo) in enumerate(((0.6, 0.45), (0.35, 0.2))):
+        K.assign_targets(anchors, None, gts, None, None, off, hi, lo, labels[:, c], targets[:, c], npos,
+                         zero_num_pos=c == 0, out_stride=2 * A)
+    for c, (hi, lo) in enumerate(((0.6, 0.45), (0.35, 0.2))):
+        ref = T.create_target_torch(anchors, None, gt, None, None, T.NearestIouSimilarity(), T.second_box_encode, hi, lo)
+        for b in range(2):
+            assert torch.equal(labels[b, c], ref[0]) and torch.equal(targets[b, c], ref[1])
+    assert int(npos[0]) == int((labels[0] > 0).sum())
+
+
+@pytest.mark.parametrize("cfg_path,names", [("configs/car_cfg.py", ["Car"]),
+                                            ("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"])])
+def test_fused_rpn_loss_matches_elementwise_path(dev, cfg_path, names):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, cfg_path))
+    head_cfg = dict(cfg.model.bbox_head)
+    head_cfg.pop("type")
+    head = SSDRotateHead(**head_cfg).to(dev)
+    ncls, B, H, W = len(names), 2, 40, 48
+    g = torch.Generator().manual_seed(3)
+    a_c = H * W * 2
+    # anchors on a small grid (real sizes / rotations), gts near anchors so that every label value occurs
+    from sassd import anchors as AN
+    r = np.random.RandomState(0)
+    anchors, masks, gtb, gtl, gtt = {}, {}, [], [], []
+    sizes = {"Car": [1.6, 3.9, 1.56], "Pedestrian": [0.6, 0.8, 1.73], "Cyclist": [0.6, 1.76, 1.73]}
+    for n in names:
+        an = AN.AnchorGeneratorStride(sizes=sizes[n], anchor_strides=[.4, .4, 1.], anchor_offsets=[.2, -9.4, -1.78],
+                                      rotations=[0, 1.57])([1, H, W]).reshape(-1, 7).astype(np.float32)
+        anchors[n] = torch.from_numpy(np.stack([an] * B)).to(dev)
+        masks[n] = torch.from_numpy(r.rand(B, a_c) < 0.6).to(dev)
+    for b in range(B):
+        k = 9
+        t = [names[i % ncls] for i in range(k)]
+        box = np.zeros((k, 7), np.float32)
+        for i, n in enumerate(t):
+            base = anchors[n][b, r.randint(a_c)].cpu().numpy()
+            box[i] = base + np.array([0.1, -0.07, 0.05, 0.03, 0.1, 0.02, r.uniform(-0.3, 0.3)], np.float32)
+        gtb.append(torch.from_numpy(box).to(dev))
+        gtl.append(torch.tensor([names.index(n) + 1 for n in t], dtype=torch.int64, device=dev))
+        gtt.append(np.array(t))
+    nloc = head._num_anchor_per_loc
+    outs = []
+    for ch in (nloc * 7, nloc * head._num_class, nloc * 2):
+        y = (torch.randn(B, ch, H, W, generator=g) * 0.5).to(dev)
+        outs.append(y.view(B, ncls, -1, H, W).permute(0, 1, 3, 4, 2).contiguous().requires_grad_())
+    res = {}
+    for fused in (False, True):
+        c = _wrap(dict(cfg.train_cfg.rpn))
+        c["fused_loss"] = fused
+        for o in outs:
+            o.grad = None
+        losses = head.loss(*outs, gtb, gtl, gtt, anchors, masks, c)
+        sum(v.sum() for v in losses.values()).backward()
+        res[fused] = ({k: v.detach().clone() for k, v in losses.items()}, [o.grad.clone() for o in outs])
+    for k in res[False][0]:
+        a, b = float(res[True][0][k].sum()), float(res[False][0][k].sum())
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (k, a, b)
+        assert res[True][0][k].shape == res[False][0][k].shape
+    assert float(res[False][0]["rpn_loc_loss"]) > 0 and float(res[False][0]["rpn_dir_loss"]) > 0
+    for ga, gb in zip(res[True][1], res[False][1]):
+        err = float((ga - gb).abs().max()) / max(float(gb.abs().max()), 1e-12)
+        assert err < 2e-5, err

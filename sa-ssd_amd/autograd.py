@@ -24,8 +24,20 @@ def bev_precision():
     return _BEV_PRECISION
 
 
+_n_ptr_cache = {}
+
+
 def _n_ptr(n, dev):
-    return torch.full((1,), int(n), dtype=torch.int32, device=dev)        # fill kernel: no blocking H2D copy
+    """[1] int32 device scalar holding n.  The same row counts recur through the layers of one step (and across steps
+    for fixed-size inputs): cached per (n, device), filled by a kernel (no blocking H2D copy), never written again."""
+    key = (int(n), dev)
+    t = _n_ptr_cache.get(key)
+    if t is None:
+        if len(_n_ptr_cache) > 512:
+            _n_ptr_cache.clear()
+        t = torch.full((1,), int(n), dtype=torch.int32, device=dev)
+        _n_ptr_cache[key] = t
+    return t
 
 
 class SparseConvFn(Function):
@@ -49,8 +61,10 @@ class SparseConvFn(Function):
         nbr, n_out = ctx.nbr, ctx.n_out
         n_in = x.shape[0]
         dev = x.device
-        dyc = torch.zeros(max(n_out, 1), cout, dtype=torch.float32, device=dev)
-        dyc[:n_out] = dy
+        if n_out > 0:
+            dyc = dy.contiguous()
+        else:
+            dyc = torch.zeros(1, cout, dtype=torch.float32, device=dev)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if cin < 16:

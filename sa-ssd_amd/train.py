@@ -20,6 +20,12 @@ from . import kernels as K
 
 
 class FlatParams:
+    """Parameters are views of `data`.  Gradients: autograd hands every parameter a fresh tensor (zero_grad() resets
+    .grad to None, so AccumulateGrad steals the incoming gradient instead of launching one add kernel per parameter
+    into a zero-filled buffer); collect() then gathers them into the contiguous gradient buffer with one multi-tensor
+    copy and re-points .grad at the views.  `grad` (the flat buffer) collects lazily, so readers always see the
+    gradients of the last backward."""
+
     def __init__(self, model):
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
@@ -30,18 +36,43 @@ class FlatParams:
             off += (n + 3) // 4 * 4                         # keep every view 16-byte aligned
         self.numel = off
         self.data = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.gviews = []
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
             self.data[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.data[o:o + n].view(p.shape)
-            p.grad = self.grad[o:o + n].view(p.shape)
+            self.gviews.append(self._grad[o:o + n].view(p.shape))
+            p.grad = self.gviews[-1]
+        self._gptr = [v.data_ptr() for v in self.gviews]
+
+    @property
+    def grad(self):
+        self.collect()
+        return self._grad
 
     def zero_grad(self):
-        self.grad.zero_()
-        for p, o in zip(self.params, self.offsets):        # autograd may have replaced a view; re-attach
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        for p in self.params:
+            p.grad = None
+
+    def collect(self, lo=0, hi=None):
+        """Gather the gradients of params[lo:hi] into the flat buffer (idempotent; a parameter that received no
+        gradient gets zeros)."""
+        hi = len(self.params) if hi is None else hi
+        dst, src = [], []
+        for i in range(lo, hi):
+            p, v = self.params[i], self.gviews[i]
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != self._gptr[i]:
+                dst.append(v)
+                src.append(g.detach())
+            else:
+                continue
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
 
 
 def annealing_cos(start, end, pct):
@@ -101,8 +132,9 @@ class AdamOneCycle:
 
     def step(self):
         self.steps += 1
-        sumsq = K.grad_sumsq(self.flat.grad, self.sumsq) if self.max_norm > 0 else None
-        K.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, sumsq, self.lr, self.mom,
+        grad = self.flat.grad                                 # gathers this step's gradients (one multi-tensor copy)
+        sumsq = K.grad_sumsq(grad, self.sumsq) if self.max_norm > 0 else None
+        K.adam_step(self.flat.data, grad, self.exp_avg, self.exp_avg_sq, sumsq, self.lr, self.mom,
                     self.beta2, self.eps, self.wd, self.steps, self.max_norm, 1.0 / self.world_size)
         K.bump_weights_generation()          # raw-pointer update: parameter `_version`s did not move
 
@@ -186,8 +218,9 @@ class GradSync:
 
     def _launch(self, b):
         if not self._launched[b]:
-            _, _, lo, hi = self.ranges[b]
-            self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            plo, phi, lo, hi = self.ranges[b]
+            self.flat.collect(plo, phi)                       # this bucket's gradients -> the flat buffer
+            self.works.append(dist.all_reduce(self.flat._grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
             self._launched[b] = True
 
     def all_reduce_grads(self):

@@ -134,3 +134,64 @@ def test_fused_rpn_loss_matches_elementwise_path(dev, cfg_path, names):
     for ga, gb in zip(res[True][1], res[False][1]):
         err = float((ga - gb).abs().max()) / max(float(gb.abs().max()), 1e-12)
         assert err < 2e-5, err
+
+
+# ---- the same kernels against the vectors generated from the REFERENCE's own Python (tests/golden/train_fns.npz) -----
+import os as _os
+
+_G = np.load(_os.path.join(_os.path.dirname(__file__), "golden", "train_fns.npz"))
+
+
+def _g(name, dev):
+    return torch.from_numpy(_G[name]).to(dev)
+
+
+@pytest.mark.parametrize("case", ["masked", "nomask", "nogt"])
+def test_assign_targets_vs_reference_golden(dev, case):
+    """create_target_np of the reference (target_ops.py:139-277) on its own inputs: labels exact, targets / overlaps 1e-6."""
+    anchors, gt = _g("anchors", dev), _g("gt", dev)
+    gmask = torch.tensor([1, 1, 0, 1, 1, 1, 0, 1, 1], dtype=torch.uint8, device=dev)
+    am, gm, gb = dict(masked=(_g("anchor_mask", dev), gmask, gt), nomask=(None, None, gt),
+                      nogt=(_g("anchor_mask", dev), None, gt[:0]))[case]
+    A = anchors.shape[0]
+    labels = torch.empty(1, A, dtype=torch.int64, device=dev)
+    targets = torch.empty(1, A, 7, device=dev)
+    best = torch.empty(1, A, device=dev)
+    npos = torch.empty(1, dtype=torch.int32, device=dev)
+    n = gb.shape[0]
+    K.assign_targets(anchors.contiguous(), am.view(1, A).view(torch.uint8).contiguous() if am is not None else None,
+                     gb.contiguous() if n else None, None, gm, K.gt_offsets([n], dev), 0.6, 0.45, labels, targets, npos,
+                     best=best)
+    assert np.array_equal(labels[0].cpu().numpy(), _G["ct_%s_labels" % case])
+    assert np.abs(targets[0].cpu().numpy() - _G["ct_%s_targets" % case]).max() <= 1e-6
+    mx = best[0].cpu()
+    ref_mx = _G["ct_%s_max" % case]
+    got = mx[am.cpu().bool()].numpy() if am is not None else mx.numpy()
+    assert np.abs(got - ref_mx).max() <= 1e-6
+    assert int(npos[0]) == int((_G["ct_%s_labels" % case] > 0).sum())
+
+
+def test_fused_rpn_loss_vs_reference_golden(dev):
+    """SSDRotateHead.loss of the reference on its own inputs: the three losses 2e-6, the three gradients 1e-6."""
+    from sassd.config import ConfigDict
+    head = SSDRotateHead(num_class=1, num_output_filters=8, num_anchor_per_loc=2, box_code_size=7).to(dev)
+    anc = dict(Car=torch.stack([_g("anchors", dev), _g("a2", dev)]))
+    msk = dict(Car=torch.stack([_g("anchor_mask", dev), _g("m2", dev)]))
+    gtb = [_g("gt", dev), _g("gt2", dev)]
+    gtl = [torch.ones(9, dtype=torch.int64, device=dev), torch.ones(6, dtype=torch.int64, device=dev)]
+    gtt = [np.array(["Car"] * 9), np.array(["Car"] * 5 + ["Van"])]
+    box, cls, dr = (_g(k, dev).clone().requires_grad_() for k in ("rpn_box", "rpn_cls", "rpn_dir"))
+    cfg = ConfigDict(assigner=ConfigDict(Car=ConfigDict(pos_iou_thr=0.6, neg_iou_thr=0.45, min_pos_iou=0.45),
+                                         ignore_iof_thr=-1, similarity_fn="NearestIouSimilarity"), anchor_thr=0.1)
+    ls = head.loss(box, cls, dr, gtb, gtl, gtt, anc, msk, cfg)                  # fused path (CUDA tensors)
+
+    def close(a, b, tol):
+        a, b = np.asarray(a.detach().cpu(), np.float64), np.asarray(b, np.float64)
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+    for k in ("rpn_loc_loss", "rpn_cls_loss", "rpn_dir_loss"):
+        close(ls[k], _G[k], 2e-6)
+    tot = ls["rpn_loc_loss"] + ls["rpn_cls_loss"] + ls["rpn_dir_loss"]
+    gb, gc, gd = torch.autograd.grad(tot.sum(), [box, cls, dr])
+    close(gb, _G["rpn_gbox"], 1e-6)
+    close(gc, _G["rpn_gcls"], 1e-6)
+    close(gd, _G["rpn_gdir"], 1e-6)

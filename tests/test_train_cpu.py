@@ -181,8 +181,12 @@ def test_flat_params_views():
     assert f.grad.abs().sum() > 0 and m[0].weight.grad.data_ptr() == f.grad.data_ptr()
     f.data.mul_(2.0)
     assert torch.equal(m[0].weight, before["0.weight"] * 2)
-    f.zero_grad()
-    assert float(m[2].weight.grad.abs().sum()) == 0
+    f.zero_grad()                                   # .grad = None: the next backward's gradients are stolen, not added
+    assert m[2].weight.grad is None
+    assert float(f.grad.abs().sum()) == 0           # the flat buffer collects lazily: no gradient -> zeros
+    assert m[2].weight.grad.data_ptr() == f.grad.data_ptr() + 4 * f.offsets[2 + 2]       # and .grad is a view again
+    m(torch.randn(4, 6)).sum().backward()           # gradients arrive in their own tensors ...
+    assert m[0].weight.grad.data_ptr() == f.grad.data_ptr() and float(f.grad.abs().sum()) > 0    # ... one collect later
 
 
 def test_rpn_loss_with_an_empty_sample():

@@ -190,8 +190,16 @@ __global__ void conv2d_wgrad_reduce_kernel(const float *__restrict__ part, int n
     const size_t n = (size_t)taps * Cout * Cin;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;            // four loads in flight, fixed summation order
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+        s0 += part[(size_t)k * n + i];
+        s1 += part[(size_t)(k + 1) * n + i];
+        s2 += part[(size_t)(k + 2) * n + i];
+        s3 += part[(size_t)(k + 3) * n + i];
+    }
+    for (; k < nsplit; ++k) s0 += part[(size_t)k * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
     const int ci = i % Cin;
     const int co = (i / Cin) % Cout;
     const int t = i / ((size_t)Cin * Cout);

@@ -653,9 +653,17 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, const int32_
     const int nwg = (n + kWgRows - 1) / kWgRows;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per) return;
-    float s = accumulate ? dw[i] : 0.f;
-    for (int g = 0; g < nwg; ++g) s += part[(size_t)g * per + i];
-    dw[i] = s;
+    // four independent partial sums keep four loads in flight (the loop is latency-bound otherwise); fixed order
+    float s0 = accumulate ? dw[i] : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 4 <= nwg; g += 4) {
+        s0 += part[(size_t)g * per + i];
+        s1 += part[(size_t)(g + 1) * per + i];
+        s2 += part[(size_t)(g + 2) * per + i];
+        s3 += part[(size_t)(g + 3) * per + i];
+    }
+    for (; g < nwg; ++g) s0 += part[(size_t)g * per + i];
+    dw[i] = (s0 + s1) + (s2 + s3);
 }
 
 template <int CIN, int COUT>

@@ -99,6 +99,7 @@ _SIGS = {
     "sassd_conv1x1_gemm_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv1x1_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_bf16_supported": (_I, [_I, _I, _I, _I]),
+    "sassd_debug_set_bf16": (None, [_I]),
     "sassd_conv2d_bf16_packed_elems": (_SZ, [_I, _I]),
     "sassd_conv2d_bf16_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv2d_bf16_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -23,6 +23,7 @@
 #include "common.h"
 
 namespace {
+int g_bf16_dbg = 0;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -77,7 +78,7 @@ __global__ void bf16_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
 // (global fp32 -> bf16 -> LDS) while the MMA waves multiply the current one.  The split matters because vector-memory
 // loads return in order: with one wave doing both, every wait for a weight fragment (L2 latency) also waited for the
 // input-tile loads issued before it (HBM / MALL latency), and the MFMA pipe idled for about half of every chunk.
-template <int COW, int NLW>
+template <int COW, int NLW, int DBG>
 __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfParams p)
 {
     constexpr int NLT = 64 * NLW;                  // loader threads
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
         stage(0, 0);
         __syncthreads();
         for (int c = 0; c < nchunk; ++c) {
-            if (c + 1 < nchunk) stage((c + 1) * kKC, (c + 1) & 1);
+            if (c + 1 < nchunk && !(DBG & 1)) stage((c + 1) * kKC, (c + 1) & 1);
             __syncthreads();
         }
         return;
@@ -179,7 +180,8 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
             for (int s = 0; s < 18; ++s) {
                 // weights RING-1 steps ahead (the last steps of a chunk fetch the first ones of the next chunk)
                 const int sa = s + RING - 1;
-                if (sa < 18) load_a(sa % RING, c, sa);
+                if (DBG & 2) load_a(sa % RING, 0, 0);      // ablation: one hot fragment
+                else if (sa < 18) load_a(sa % RING, c, sa);
                 else load_a(sa % RING, cn, sa - 18);
                 if (s + 1 < 18) {
                     const int tap = (s + 1) >> 1, ks = (s + 1) & 1;
@@ -190,11 +192,16 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
                 }
                 // RING loads are outstanding; the oldest one is this step's fragment
                 asm volatile("s_waitcnt vmcnt(%1)" : "+v"(aring[s % RING]) : "n"(RING - 1));
+                if (!(DBG & 4)) {
 #pragma unroll
                 for (int n = 0; n < NPB; ++n)
                     acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aring[s % RING]),
                                                                     __builtin_bit_cast(bf16x8, bf[s & 1][n]), acc[n],
                                                                     0, 0, 0);
+                } else {
+#pragma unroll
+                for (int n = 0; n < NPB; ++n) acc[n][0] += __builtin_bit_cast(float, aring[s % RING][0] ^ bf[s & 1][n][1]);
+                }
             }
         }
         __syncthreads();
@@ -208,6 +215,15 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
     // ---- epilogue: D row = cout = (r & 3) + 8 * (r >> 2) + 4 * lh, column = pixel li -> (row li >> 4, column li & 15)
     if (!active) return;
     float *yb = p.y + (size_t)b * p.Cout * hw;
+    if (DBG & 8) {      // ablation: one store per lane that depends on every accumulator
+        float t = 0.f;
+#pragma unroll
+        for (int n = 0; n < NPB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[n][r];
+        yb[(size_t)(co_w + lh) * hw + (size_t)(r0 + (li >> 4)) * p.W + c0 + (li & 15)] = t;
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NPB; ++n) {
         const int yy = r0 + 2 * n + (li >> 4), xx = c0 + (li & 15);
@@ -221,6 +237,10 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
     }
 }
 }  // namespace
+
+// ablation (tools/run_bf16_conv.py --ablate): bit0 stage only the first input chunk, bit1 re-load one hot weight
+// fragment, bit2 no MFMA, bit3 no output stores
+extern "C" void sassd_debug_set_bf16(int flags) { g_bf16_dbg = flags; }
 
 extern "C" int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W)
 {
@@ -249,9 +269,17 @@ extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const
     p.tiles_x = W / kTC; p.tiles_y = cdiv(H, kTR);
     hipStream_t s = (hipStream_t)stream_;
     const long tiles = (long)p.tiles_x * p.tiles_y * batch;
-    if (Cout % 256 == 0)
-        hipLaunchKernelGGL((conv2d_bf16_kernel<8, 4>), dim3((unsigned)(tiles * (Cout / 256))), dim3(768), 0, s, p);
-    else        // 128-cout tiles; the last one may be partly idle (Cout = 320: 3 tiles, 2.5 used)
-        hipLaunchKernelGGL((conv2d_bf16_kernel<4, 4>), dim3((unsigned)(tiles * cdiv(Cout, 128))), dim3(512), 0, s, p);
+    if (Cout % 256 == 0) {
+        const dim3 grid((unsigned)(tiles * (Cout / 256)));
+        switch (g_bf16_dbg) {       // compile-time ablation variants (a run-time switch inside the kernel de-tunes it)
+#define SASSD_BF16_VARIANT(D) case D: hipLaunchKernelGGL((conv2d_bf16_kernel<8, 4, D>), grid, dim3(768), 0, s, p); break;
+            SASSD_BF16_VARIANT(1) SASSD_BF16_VARIANT(2) SASSD_BF16_VARIANT(3) SASSD_BF16_VARIANT(4)
+            SASSD_BF16_VARIANT(8) SASSD_BF16_VARIANT(11) SASSD_BF16_VARIANT(15)
+#undef SASSD_BF16_VARIANT
+            default: hipLaunchKernelGGL((conv2d_bf16_kernel<8, 4, 0>), grid, dim3(768), 0, s, p);
+        }
+    } else {    // 128-cout tiles; the last one may be partly idle (Cout = 320: 3 tiles, 2.5 used)
+        hipLaunchKernelGGL((conv2d_bf16_kernel<4, 4, 0>), dim3((unsigned)(tiles * cdiv(Cout, 128))), dim3(512), 0, s, p);
+    }
     return sassd_launch_status();
 }

@@ -28,6 +28,7 @@ def timed(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--ablate", action="store_true", help="time the bf16 conv with parts switched off")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     x = torch.randn(2, 256, 200, 176, device=dev)
@@ -47,6 +48,14 @@ def main():
         out["fwd3x3_bf16_ms"] = timed(lambda: K.conv2d_bf16_fwd(x, pk, 256), a.iters)
         out["fwd3x3_wino4_fp32_ms"] = timed(lambda: K.conv2d_wino4_fwd(x, p4, 256, None, None), a.iters)
         out["fwd3x3_bf16_tflops"] = flops / out["fwd3x3_bf16_ms"] / 1e9
+        if a.ablate:
+            from sassd import _C
+            names = {1: "no_input_staging", 2: "hot_weights", 4: "no_mfma", 8: "no_stores", 3: "no_global_loads",
+                     15: "only_lds", 11: "mfma_and_lds_only"}
+            for flag, name in names.items():
+                _C.lib().sassd_debug_set_bf16(flag)
+                out["ablate_" + name + "_ms"] = timed(lambda: K.conv2d_bf16_fwd(x, pk, 256), a.iters)
+            _C.lib().sassd_debug_set_bf16(0)
     print(json.dumps(out, indent=1))
 
 

@@ -646,6 +646,110 @@ spconv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, c
         }
 }
 
+// Second formulation of the same partial sums (default): ONE wave per kernel offset instead of one wave per 16x16 tile.
+// The MFMA work of a weight gradient is tiny (~1 GFLOP per layer); what bounded the tile-per-wave kernel above was that
+// every lane issued 27 four-byte gathers per 4-row step and that ~2/3 of its MFMA steps multiplied rows without a pair.
+// Here a workgroup is still one 128-row chunk, but its 8 waves split the 27 OFFSETS (wave 0: the centre offset, which
+// pairs every row of a submanifold layer; waves 1-7: three or four of the others -- about one "row chunk" of pairs each).
+// A wave compacts the pairs of its offset with ballots (in / out row lists in LDS), then runs dense 16x16x4 MFMA steps
+// over four pairs at a time for the whole Cin x Cout tile (<= 16 accumulator tiles): 64-byte row segments per load,
+// two steps of operands in flight, no empty steps.  Partial sums land in the same [chunk][offset][Cin][Cout] layout.
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(512) spconv_wgrad_offset_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                                  const int32_t *__restrict__ nbr,
+                                                                  const int32_t *__restrict__ n_ptr, int cap,
+                                                                  float *__restrict__ part)
+{
+    constexpr int MT = (CIN + 15) / 16, NTT = COUT / 16;
+    __shared__ int lists[8][2][kWgRows];
+    const int n = min(*n_ptr, cap);
+    const int r0 = blockIdx.x * kWgRows;
+    if (r0 >= n) return;                                        // workgroup-uniform
+    const int rows = min(kWgRows, n - r0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, m16 = lane & 15;
+    int *lin = lists[wave][0], *lout = lists[wave][1];
+    float *dst = part + (size_t)blockIdx.x * kK * CIN * COUT;
+    // offsets of this wave: wave 0 -> 13; wave w >= 1 -> the (w-1)-th, (w+6)-th, ... of the other 26
+#pragma unroll 1
+    for (int t = 0; t < (wave == 0 ? 1 : 4); ++t) {
+        int k;
+        if (wave == 0) {
+            k = 13;
+        } else {
+            const int j = (wave - 1) + 7 * t;                   // index among the 26 non-centre offsets
+            if (j >= 26) break;
+            k = j < 13 ? j : j + 1;
+        }
+        // ---- compact the (in, out) pairs of offset k over the chunk's rows (ascending row order: deterministic)
+        int cnt = 0;
+        for (int rb = 0; rb < rows; rb += 64) {
+            const int rl = rb + lane;
+            const int in = rl < rows ? nbr[(size_t)(r0 + rl) * kK + k] : -1;
+            const unsigned long long m = __ballot(in >= 0);
+            if (in >= 0) {
+                const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                lin[pos] = in;
+                lout[pos] = r0 + rl;
+            }
+            cnt += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4 acc[MT][NTT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NTT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // ---- dense MFMA steps, 4 pairs each; the operands of step s+1 are in flight during the MFMAs of step s
+        float av[2][MT], bv[2][NTT];
+        auto fetch = [&](int s, float *a, float *b) {
+            const int pidx = 4 * s + q;
+            const bool ok = pidx < cnt;
+            const int in = ok ? lin[pidx] : 0, out = ok ? lout[pidx] : 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ci = mt * 16 + m16;
+                const bool cok = ok && ci < CIN;
+                const float v = x[cok ? (size_t)in * CIN + ci : 0];
+                a[mt] = cok ? v : 0.f;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt) {
+                const float v = dy[ok ? (size_t)out * COUT + nt * 16 + m16 : 0];
+                b[nt] = ok ? v : 0.f;
+            }
+        };
+        const int nsteps = (cnt + 3) >> 2;
+        if (nsteps > 0) fetch(0, av[0], bv[0]);
+#pragma unroll 1
+        for (int s = 0; s < nsteps; s += 2) {
+            if (s + 1 < nsteps) fetch(s + 1, av[1], bv[1]);
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NTT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][a], bv[0][b], acc[a][b], 0, 0, 0);
+            if (s + 1 >= nsteps) break;
+            if (s + 2 < nsteps) fetch(s + 2, av[0], bv[0]);
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NTT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][a], bv[1][b], acc[a][b], 0, 0, 0);
+        }
+        // D[row = q*4 + reg][col = m16] -> dW[k][ci = a*16 + q*4 + reg][co = b*16 + m16]
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NTT; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int ci = a * 16 + q * 4 + reg;
+                    if (ci < CIN) dst[((size_t)k * CIN + ci) * COUT + b * 16 + m16] = acc[a][b][reg];
+                }
+        __builtin_amdgcn_wave_barrier();                       // the lists are rewritten for the next offset
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, const int32_t *__restrict__ n_ptr, int cap,
                                     int per, float *__restrict__ dw, int accumulate)
 {
@@ -673,8 +777,12 @@ int launch_wgrad(const float *x, const float *dy, const int32_t *nbr, const int3
     constexpr int MT = (CIN + 15) / 16, NTT = COUT / 16;
     constexpr int WPW = MT * NTT < 8 ? MT * NTT : 8;
     const int nwg = cdiv(cap, kWgRows);
-    hipLaunchKernelGGL((spconv_wgrad_kernel<CIN, COUT>), dim3(nwg, MT * NTT / WPW), dim3(WPW * 64), 0, stream, x, dy,
-                       nbr, n_ptr, cap, part);
+    if (g_spconv_dbg & 32)      // debug bit 5: the tile-per-wave formulation
+        hipLaunchKernelGGL((spconv_wgrad_kernel<CIN, COUT>), dim3(nwg, MT * NTT / WPW), dim3(WPW * 64), 0, stream, x,
+                           dy, nbr, n_ptr, cap, part);
+    else
+        hipLaunchKernelGGL((spconv_wgrad_offset_kernel<CIN, COUT>), dim3(nwg), dim3(512), 0, stream, x, dy, nbr, n_ptr,
+                           cap, part);
     const int per = kK * CIN * COUT;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(per, 256)), dim3(256), 0, stream, (const float *)part, n_ptr, cap,
                        per, dw, accumulate);
@@ -735,7 +843,8 @@ namespace {
 }  // namespace
 
 // debug / ablation switches (tools/ablate_spconv.py): bit0 no gather loads, bit1 no slab accumulate, bit2 no MFMA,
-// bit3 no weight loads, bit4 dynamic (ticket) offset assignment instead of the static table, bit8 legacy
+// bit3 no weight loads, bit4 dynamic (ticket) offset assignment instead of the static table, bit5 tile-per-wave weight
+// gradient, bit8 legacy
 // register-stationary kernel; bits 16.. select the workgroup geometry (0 default)
 extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags & 0xFFFF; g_spconv_cfg = flags >> 16; }
 

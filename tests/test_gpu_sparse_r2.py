@@ -185,3 +185,31 @@ def test_spconv_is_bit_reproducible(dev):
             busy = busy @ busy * 1e-3                 # another kernel in flight changes the wave timing
         y = K.spconv_fwd(x, nb, nptr, n, wp, 27, 64, 64)
         assert torch.equal(y, ref), i
+
+
+def test_weight_gradient_formulations_agree(dev):
+    """The offset-per-wave weight gradient (default) against the tile-per-wave kernel (debug bit 5) on the K21 input
+    level (oracle rulebook): same partial-sum layout, different order inside a 128-row chunk -> equal to fp32 rounding;
+    both bit-reproducible."""
+    idx0 = _level0("k21")
+    _, nbr_np = orb.subm_rulebook(idx0, (40, 1600, 1408))
+    n = len(idx0)
+    cap = n + 37
+    nbr = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+    nbr[:n] = torch.from_numpy(nbr_np).to(dev)
+    n_ptr = torch.tensor([n], dtype=torch.int32, device=dev)
+    g = torch.Generator().manual_seed(0)
+    for cin, cout in ((64, 64), (16, 32), (4, 16)):
+        x = torch.zeros(cap, cin, device=dev)
+        dy = torch.zeros(cap, cout, device=dev)
+        x[:n] = torch.randn(n, cin, generator=g).to(dev)
+        dy[:n] = torch.randn(n, cout, generator=g).to(dev)
+        new = K.spconv_bwd_weight(x, dy, nbr, n_ptr, cap, cin, cout)
+        assert torch.equal(new, K.spconv_bwd_weight(x, dy, nbr, n_ptr, cap, cin, cout))
+        K.debug_set_spconv(32)
+        try:
+            old = K.spconv_bwd_weight(x, dy, nbr, n_ptr, cap, cin, cout)
+        finally:
+            K.debug_set_spconv(0)
+        err = float((new - old).abs().max()) / float(old.abs().max())
+        assert err < 1e-5, (cin, cout, err)

@@ -460,6 +460,10 @@ int sassd_noise_per_box(const float *boxes, const uint8_t *valid, const double *
  *                   non-NULL and max_norm > 0 (torch clip_grad_norm_ semantics), else grad * grad_scale;
  *                   p *= 1 - wd*lr; m,v Adam moments; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
  *                   `step` is t >= 1.  All pointers 16-byte aligned. */
+/* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for i < n; dst fp32, or bf16 (round-to-nearest-even) when bf16 != 0: every
+ * kernel-layout weight image is a permutation (+ zero padding) of the flat parameter buffer, so ONE gather re-packs all
+ * of them after an optimizer step (sassd.train.PackPlan). */
+int sassd_gather_pack(const float *src, const int32_t *map, void *dst, long n, int bf16, void *stream);
 int sassd_grad_sumsq(const float *grad, long n, float *out, void *stream);
 int sassd_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n,
                     const float *grad_sumsq, float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -40,6 +40,22 @@ def _n_ptr(n, dev):
     return t
 
 
+_sp_t_packs = {}
+
+
+def _spconv_t_pack(weight):
+    """Transposed packed image of a sparse-conv weight [K, Cin, Cout] for the data gradient, cached per parameter
+    storage and weight generation (sassd.train.PackPlan refreshes the entry right after the optimizer step)."""
+    key = (weight.data_ptr(), tuple(weight.shape))
+    gen = K.weight_key(weight)
+    hit = _sp_t_packs.get(key)
+    if hit is not None and hit[0] == gen:
+        return hit[1]
+    pack = K.spconv_pack_weight_t(weight.detach().contiguous())
+    _sp_t_packs[key] = (gen, pack)
+    return pack
+
+
 class SparseConvFn(Function):
     """y = sum_k x[nbr[:, k]] @ w[k]  (raw conv; BatchNorm / ReLU stay separate modules in training mode)."""
 
@@ -69,7 +85,7 @@ class SparseConvFn(Function):
         if ctx.needs_input_grad[0]:
             if cin < 16:
                 raise NotImplementedError("sparse data gradient needs Cin >= 16 (the 4-channel input layer has none)")
-            wt = K.spconv_pack_weight_t(weight.detach().contiguous())
+            wt = _spconv_t_pack(weight)
             if nbr is None:
                 dx = K.spconv_bwd_data(dyc, None, _n_ptr(n_in, dev), max(n_in, 1), wt, 1, cin, cout)[:n_in]
             else:
@@ -97,14 +113,18 @@ def _conv_any(x, weight, ks, packed=None, wino=None, shift=None, wino4=None):
 
 
 _dgrad_packs = {}
+_dgrad_direct = {}
 
 
 def _dgrad_pack(weight, h, w):
     """Packed image of the data-gradient conv's weights (transposed, taps mirrored), cached per parameter storage and
     weight generation: the pack is a pure function of the weights, which change once per optimizer step."""
     ks = weight.shape[2]
-    key = (weight.data_ptr(), tuple(weight.shape), h, w)
     gen = K.weight_key(weight)
+    hit = _dgrad_direct.get((weight.data_ptr(), tuple(weight.shape)))       # installed by sassd.train.PackPlan
+    if hit is not None and hit[0] == gen:
+        return hit[1]
+    key = (weight.data_ptr(), tuple(weight.shape), h, w)
     hit = _dgrad_packs.get(key)
     if hit is not None and hit[0] == gen:
         return hit[1]

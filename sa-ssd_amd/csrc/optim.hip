@@ -101,3 +101,44 @@ extern "C" int sassd_adam_step(float *param, const float *grad, float *exp_avg, 
                        exp_avg_sq, n, grad_sumsq, a);
     return sassd_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Re-packing of EVERY kernel-layout weight image after an update, in one launch per destination type: all parameters
+// live in one flat buffer and every pack (sparse-conv MFMA fragment order, its transposed twin for the data gradient,
+// the direct conv's [chunk][tap][kc][CoutPad], the bf16 [tap][Cin/8][Cout][8] images) is a pure permutation with zero
+// padding, so "pack" = gather through a precomputed index map (sassd.train.PackPlan builds the maps once by pushing
+// index-valued weights through the individual pack kernels).  map[i] < 0 -> 0.
+namespace {
+__global__ void gather_pack_f32_kernel(const float *__restrict__ src, const int32_t *__restrict__ map,
+                                       float *__restrict__ dst, long n)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int m = map[i];
+    dst[i] = m >= 0 ? src[m] : 0.f;
+}
+
+__global__ void gather_pack_bf16_kernel(const float *__restrict__ src, const int32_t *__restrict__ map,
+                                        unsigned short *__restrict__ dst, long n)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int m = map[i];
+    const float v = m >= 0 ? src[m] : 0.f;
+    dst[i] = __builtin_bit_cast(unsigned short, (__bf16)v);          // round-to-nearest-even, like the pack kernels
+}
+}  // namespace
+
+extern "C" int sassd_gather_pack(const float *src, const int32_t *map, void *dst, long n, int bf16, void *stream_)
+{
+    if (!src || !map || !dst || n < 0) return SASSD_EINVAL;
+    if (n == 0) return SASSD_OK;
+    hipStream_t s = (hipStream_t)stream_;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (bf16)
+        hipLaunchKernelGGL(gather_pack_bf16_kernel, dim3(grid), dim3(256), 0, s, src, map, (unsigned short *)dst, n);
+    else
+        hipLaunchKernelGGL(gather_pack_f32_kernel, dim3(grid), dim3(256), 0, s, src, map, (float *)dst, n);
+    return sassd_launch_status();
+}
+

@@ -786,3 +786,12 @@ def rpn_loss(box_preds, cls_preds, dir_preds, labels, targets, anchors, num_pos)
                               _C.ptr(gbox), _C.ptr(gcls), _C.ptr(gdir), _C.ptr(sums), _C.ptr(ws), wsb, _C.stream()),
              "sassd_rpn_loss")
     return sums, gbox, gcls, gdir
+
+
+def gather_pack(src_flat, index_map, dst):
+    """dst[i] = src_flat[index_map[i]] (0 where the map is negative); dst fp32, or int16 holding bf16 bits."""
+    _chk_cuda(src_flat, index_map, dst)
+    assert index_map.dtype == torch.int32 and index_map.numel() == dst.numel()
+    _C.check(_C.lib().sassd_gather_pack(_C.ptr(src_flat), _C.ptr(index_map), _C.ptr(dst), dst.numel(),
+                                        0 if dst.dtype == torch.float32 else 1, _C.stream()), "sassd_gather_pack")
+    return dst

@@ -75,6 +75,111 @@ class FlatParams:
             torch._foreach_copy_(dst, src)
 
 
+class PackPlan:
+    """Every kernel-layout weight image of the training step, refreshed by ONE gather launch per element type right
+    after the optimizer step (sassd_gather_pack) instead of ~60 individual pack launches spread over forward and
+    backward: the sparse convs' MFMA-fragment packs and their transposed twins (data gradient), the direct conv packs
+    of the 1x1 head convs (forward + data gradient) and -- under set_bev_precision("bf16") -- the bf16 images of the 3x3
+    BEV convs (forward + data gradient).  Each image is a permutation (+ zero padding) of the flat parameter buffer;
+    the index maps are built once by pushing index-valued weights through the individual pack routines, so the layouts
+    stay defined in one place.  Packs not covered here (Winograd transforms of the fp32 mode) keep packing lazily."""
+
+    def __init__(self, model, flat):
+        import numpy as np
+        from . import autograd as AG, spconv as SP
+        from .detector import _HipConv2d
+        self.flat = flat
+        dev = flat.data.device
+        base = flat.data.data_ptr()
+        f32_maps, bf_maps = [], []
+        self._f32, self._bf = [], []                  # (offset, numel, install(view))
+
+        def idx_like(p):
+            """(flat index + 1) of every element of p, int32, shaped like p."""
+            off = (p.data_ptr() - base) // 4
+            assert 0 <= off and off + p.numel() <= flat.numel, "parameter outside the flat buffer"
+            return (torch.arange(p.numel(), dtype=torch.int32, device=dev) + (off + 1)).view(p.shape)
+
+        def bits(t):
+            """int32 -> the same words typed fp32 (the pack kernels only move words, they never compute)."""
+            return t.contiguous().view(torch.float32)
+
+        def add(maps, sinks, m, install):
+            sinks.append((sum(x.numel() for x in maps), m.numel(), install))
+            maps.append(m.reshape(-1))
+
+        def add_f32(packed_bits, install):
+            add(f32_maps, self._f32, packed_bits.view(torch.int32) - 1, install)
+
+        def bf16_map(off, cout, cin, transposed):
+            i = off + np.arange(cout * cin * 9, dtype=np.int64).reshape(cout, cin, 9)
+            if transposed:                            # weight.transpose(0, 1).flip(2, 3): [cin, cout, 8 - tap]
+                i = i.transpose(1, 0, 2)[:, :, ::-1]
+                cout, cin = cin, cout
+            cp = (cin + 31) // 32 * 32
+            pad = np.full((cout, cp, 9), -1, np.int64)
+            pad[:, :cin] = i
+            return torch.from_numpy(pad.reshape(cout, cp // 8, 8, 9).transpose(3, 1, 0, 2).reshape(-1).astype(np.int32)).to(dev)
+
+        bf16 = AG.bev_precision() == "bf16"
+        for m in model.modules():
+            if isinstance(m, SP.SparseConvolution) and m.weight.requires_grad:
+                k = int(np.prod(m.kernel_size))
+                wi = bits(idx_like(m.weight).reshape(k, m.in_channels, m.out_channels))
+
+                def inst(view, m=m):
+                    m._packed, m._packed_version = view, K.weight_key(m.weight)
+                add_f32(K.spconv_pack_weight(wi), inst)
+                if m.in_channels >= 16:
+                    key = (m.weight.data_ptr(), (k, m.in_channels, m.out_channels))
+
+                    def inst_t(view, m=m, key=key):
+                        AG._sp_t_packs[key] = (K.weight_key(m.weight), view)
+                    add_f32(K.spconv_pack_weight_t(wi), inst_t)
+            elif isinstance(m, _HipConv2d) and m.weight.requires_grad:
+                cout, cin, ks = m.out_channels, m.in_channels, m.kernel_size[0]
+                off = (m.weight.data_ptr() - base) // 4
+                wkey = (m.weight.data_ptr(), tuple(m.weight.shape))
+                direct_fwd = ks == 1
+                if ks == 3 and bf16:
+                    if cout % 32 == 0:
+                        def inst_b(view, m=m, wkey=wkey):
+                            AG._bf16_packs[wkey + (False,)] = (K.weight_key(m.weight), view)
+                        add(bf_maps, self._bf, bf16_map(off, cout, cin, False), inst_b)
+                    else:
+                        direct_fwd = True
+                    if cin % 32 == 0:
+                        def inst_bt(view, m=m, wkey=wkey):
+                            AG._bf16_packs[wkey + (True,)] = (K.weight_key(m.weight), view)
+                        add(bf_maps, self._bf, bf16_map(off, cout, cin, True), inst_bt)
+                if direct_fwd:
+                    def inst_d(view, m=m):
+                        m._pk, m._pkv = view, K.weight_key(m.weight)
+                    add_f32(K.conv2d_pack_weight(bits(idx_like(m.weight))), inst_d)
+                if ks == 1:
+                    wt = bits(idx_like(m.weight).transpose(0, 1).flip(2, 3))
+
+                    def inst_dt(view, m=m, wkey=wkey):
+                        AG._dgrad_direct[wkey] = (K.weight_key(m.weight),
+                                                  dict(packed=view, wt=m.weight.detach().transpose(0, 1)))
+                    add_f32(K.conv2d_pack_weight(wt), inst_dt)
+        self.f32_map = torch.cat(f32_maps) if f32_maps else None
+        self.bf_map = torch.cat(bf_maps) if bf_maps else None
+        self.f32_dst = torch.empty(self.f32_map.numel(), dtype=torch.float32, device=dev) if f32_maps else None
+        self.bf_dst = torch.empty(self.bf_map.numel(), dtype=torch.int16, device=dev) if bf_maps else None
+        self.run()
+
+    def run(self):
+        if self.f32_map is not None:
+            K.gather_pack(self.flat.data, self.f32_map, self.f32_dst)
+            for off, n, install in self._f32:
+                install(self.f32_dst[off:off + n])
+        if self.bf_map is not None:
+            K.gather_pack(self.flat.data, self.bf_map, self.bf_dst)
+            for off, n, install in self._bf:
+                install(self.bf_dst[off:off + n])
+
+
 def annealing_cos(start, end, pct):
     return end + (start - end) / 2 * (math.cos(math.pi * pct) + 1)
 
@@ -126,6 +231,7 @@ class AdamOneCycle:
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.flat.data.device)
         self.steps = 0
+        self.pack_plan = None                 # PackPlan(model, self.flat): all weight images re-packed in one launch
 
     def zero_grad(self):
         self.flat.zero_grad()
@@ -137,6 +243,8 @@ class AdamOneCycle:
         K.adam_step(self.flat.data, grad, self.exp_avg, self.exp_avg_sq, sumsq, self.lr, self.mom,
                     self.beta2, self.eps, self.wd, self.steps, self.max_norm, 1.0 / self.world_size)
         K.bump_weights_generation()          # raw-pointer update: parameter `_version`s did not move
+        if self.pack_plan is not None:
+            self.pack_plan.run()
 
     def state_dict(self):
         return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), steps=self.steps, lr=self.lr,
@@ -152,8 +260,11 @@ class AdamOneCycle:
 def build_optimizer(model, optim_cfg, world_size=1):
     if optim_cfg["type"] != "adam_onecycle":
         raise NotImplementedError("the SA-SSD configs train with 'adam_onecycle'")
-    return AdamOneCycle(model, optim_cfg["lr"], optim_cfg["weight_decay"], grad_clip=optim_cfg.get("grad_clip"),
-                        world_size=world_size)
+    opt = AdamOneCycle(model, optim_cfg["lr"], optim_cfg["weight_decay"], grad_clip=optim_cfg.get("grad_clip"),
+                       world_size=world_size)
+    if opt.flat.data.is_cuda and optim_cfg.get("pack_plan", True):
+        opt.pack_plan = PackPlan(model, opt.flat)
+    return opt
 
 
 def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, optim_cfg, lr_cfg):

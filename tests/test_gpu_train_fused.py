@@ -195,3 +195,58 @@ def test_fused_rpn_loss_vs_reference_golden(dev):
     close(gb, _G["rpn_gbox"], 1e-6)
     close(gc, _G["rpn_gcls"], 1e-6)
     close(gd, _G["rpn_gdir"], 1e-6)
+
+
+def test_pack_plan_matches_individual_packs(dev):
+    """sassd.train.PackPlan: after an optimizer step every cached weight image (sparse fwd / transposed, direct conv fwd
+    / data-gradient, bf16 fwd / data-gradient) equals what the individual pack routine produces from the new weights."""
+    import os
+    from sassd import autograd as AG, spconv as SP, train
+    from sassd.detector import _HipConv2d, build_detector
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "car_cfg.py"))
+    try:
+        AG.set_bev_precision("bf16")
+        model = synth.randomize_detector(build_detector(cfg.model, cfg.train_cfg, cfg.test_cfg), 0).to(dev)
+        opt = train.build_optimizer(model, cfg.optimizer, 1)
+        assert opt.pack_plan is not None
+        opt.flat.grad.normal_(0, 1e-2)
+        opt.lr = 1e-2
+        opt.step()
+        torch.cuda.synchronize()
+        checked = dict(sp=0, spt=0, direct=0, dgrad=0, bf=0, bft=0)
+        for m in model.modules():
+            if isinstance(m, SP.SparseConvolution):
+                k = int(np.prod(m.kernel_size))
+                w = m.weight.detach().reshape(k, m.in_channels, m.out_channels).contiguous()
+                assert m._packed_version == K.weight_key(m.weight)
+                assert torch.equal(m._packed, K.spconv_pack_weight(w)); checked["sp"] += 1
+                if m.in_channels >= 16:
+                    gen, pk = AG._sp_t_packs[(m.weight.data_ptr(), (k, m.in_channels, m.out_channels))]
+                    assert gen == K.weight_key(m.weight) and torch.equal(pk, K.spconv_pack_weight_t(w)); checked["spt"] += 1
+            elif isinstance(m, _HipConv2d):
+                w = m.weight.detach()
+                key = (w.data_ptr(), tuple(w.shape))
+                if m.kernel_size[0] == 1:
+                    assert m._pkv == K.weight_key(m.weight) and torch.equal(m._pk, K.conv2d_pack_weight(w.contiguous()))
+                    gen, d = AG._dgrad_direct[key]
+                    wt = w.transpose(0, 1).flip(2, 3).contiguous()
+                    assert gen == K.weight_key(m.weight) and torch.equal(d["packed"], K.conv2d_pack_weight(wt))
+                    assert tuple(d["wt"].shape) == tuple(wt.shape)
+                    checked["direct"] += 1; checked["dgrad"] += 1
+                else:
+                    if m.out_channels % 32 == 0:
+                        gen, pk = AG._bf16_packs[key + (False,)]
+                        assert gen == K.weight_key(m.weight) and torch.equal(pk, K.conv2d_bf16_pack_weight(w.contiguous()))
+                        checked["bf"] += 1
+                    else:
+                        assert torch.equal(m._pk, K.conv2d_pack_weight(w.contiguous())); checked["direct"] += 1
+                    if m.in_channels % 32 == 0:
+                        gen, pk = AG._bf16_packs[key + (True,)]
+                        wt = w.transpose(0, 1).flip(2, 3).contiguous()
+                        assert gen == K.weight_key(m.weight) and torch.equal(pk, K.conv2d_bf16_pack_weight(wt))
+                        checked["bft"] += 1
+        assert checked["sp"] >= 14 and checked["spt"] >= 13 and checked["bf"] == 7 and checked["bft"] == 8, checked
+        assert checked["direct"] >= 6 and checked["dgrad"] >= 5, checked
+    finally:
+        AG.set_bev_precision("fp32")

@@ -262,6 +262,14 @@ int sassd_assign_targets(const float *anchors, int anchors_per_sample, const uin
                          float matched_threshold, float unmatched_threshold, int64_t *labels, float *targets,
                          float *best_overlap, size_t out_sample_stride, int32_t *num_pos, int zero_num_pos,
                          void *workspace, size_t workspace_bytes, void *stream);
+/* Guided-anchor selection for training (ssd_rotate_head.py:316-388) without a host round trip: ascending indices of the
+ * anchors with anchor_mask set (NULL = all) and sigmoid(max_c cls_preds[b,a,c]) > score_thr go to sel[b][0..counts[b]) of
+ * a fixed-capacity [B,cap] int64 buffer (remaining entries 0); *overflow is set (never cleared) when a sample had more
+ * than cap (the surplus is dropped).  Workspace: sassd_guided_select_workspace_bytes. */
+size_t sassd_guided_select_workspace_bytes(int batch, int n_anchors);
+int sassd_guided_select(const float *cls_preds, const uint8_t *anchor_mask, int n_anchors, int batch, int num_class,
+                        float score_thr, int cap, int64_t *sel, int32_t *counts, int32_t *overflow, void *workspace,
+                        size_t workspace_bytes, void *stream);
 size_t sassd_rpn_loss_workspace_bytes(int batch, int n_anchors);
 int sassd_rpn_loss(const float *box_preds, const float *cls_preds, const float *dir_preds, int num_class,
                    const int64_t *labels, const float *targets, const float *anchors, int anchors_per_sample,

@@ -108,6 +108,8 @@ _SIGS = {
     "sassd_assign_targets_workspace_bytes": (_SZ, [_I, _I, _I]),
     "sassd_assign_targets": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _F, _F, _P, _P, _P, _SZ, _P, _I, _P,
                                   _SZ, _P]),
+    "sassd_guided_select_workspace_bytes": (_SZ, [_I, _I]),
+    "sassd_guided_select": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P, _SZ, _P]),
     "sassd_rpn_loss_workspace_bytes": (_SZ, [_I, _I]),
     "sassd_rpn_loss": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "sassd_conv2d_bwd_weight_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),

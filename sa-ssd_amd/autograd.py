@@ -259,3 +259,22 @@ class RpnLossFn(Function):
     def backward(ctx, g):
         gbox, gcls, gdir = ctx.saved_tensors
         return (gbox * g[0], gcls * g[1], gdir * g[2] if ctx.has_dir else None, None, None, None, None)
+
+
+class PSWarpBatchFn(Function):
+    """Part-sensitive sampling of a whole batch on padded boxes: feat [B,28,H,W], boxes [B,capK,7], counts [B] int32
+    (device) -> logits [B,capK], zero for the rows past a sample's count (their gradients are zero too)."""
+
+    @staticmethod
+    def forward(ctx, feat, boxes, counts, grid_offsets, spatial_scale):
+        feat, boxes = feat.contiguous(), boxes.contiguous()
+        lg = K.pswarp_sample(feat, boxes, counts, boxes.shape[1], grid_offsets, spatial_scale)
+        ctx.save_for_backward(feat, boxes, counts)
+        ctx.args = (grid_offsets, spatial_scale)
+        return lg
+
+    @staticmethod
+    def backward(ctx, dlog):
+        feat, boxes, counts = ctx.saved_tensors
+        dfeat, dg = K.pswarp_sample_bwd(feat, boxes, counts, boxes.shape[1], ctx.args[0], ctx.args[1], dlog.contiguous())
+        return dfeat, dg, None, None, None

@@ -290,6 +290,70 @@ __global__ void __launch_bounds__(256) rpn_loss_sum_kernel(const float *__restri
     if (threadIdx.x < 3) out[threadIdx.x] = (float)((red[threadIdx.x][0] + red[threadIdx.x][1]) +
                                                     (red[threadIdx.x][2] + red[threadIdx.x][3]));
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Guided-anchor selection of the training step (ssd_rotate_head.py:316-388: anchors inside the anchor mask whose best
+// class score exceeds train_cfg.rpn.anchor_thr), without the host round trip of a boolean compaction: ascending
+// anchor indices of the selected anchors land in sel[b][0 .. cnt[b]) of a FIXED-capacity buffer (the rest stays 0) and
+// the count stays on the device, so the decode / PSWarp / loss that follow run on padded tensors with a device count.
+struct GuidedArgs {
+    const float *cls;          // [B,A,NC] logits
+    const uint8_t *mask;       // [B,A] or null
+    int A, B, NC, cap, nblk;
+    float thr;
+    int64_t *sel;              // [B,cap]
+    int *cnt;                  // [B]
+    int *overflow;             // [1]: set when a sample selected more than cap anchors (the surplus is dropped)
+    int *blk;                  // [B,nblk] workspace
+};
+
+__device__ __forceinline__ bool guided_flag(const GuidedArgs &P, int b, int a)
+{
+    if (a >= P.A) return false;
+    const size_t ia = (size_t)b * P.A + a;
+    if (P.mask && !P.mask[ia]) return false;
+    float best = -INFINITY;
+    for (int c = 0; c < P.NC; ++c) best = fmaxf(best, P.cls[ia * P.NC + c]);
+    return 1.f / (1.f + expf(-best)) > P.thr;              // sigmoid is monotone: max of sigmoids = sigmoid of max
+}
+
+__global__ void __launch_bounds__(256) guided_count_kernel(GuidedArgs P)
+{
+    __shared__ int wc[4];
+    const int b = blockIdx.y;
+    const bool f = guided_flag(P, b, blockIdx.x * 256 + threadIdx.x);
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) P.blk[b * P.nblk + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ void __launch_bounds__(256) guided_emit_kernel(GuidedArgs P)
+{
+    __shared__ int red[4];
+    __shared__ int wc[4];
+    const int b = blockIdx.y;
+    int part = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += P.blk[b * P.nblk + i];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    const bool f = guided_flag(P, b, a);
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wc[wave] = __popcll(m);
+    __syncthreads();
+    const int base = red[0] + red[1] + red[2] + red[3];
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wc[w];
+    const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+    if (f && pos < P.cap) P.sel[(size_t)b * P.cap + pos] = a;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const int total = base + wc[0] + wc[1] + wc[2] + wc[3];
+        P.cnt[b] = min(total, P.cap);
+        if (total > P.cap) atomicExch(P.overflow, 1);
+    }
+}
 }  // namespace
 
 extern "C" size_t sassd_assign_targets_workspace_bytes(int batch, int n_anchors, int total_gt)
@@ -360,3 +424,30 @@ extern "C" int sassd_rpn_loss(const float *box_preds, const float *cls_preds, co
                        (int)(grid.x * grid.y), loss_sums);
     return sassd_launch_status();
 }
+
+extern "C" size_t sassd_guided_select_workspace_bytes(int batch, int n_anchors)
+{
+    return batch < 1 || n_anchors < 1 ? 0 : (size_t)batch * cdiv(n_anchors, 256) * sizeof(int);
+}
+
+extern "C" int sassd_guided_select(const float *cls_preds, const uint8_t *anchor_mask, int n_anchors, int batch,
+                                   int num_class, float score_thr, int cap, int64_t *sel, int32_t *counts,
+                                   int32_t *overflow, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (!cls_preds || !sel || !counts || !overflow || !workspace || n_anchors < 1 || batch < 1 || batch > 65535 ||
+        num_class < 1 || cap < 1)
+        return SASSD_EINVAL;
+    if (workspace_bytes < sassd_guided_select_workspace_bytes(batch, n_anchors)) return SASSD_ENOSPC;
+    hipStream_t s = (hipStream_t)stream_;
+    GuidedArgs P;
+    P.cls = cls_preds; P.mask = anchor_mask; P.A = n_anchors; P.B = batch; P.NC = num_class; P.cap = cap;
+    P.nblk = cdiv(n_anchors, 256); P.thr = score_thr; P.sel = sel; P.cnt = counts; P.overflow = overflow;
+    P.blk = (int *)workspace;
+    int rc;
+    if ((rc = sassd_hip(hipMemsetAsync(sel, 0, (size_t)batch * cap * sizeof(int64_t), s)))) return rc;
+    const dim3 grid(P.nblk, batch);
+    hipLaunchKernelGGL(guided_count_kernel, grid, dim3(256), 0, s, P);
+    hipLaunchKernelGGL(guided_emit_kernel, grid, dim3(256), 0, s, P);
+    return sassd_launch_status();
+}
+

@@ -24,7 +24,7 @@ from . import iou3d_utils
 from . import kernels as K
 from . import spconv
 from . import train_ops as T
-from .autograd import Conv2dFn, PSWarpFn, RpnLossFn, bev_precision
+from .autograd import Conv2dFn, PSWarpBatchFn, PSWarpFn, RpnLossFn, bev_precision
 from .config import _wrap, obj_from_dict
 from .kitti_common import kitti_bbox2results
 from .pipeline import InferencePlan
@@ -40,6 +40,30 @@ def _const(dev, values):
     if key not in _CONSTS:
         _CONSTS[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
     return _CONSTS[key]
+
+
+_CONSTS_I32 = {}
+
+
+_CONSTS_I64 = {}
+
+
+def _const_i64(dev, values):
+    key = (str(dev), tuple(int(v) for v in values))
+    if key not in _CONSTS_I64:
+        if len(_CONSTS_I64) > 4096:
+            _CONSTS_I64.clear()
+        _CONSTS_I64[key] = torch.tensor(key[1], dtype=torch.int64, device=dev)
+    return _CONSTS_I64[key]
+
+
+def _const_i32(dev, values):
+    key = (str(dev), tuple(int(v) for v in values))
+    if key not in _CONSTS_I32:
+        if len(_CONSTS_I32) > 4096:
+            _CONSTS_I32.clear()
+        _CONSTS_I32[key] = torch.tensor(key[1], dtype=torch.int32, device=dev)
+    return _CONSTS_I32[key]
 
 
 def change_default_args(**kwargs):
@@ -434,6 +458,54 @@ class SSDRotateHead(nn.Module):
                                                            avg_factor=1.) / b * .2
         return out
 
+    def get_guided_anchors_padded(self, box_preds, cls_preds, dir_cls_preds, anchors, anchors_mask, gt_bboxes, thr=.1,
+                                  cap=None):
+        """The training-mode selection of get_guided_anchors without its host round trip (boolean compaction): the
+        selected anchor indices come from sassd_guided_select into a fixed-capacity buffer with a DEVICE count, the
+        decode / direction flip run on the padded [B, cap, 7] gather, and the result is one [B, Gmax + cap, 7] tensor
+        whose rows [0, G_b) are the sample's ground truth, [G_b, G_b + K_b) the selected boxes in ascending anchor
+        order and the rest padding (count[b] = G_b + K_b stays on the device).  Gradients reach box_preds through the
+        gather.  -> (guided [B, Gmax+cap, 7], counts [B] int32)."""
+        b = box_preds.shape[0]
+        dev = box_preds.device
+        if isinstance(anchors, dict):
+            anchors = torch.cat(list(anchors.values()), 1)
+        if isinstance(anchors_mask, dict):
+            anchors_mask = torch.cat(list(anchors_mask.values()), 1)
+        a = anchors.view(b, -1, 7).shape[1]
+        cap = int(cap) if cap else min(a, 8192)
+        mask = anchors_mask.view(b, -1)
+        mask = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+        if getattr(self, "_guided_overflow", None) is None or self._guided_overflow.device != dev:
+            self._guided_overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        sel, cnt = K.guided_select(cls_preds.detach().reshape(b, a, self._num_class).contiguous(), mask, thr, cap,
+                                   self._guided_overflow)
+        s7 = sel.unsqueeze(-1).expand(b, cap, 7)
+        box = T.second_box_decode(box_preds.view(b, a, self._box_code_size).gather(1, s7),
+                                  anchors.view(b, a, 7).gather(1, s7))
+        if self._use_direction_classifier:
+            dirp = dir_cls_preds.view(b, a, 2).gather(1, sel.unsqueeze(-1).expand(b, cap, 2))
+            opp = (box[..., -1] > 0) ^ (dirp[..., 1] > dirp[..., 0])          # argmax of two = (second > first)
+            box = torch.cat([box[..., :-1], (box[..., -1] + opp.type_as(box) * np.pi).unsqueeze(-1)], dim=-1)
+        counts = [int(g.shape[0]) for g in gt_bboxes]
+        gmax = max(counts) if counts else 0
+        rows = []
+        for i in range(b):
+            parts = [gt_bboxes[i].type_as(box), box[i]] if counts[i] else [box[i]]
+            if gmax > counts[i]:
+                parts.append(box.new_zeros(gmax - counts[i], 7))
+            rows.append(torch.cat(parts, 0) if len(parts) > 1 else parts[0])
+        guided = torch.stack(rows, 0)
+        return guided, cnt + _const_i32(dev, counts)
+
+    def check_guided_capacity(self):
+        """Raises if an earlier get_guided_anchors_padded call overflowed its capacity (one host read: call it where
+        the step synchronises anyway)."""
+        f = getattr(self, "_guided_overflow", None)
+        if f is not None and int(f.item()) != 0:
+            f.zero_()
+            raise RuntimeError("guided anchors exceeded the padded capacity: raise train_cfg.rpn.guided_cap")
+
     def get_guided_anchors(self, box_preds, cls_preds, dir_cls_preds, anchors, anchors_mask, gt_bboxes, gt_labels,
                            thr=.1):
         """ssd_rotate_head.py:316-388, module-level torch path used by training (gradients flow into box_preds;
@@ -506,6 +578,45 @@ class PSWarpHead(nn.Module):
                                  1.0 / self.featmap_stride)
             scores.append(lg.view(-1))
         return scores if is_test else torch.cat(scores, 0)
+
+    def forward_padded(self, x, guided, counts):
+        """guided [B, capK, 7] padded, counts [B] int32 (device) -> logits [B, capK] (zero past a sample's count)."""
+        return PSWarpBatchFn.apply(self.convs(x), guided.float(), counts, tuple(self.grid_offsets),
+                                   1.0 / self.featmap_stride)
+
+    def loss_padded(self, logits, gt_bboxes, guided, counts, cfg):
+        """loss() on the padded batch: rotated 3-D IoU per sample (HIP overlap kernel), ONE sassd_assign_targets call for
+        the labels of the whole batch (rows past a sample's count are masked to -1 and so carry no weight), focal loss
+        normalised by the positives of the batch."""
+        b, capk = logits.shape
+        dev = logits.device
+        g_counts = [int(g.shape[0]) for g in gt_bboxes]
+        tot = sum(g_counts)
+        labels = torch.empty(b, capk, dtype=torch.int64, device=dev)
+        targets = torch.empty(b, capk, 7, dtype=torch.float32, device=dev)
+        num_pos = torch.empty(b, dtype=torch.int32, device=dev)
+        boxes = guided.detach().float().contiguous()
+        row_ok = (torch.arange(capk, device=dev, dtype=torch.int32)[None, :] < counts[:, None]).view(torch.uint8)
+        ovs, offs, o = [], [0], 0
+        for i in range(b):
+            if g_counts[i]:
+                ovs.append(iou3d_utils.boxes_iou3d_gpu(boxes[i], gt_bboxes[i].float()).reshape(-1))
+            o += capk * g_counts[i]
+            offs.append(o)
+        ov = torch.cat(ovs) if len(ovs) > 1 else (ovs[0] if ovs else None)
+        if cfg.assigner.similarity_fn != 'RotateIou3dSimilarity':
+            raise NotImplementedError("padded rescoring loss: RotateIou3dSimilarity only")
+        K.assign_targets(boxes, row_ok.contiguous(), torch.cat([g.float() for g in gt_bboxes]).contiguous() if tot else None,
+                         None, None, K.gt_offsets(g_counts, dev), cfg.assigner.pos_iou_thr, cfg.assigner.neg_iou_thr,
+                         labels, targets, num_pos, overlaps=ov.contiguous() if ov is not None else boxes,
+                         overlap_offsets=_const_i64(dev, offs))
+        labels = labels.view(-1, 1)
+        cared, positives = labels >= 0, labels > 0
+        w = cared.float() / torch.clamp(num_pos.sum().float(), min=1.0)
+        cls_targets = labels * cared.type_as(labels)
+        cls = T.weighted_sigmoid_focal_loss(logits.reshape(-1, self._num_class), cls_targets.float(), weight=w,
+                                            avg_factor=1.)
+        return dict(loss_cls=cls / b)
 
     def loss(self, cls_preds, gt_bboxes, gt_labels, anchors, cfg):
         """ssd_rotate_head.py:456-490: class-agnostic rescoring targets from the rotated 3-D IoU (HIP overlap kernel)."""
@@ -609,12 +720,23 @@ class SingleStageDetector(nn.Module):
         rpn_outs = self.rpn_head(x)
         losses.update(self.rpn_head.loss(*rpn_outs, ret['gt_bboxes'], ret['gt_labels'], ret['gt_types'],
                                          ret['anchors'], ret['anchors_mask'], self.train_cfg.rpn))
+        rpn_cfg = self.train_cfg.rpn
+        extra = getattr(self, 'extra_head', None)
+        if (x.is_cuda and rpn_cfg.get('padded_guided', True) and self.rpn_head._use_sigmoid_cls and extra is not None
+                and self.train_cfg.extra.assigner.similarity_fn == 'RotateIou3dSimilarity'):
+            # no host synchronisation between the backbone and the last loss term: the next step's forward can be
+            # queued while this step's backward still runs
+            guided, counts = self.rpn_head.get_guided_anchors_padded(
+                *rpn_outs, ret['anchors'], ret['anchors_mask'], ret['gt_bboxes'], thr=rpn_cfg.anchor_thr,
+                cap=rpn_cfg.get('guided_cap'))
+            score = extra.forward_padded(conv6, guided, counts)
+            losses.update(extra.loss_padded(score, ret['gt_bboxes'], guided, counts, self.train_cfg.extra))
+            return losses
         guided, _ = self.rpn_head.get_guided_anchors(*rpn_outs, ret['anchors'], ret['anchors_mask'], ret['gt_bboxes'],
-                                                     ret['gt_labels'], thr=self.train_cfg.rpn.anchor_thr)
-        if getattr(self, 'extra_head', None) is not None:
-            score = self.extra_head(conv6, guided)
-            losses.update(self.extra_head.loss(score, ret['gt_bboxes'], ret['gt_labels'], guided,
-                                               self.train_cfg.extra))
+                                                     ret['gt_labels'], thr=rpn_cfg.anchor_thr)
+        if extra is not None:
+            score = extra(conv6, guided)
+            losses.update(extra.loss(score, ret['gt_bboxes'], ret['gt_labels'], guided, self.train_cfg.extra))
         return losses
 
     def forward_test(self, img, img_meta, **kwargs):

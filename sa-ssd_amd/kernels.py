@@ -795,3 +795,20 @@ def gather_pack(src_flat, index_map, dst):
     _C.check(_C.lib().sassd_gather_pack(_C.ptr(src_flat), _C.ptr(index_map), _C.ptr(dst), dst.numel(),
                                         0 if dst.dtype == torch.float32 else 1, _C.stream()), "sassd_gather_pack")
     return dst
+
+
+def guided_select(cls_preds, anchor_mask, score_thr, cap, overflow):
+    """sassd_guided_select: cls_preds [B,A,NC], anchor_mask [B,A] (bool / uint8) or None -> (sel [B,cap] int64 ascending
+    anchor indices, zero padded; counts [B] int32).  `overflow` is a persistent [1] int32 device flag."""
+    _chk_cuda(cls_preds, anchor_mask, overflow)
+    b, a, nc = cls_preds.shape
+    dev = cls_preds.device
+    sel = torch.empty(b, cap, dtype=torch.int64, device=dev)
+    counts = torch.empty(b, dtype=torch.int32, device=dev)
+    L = _C.lib()
+    wsb = L.sassd_guided_select_workspace_bytes(b, a)
+    ws = workspace("guided_select", wsb, dev)
+    _C.check(L.sassd_guided_select(_C.ptr(cls_preds), _C.ptr(anchor_mask), a, b, nc, float(score_thr), int(cap),
+                                   _C.ptr(sel), _C.ptr(counts), _C.ptr(overflow), _C.ptr(ws), wsb, _C.stream()),
+             "sassd_guided_select")
+    return sel, counts

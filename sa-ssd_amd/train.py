@@ -363,6 +363,8 @@ def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None):
     optimizer.zero_grad()
     loss, terms = parse_losses(model(**batch))
     nxt = prefetch() if prefetch is not None else None
+    if prefetch is not None and hasattr(getattr(model, "rpn_head", None), "check_guided_capacity"):
+        model.rpn_head.check_guided_capacity()       # prefetch synchronised already: reading the flag costs nothing
     loss.backward()
     sync.all_reduce_grads()
     optimizer.step()

@@ -250,3 +250,40 @@ def test_pack_plan_matches_individual_packs(dev):
         assert checked["direct"] >= 6 and checked["dgrad"] >= 5, checked
     finally:
         AG.set_bev_precision("fp32")
+
+
+def test_padded_guided_path_equals_list_path(dev):
+    """forward_train with the sync-free padded guided anchors (sassd_guided_select + batched PSWarp + one assignment
+    call) against the per-sample list formulation it replaces: every loss term and every parameter gradient."""
+    import bench
+    from sassd import train
+    w = synth.workload("car")
+    model, cfg = synth.build_detector_for(w, 0, train=True, cls_bias=-2.0)     # enough anchors above anchor_thr
+    model = model.to(dev).train()
+    anchors = dict(Car=torch.from_numpy(w["anchors"]).to(dev))
+    anchors_bv = dict(Car=torch.from_numpy(w["anchors_bv"]).to(dev))
+    clouds = [torch.from_numpy(synth.k21(i)).to(dev) for i in range(2)]
+    gts = [torch.from_numpy(bench.synth_gt_on_points(synth.k21(i), i)[:8 - 3 * i]).to(dev) for i in range(2)]  # 8 and 5
+    types = [np.array(["Car"] * int(g.shape[0])) for g in gts]
+    batch = train.device_batch(clouds, gts, types, ["Car"], anchors, anchors_bv, synth.KITTI_VOXEL, synth.KITTI_RANGE,
+                               model=model)
+    res = {}
+    for padded in (False, True):
+        model.train_cfg.rpn["padded_guided"] = padded
+        model.zero_grad(set_to_none=True)
+        losses = model(**batch)
+        sum(v.sum() for v in losses.values()).backward()
+        res[padded] = ({k: float(v.sum()) for k, v in losses.items()},
+                       {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    model.rpn_head.check_guided_capacity()
+    assert res[True][0].keys() == res[False][0].keys()
+    for k, v in res[False][0].items():
+        assert abs(res[True][0][k] - v) <= 2e-6 * max(1.0, abs(v)), (k, res[True][0][k], v)
+    assert float(res[False][0]["loss_cls"]) > 0
+    assert res[True][1].keys() == res[False][1].keys()
+    worst = 0.0
+    for n, g in res[False][1].items():
+        d = float((res[True][1][n] - g).norm()) / max(float(g.norm()), 1e-12)
+        worst = max(worst, d)
+        assert d < 1e-4, (n, d)
+    print("padded vs list guided path: worst relative gradient difference %.2e" % worst)

@@ -264,7 +264,7 @@ int sassd_assign_targets(const float *anchors, int anchors_per_sample, const uin
                          void *workspace, size_t workspace_bytes, void *stream);
 /* Guided-anchor selection for training (ssd_rotate_head.py:316-388) without a host round trip: ascending indices of the
  * anchors with anchor_mask set (NULL = all) and sigmoid(max_c cls_preds[b,a,c]) > score_thr go to sel[b][0..counts[b]) of
- * a fixed-capacity [B,cap] int64 buffer (remaining entries 0); *overflow is set (never cleared) when a sample had more
+ * a fixed-capacity [B,cap] int64 buffer (remaining entries p -> p: valid, distinct indices); *overflow is set (never cleared) when a sample had more
  * than cap (the surplus is dropped).  Workspace: sassd_guided_select_workspace_bytes. */
 size_t sassd_guided_select_workspace_bytes(int batch, int n_anchors);
 int sassd_guided_select(const float *cls_preds, const uint8_t *anchor_mask, int n_anchors, int batch, int num_class,

@@ -77,23 +77,38 @@ __global__ void nn_count_kernel(int m, const float *__restrict__ known, NnBins g
     if (c >= 0) atomicAdd(&count[c], 1);
 }
 
-// single block: start[c] = exclusive prefix of count; cursor[c] = start[c]
-__global__ void __launch_bounds__(1024) nn_scan_kernel(int ncell, const int *__restrict__ count,
-                                                       int *__restrict__ start, int *__restrict__ cursor)
+// start[c] = exclusive prefix of count, cursor[c] = start[c], in two coalesced passes over 1024-cell blocks (a single
+// block walking ~70 cells per thread was latency-bound at 60-150 us): pass 1 scans inside each block and records the
+// block totals, pass 2 adds the totals of the preceding blocks (at most 1024 of them: one per thread).
+__global__ void __launch_bounds__(1024) nn_scan_local_kernel(int ncell, const int *__restrict__ count,
+                                                             int *__restrict__ start, int *__restrict__ btot)
 {
     __shared__ int wsum[17];
-    const int per = (ncell + 1023) / 1024;
-    const int lo = min((int)threadIdx.x * per, ncell), hi = min(lo + per, ncell);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += count[i];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int v = i < ncell ? count[i] : 0;
     int total;
-    int base = block_exclusive_scan(s, wsum, &total);
-    for (int i = lo; i < hi; ++i) {
-        start[i] = base;
-        cursor[i] = base;
-        base += count[i];
+    const int ex = block_exclusive_scan(v, wsum, &total);
+    if (i < ncell) start[i] = ex;
+    if (threadIdx.x == 0) btot[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) nn_scan_offset_kernel(int ncell, const int *__restrict__ btot,
+                                                              int *__restrict__ start, int *__restrict__ cursor)
+{
+    __shared__ int wsum[17];
+    const int mine = (int)threadIdx.x < (int)blockIdx.x ? btot[threadIdx.x] : 0;      // blocks before this one
+    const int last = (int)threadIdx.x < (int)gridDim.x ? btot[threadIdx.x] : 0;       // all blocks (for the grand total)
+    int before, all;
+    block_exclusive_scan(mine, wsum, &before);
+    __syncthreads();
+    block_exclusive_scan(last, wsum, &all);
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < ncell) {
+        const int s = start[i] + before;
+        start[i] = s;
+        cursor[i] = s;
     }
-    if (threadIdx.x == 0) start[ncell] = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) start[ncell] = all;
 }
 
 __global__ void nn_fill_kernel(int m, const float *__restrict__ known, NnBins g, int *__restrict__ cursor,
@@ -246,7 +261,7 @@ extern "C" int sassd_three_nn(int n, int m, const float *unknown, const float *k
 }
 
 namespace {
-struct NnLayout { size_t count, start, cursor, sorted, rows, total; int ncell; };
+struct NnLayout { size_t count, start, cursor, btot, sorted, rows, total; int ncell; };
 NnLayout nn_layout(int m, int nx, int ny, int nb)
 {
     NnLayout L;
@@ -255,6 +270,7 @@ NnLayout nn_layout(int m, int nx, int ny, int nb)
     L.count = o;  o = align_up(o + (size_t)L.ncell * 4, 256);
     L.start = o;  o = align_up(o + (size_t)(L.ncell + 1) * 4, 256);
     L.cursor = o; o = align_up(o + (size_t)L.ncell * 4, 256);
+    L.btot = o;   o = align_up(o + (size_t)1024 * 4, 256);
     L.sorted = o; o = align_up(o + (size_t)(m > 0 ? m : 1) * 16, 256);
     L.rows = o;   o = align_up(o + (size_t)(m > 0 ? m : 1) * 4, 256);
     L.total = o;
@@ -287,7 +303,10 @@ extern "C" int sassd_three_nn_binned(int n, int m, const float *unknown, const f
     g.nx = nx; g.ny = ny; g.nb = batch_size; g.x0 = x0; g.y0 = y0; g.cell = cell;
     if (hipMemsetAsync(count, 0, (size_t)L.ncell * 4, s) != hipSuccess) return sassd_launch_status();
     if (m > 0) hipLaunchKernelGGL(nn_count_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, m, known, g, count);
-    hipLaunchKernelGGL(nn_scan_kernel, dim3(1), dim3(1024), 0, s, L.ncell, count, start, cursor);
+    int *btot = (int *)(ws + L.btot);
+    const int nsb = cdiv(L.ncell, 1024);                       // <= 1024 (nn_grid_ok)
+    hipLaunchKernelGGL(nn_scan_local_kernel, dim3(nsb), dim3(1024), 0, s, L.ncell, count, start, btot);
+    hipLaunchKernelGGL(nn_scan_offset_kernel, dim3(nsb), dim3(1024), 0, s, L.ncell, (const int *)btot, start, cursor);
     if (m > 0) hipLaunchKernelGGL(nn_fill_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, m, known, g, cursor, sorted, rows);
     hipLaunchKernelGGL(three_nn_binned_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, unknown, g, start, sorted, rows,
                        dist2, idx);

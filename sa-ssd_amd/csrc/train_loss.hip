@@ -317,6 +317,12 @@ __device__ __forceinline__ bool guided_flag(const GuidedArgs &P, int b, int a)
     return 1.f / (1.f + expf(-best)) > P.thr;              // sigmoid is monotone: max of sigmoids = sigmoid of max
 }
 
+__global__ void guided_iota_kernel(int64_t *sel, int cap, int n_anchors)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < cap) sel[(size_t)blockIdx.y * cap + p] = p < n_anchors ? p : 0;
+}
+
 __global__ void __launch_bounds__(256) guided_count_kernel(GuidedArgs P)
 {
     __shared__ int wc[4];
@@ -443,8 +449,9 @@ extern "C" int sassd_guided_select(const float *cls_preds, const uint8_t *anchor
     P.cls = cls_preds; P.mask = anchor_mask; P.A = n_anchors; P.B = batch; P.NC = num_class; P.cap = cap;
     P.nblk = cdiv(n_anchors, 256); P.thr = score_thr; P.sel = sel; P.cnt = counts; P.overflow = overflow;
     P.blk = (int *)workspace;
-    int rc;
-    if ((rc = sassd_hip(hipMemsetAsync(sel, 0, (size_t)batch * cap * sizeof(int64_t), s)))) return rc;
+    // padding entries: sel[b][p] = p (valid, DISTINCT anchor indices -- the backward of the gather that follows is a
+    // scatter-add, and thousands of padding rows aimed at one index would serialise on its atomics)
+    hipLaunchKernelGGL(guided_iota_kernel, dim3(cdiv(cap, 256), batch), dim3(256), 0, s, sel, cap, n_anchors);
     const dim3 grid(P.nblk, batch);
     hipLaunchKernelGGL(guided_count_kernel, grid, dim3(256), 0, s, P);
     hipLaunchKernelGGL(guided_emit_kernel, grid, dim3(256), 0, s, P);

@@ -799,7 +799,7 @@ def gather_pack(src_flat, index_map, dst):
 
 def guided_select(cls_preds, anchor_mask, score_thr, cap, overflow):
     """sassd_guided_select: cls_preds [B,A,NC], anchor_mask [B,A] (bool / uint8) or None -> (sel [B,cap] int64 ascending
-    anchor indices, zero padded; counts [B] int32).  `overflow` is a persistent [1] int32 device flag."""
+    anchor indices, padded with sel[b][p] = p; counts [B] int32).  `overflow` is a persistent [1] int32 device flag."""
     _chk_cuda(cls_preds, anchor_mask, overflow)
     b, a, nc = cls_preds.shape
     dev = cls_preds.device

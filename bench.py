@@ -152,13 +152,14 @@ def main_train(args):
         return train.device_batch([clouds[k] for k in ids], [gts[k] for k in ids], [types[k] for k in ids], ["Car"],
                                   anchors, anchors_bv, synth.KITTI_VOXEL, synth.KITTI_RANGE, model=model)
 
-    state = {"batch": make_batch(0)}
+    make_next = train.SideStreamPrefetch(make_batch)        # data preparation on its own stream: its host reads of
+    state = {"batch": make_batch(0)}                        # row counts do not drain the training step
 
     def one(i):
         # the next batch (device voxelize, anchor masks, rulebooks -- the host syncs) is built between this step's
         # forward and backward
         loss, terms, state["batch"] = train.train_one_iter(model, opt, sched, sync, state["batch"], i,
-                                                           prefetch=lambda: make_batch(i + 1))
+                                                           prefetch=lambda: make_next(i + 1))
         return loss, terms
 
     def barrier():

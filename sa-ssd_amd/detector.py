@@ -506,6 +506,26 @@ class SSDRotateHead(nn.Module):
             f.zero_()
             raise RuntimeError("guided anchors exceeded the padded capacity: raise train_cfg.rpn.guided_cap")
 
+    def poll_guided_capacity(self):
+        """check_guided_capacity without blocking: the flag travels to pinned host memory by an asynchronous copy and is
+        looked at once that copy has completed (i.e. an overflow is reported a step or two after it happened)."""
+        f = getattr(self, "_guided_overflow", None)
+        if f is None:
+            return
+        st = getattr(self, "_guided_poll", None)
+        if st is not None and st[1].query():
+            if int(st[0][0]) != 0:
+                f.zero_()
+                self._guided_poll = None
+                raise RuntimeError("guided anchors exceeded the padded capacity: raise train_cfg.rpn.guided_cap")
+            st = None
+        if st is None:
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            host.copy_(f, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._guided_poll = (host, ev)
+
     def get_guided_anchors(self, box_preds, cls_preds, dir_cls_preds, anchors, anchors_mask, gt_bboxes, gt_labels,
                            thr=.1):
         """ssd_rotate_head.py:316-388, module-level torch path used by training (gradients flow into box_preds;

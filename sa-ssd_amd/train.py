@@ -346,6 +346,44 @@ class GradSync:
         self._launched = [False] * len(self.ranges)
 
 
+def _record_stream(obj, stream):
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+    elif hasattr(obj, "buf") and torch.is_tensor(getattr(obj, "buf")):        # kernels.HashTable
+        _record_stream(obj.buf, stream)
+
+
+class SideStreamPrefetch:
+    """Builds the next batch (device voxelizer, anchor masks, rulebooks: kernels plus a few host reads of row counts)
+    on its own HIP stream.  The host reads then wait only for the data-preparation kernels, not for the training
+    step queued on the main stream -- with everything on one stream each `.item()` drained the whole step and the GPU
+    idled while the host prepared the batch and began queueing the backward pass.  The main stream waits for the side
+    stream's event before it touches the batch; every tensor of the batch is recorded on the main stream so that the
+    caching allocator does not hand its memory to the next side-stream batch while main-stream kernels still read it."""
+
+    def __init__(self, build):
+        self.build = build
+        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    def __call__(self, *args, **kw):
+        if self.stream is None:
+            return self.build(*args, **kw)
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.stream):
+            batch = self.build(*args, **kw)
+            done = self.stream.record_event()
+        main.wait_event(done)
+        _record_stream(batch, main)
+        return batch
+
+
 def parse_losses(losses):
     """train_utils/__init__.py:8-25 without the per-term .item() host syncs: (total loss tensor, detached terms)."""
     terms = {k: (v.mean() if torch.is_tensor(v) else sum(x.mean() for x in v)) for k, v in losses.items()}
@@ -363,8 +401,8 @@ def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None):
     optimizer.zero_grad()
     loss, terms = parse_losses(model(**batch))
     nxt = prefetch() if prefetch is not None else None
-    if prefetch is not None and hasattr(getattr(model, "rpn_head", None), "check_guided_capacity"):
-        model.rpn_head.check_guided_capacity()       # prefetch synchronised already: reading the flag costs nothing
+    if hasattr(getattr(model, "rpn_head", None), "poll_guided_capacity"):
+        model.rpn_head.poll_guided_capacity()        # non-blocking: reports an overflow a step or two late
     loss.backward()
     sync.all_reduce_grads()
     optimizer.step()

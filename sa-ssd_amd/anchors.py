@@ -76,4 +76,5 @@ def rbbox2d_to_near_bbox(rbboxes):
     rots = rbboxes[..., -1]
     swap = (np.abs(limit_period(rots, 0.5, np.pi)) > np.pi / 4)[..., np.newaxis]
     cen = np.where(swap, rbboxes[:, [0, 1, 3, 2]], rbboxes[:, :4])
-    return np.concatenate([cen[:, :2] - cen[:, 2:] / 2, cen[:, :2] + cen[:, 2:] / 2], axis=-1)
+    # (fancy column indexing above leaves Fortran-ordered arrays behind: hand out a C-contiguous [N,4])
+    return np.ascontiguousarray(np.concatenate([cen[:, :2] - cen[:, 2:] / 2, cen[:, :2] + cen[:, 2:] / 2], axis=-1))

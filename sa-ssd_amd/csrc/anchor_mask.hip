@@ -111,18 +111,15 @@ extern "C" size_t sassd_anchor_mask_workspace_bytes(int H0, int W0)
     return align_up((size_t)H0 * W0 * 4, 256) + align_up((size_t)nseg * W0 * 4, 256);
 }
 
-// `batch` samples in ONE launch sequence: sample b owns coordinate rows [row_offsets[b], row_offsets[b+1]) of `coors`,
+namespace {
+// One launch sequence for `batch` samples: sample b owns the coordinate rows [rb[b], re[b]) of `coors` (rb == NULL: 0),
 // mask[b*n_anchors ..] and one sassd_anchor_mask_workspace_bytes slice of the workspace.
-extern "C" int sassd_anchor_mask_batch(const int32_t *coors, const int32_t *row_offsets, int batch, int H0, int W0,
-                                       const float *anchors_bv, int n_anchors, const float *voxel_size,
-                                       const float *coors_range, float area_threshold, uint8_t *mask, void *workspace,
-                                       size_t workspace_bytes, void *stream_)
+int anchor_mask_run(const int32_t *coors, const int32_t *rb, const int32_t *re, int batch, int H0, int W0,
+                    const float *anchors_bv, int n_anchors, const float *voxel_size, const float *coors_range,
+                    float area_threshold, uint8_t *mask, void *workspace, size_t workspace_bytes, hipStream_t stream)
 {
-    if (!coors || !row_offsets || !anchors_bv || !voxel_size || !coors_range || !mask || !workspace) return SASSD_EINVAL;
-    if (H0 < 1 || W0 < 1 || n_anchors < 1 || batch < 1 || batch > 65535) return SASSD_EINVAL;
     const size_t per = sassd_anchor_mask_workspace_bytes(H0, W0);
     if (workspace_bytes < per * batch) return SASSD_ENOSPC;
-    hipStream_t stream = (hipStream_t)stream_;
     const size_t gbytes = align_up((size_t)H0 * W0 * 4, 256);
     unsigned *grid = (unsigned *)workspace;                                   // [batch] grids, then [batch] segment sums
     unsigned *seg = (unsigned *)((char *)workspace + gbytes * batch);
@@ -132,8 +129,8 @@ extern "C" int sassd_anchor_mask_batch(const int32_t *coors, const int32_t *row_
     if ((rc = sassd_hip(hipMemsetAsync(grid, 0, gbytes * batch, stream)))) return rc;
     // the voxel count of one cloud never exceeds H0*W0*D; launch for a generous fixed bound and exit early
     const int max_rows = 1 << 18;
-    hipLaunchKernelGGL(am_scatter_kernel, dim3(cdiv(max_rows, 256), 1, batch), dim3(256), 0, stream, coors, row_offsets,
-                       row_offsets + 1, W0, grid, gstride);
+    hipLaunchKernelGGL(am_scatter_kernel, dim3(cdiv(max_rows, 256), 1, batch), dim3(256), 0, stream, coors, rb, re, W0,
+                       grid, gstride);
     hipLaunchKernelGGL(am_rowscan_kernel, dim3(H0, 1, batch), dim3(256), 0, stream, grid, W0, gstride);
     hipLaunchKernelGGL(am_colseg_kernel, dim3(cdiv(W0, 256), nseg, batch), dim3(256), 0, stream, grid, H0, W0, seg, gstride,
                        sstride);
@@ -145,6 +142,19 @@ extern "C" int sassd_anchor_mask_batch(const int32_t *coors, const int32_t *row_
                        (const unsigned *)grid, (const unsigned *)seg, mask, gstride, sstride);
     return sassd_launch_status();
 }
+}  // namespace
+
+// `batch` samples in ONE launch sequence: sample b owns coordinate rows [row_offsets[b], row_offsets[b+1]) of `coors`
+extern "C" int sassd_anchor_mask_batch(const int32_t *coors, const int32_t *row_offsets, int batch, int H0, int W0,
+                                       const float *anchors_bv, int n_anchors, const float *voxel_size,
+                                       const float *coors_range, float area_threshold, uint8_t *mask, void *workspace,
+                                       size_t workspace_bytes, void *stream_)
+{
+    if (!coors || !row_offsets || !anchors_bv || !voxel_size || !coors_range || !mask || !workspace) return SASSD_EINVAL;
+    if (H0 < 1 || W0 < 1 || n_anchors < 1 || batch < 1 || batch > 65535) return SASSD_EINVAL;
+    return anchor_mask_run(coors, row_offsets, row_offsets + 1, batch, H0, W0, anchors_bv, n_anchors, voxel_size,
+                           coors_range, area_threshold, mask, workspace, workspace_bytes, (hipStream_t)stream_);
+}
 
 extern "C" int sassd_anchor_mask(const int32_t *coors, const int32_t *row_begin_ptr, const int32_t *row_end_ptr,
                                  int H0, int W0, const float *anchors_bv, int n_anchors, const float *voxel_size,
@@ -153,25 +163,6 @@ extern "C" int sassd_anchor_mask(const int32_t *coors, const int32_t *row_begin_
 {
     if (!coors || !row_end_ptr || !anchors_bv || !voxel_size || !coors_range || !mask || !workspace) return SASSD_EINVAL;
     if (H0 < 1 || W0 < 1 || n_anchors < 1) return SASSD_EINVAL;
-    if (workspace_bytes < sassd_anchor_mask_workspace_bytes(H0, W0)) return SASSD_ENOSPC;
-    hipStream_t stream = (hipStream_t)stream_;
-    const size_t gbytes = align_up((size_t)H0 * W0 * 4, 256);
-    unsigned *grid = (unsigned *)workspace;
-    unsigned *seg = (unsigned *)((char *)workspace + gbytes);
-    const int nseg = cdiv(H0, kRB);
-    int rc;
-    if ((rc = sassd_hip(hipMemsetAsync(grid, 0, (size_t)H0 * W0 * 4, stream)))) return rc;
-    const int max_rows = 1 << 18;
-    hipLaunchKernelGGL(am_scatter_kernel, dim3(cdiv(max_rows, 256)), dim3(256), 0, stream, coors, row_begin_ptr,
-                       row_end_ptr, W0, grid, (size_t)0);
-    hipLaunchKernelGGL(am_rowscan_kernel, dim3(H0), dim3(256), 0, stream, grid, W0, (size_t)0);
-    hipLaunchKernelGGL(am_colseg_kernel, dim3(cdiv(W0, 256), nseg), dim3(256), 0, stream, grid, H0, W0, seg, (size_t)0,
-                       (size_t)0);
-    hipLaunchKernelGGL(am_segscan_kernel, dim3(cdiv(W0, 256)), dim3(256), 0, stream, seg, nseg, W0, (size_t)0);
-    AmParams P;
-    P.vs0 = voxel_size[0]; P.vs1 = voxel_size[1]; P.off0 = coors_range[0]; P.off1 = coors_range[1];
-    P.thr = area_threshold; P.H0 = H0; P.W0 = W0; P.n = n_anchors;
-    hipLaunchKernelGGL(am_anchor_kernel, dim3(cdiv(n_anchors, 256)), dim3(256), 0, stream, anchors_bv, P,
-                       (const unsigned *)grid, (const unsigned *)seg, mask, (size_t)0, (size_t)0);
-    return sassd_launch_status();
+    return anchor_mask_run(coors, row_begin_ptr, row_end_ptr, 1, H0, W0, anchors_bv, n_anchors, voxel_size, coors_range,
+                           area_threshold, mask, workspace, workspace_bytes, (hipStream_t)stream_);
 }

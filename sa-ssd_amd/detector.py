@@ -473,7 +473,7 @@ class SSDRotateHead(nn.Module):
         if isinstance(anchors_mask, dict):
             anchors_mask = torch.cat(list(anchors_mask.values()), 1)
         a = anchors.view(b, -1, 7).shape[1]
-        cap = int(cap) if cap else min(a, 8192)
+        cap = min(int(cap), a) if cap else a        # default: every anchor fits (padding rows cost next to nothing)
         mask = anchors_mask.view(b, -1)
         mask = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
         if getattr(self, "_guided_overflow", None) is None or self._guided_overflow.device != dev:

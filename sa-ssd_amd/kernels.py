@@ -484,6 +484,8 @@ def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False, bf16=False):
 # --------------------------------------------------------------------------------------------------
 def anchor_mask(coors, row_begin_ptr, row_end_ptr, h0, w0, anchors_bv, voxel_size, coors_range, area_threshold,
                 mask=None):
+    _chk_cuda(coors, row_begin_ptr, row_end_ptr, anchors_bv, mask)      # raw pointers: row-major [A,4] fp32 or nothing
+    assert anchors_bv.dtype == torch.float32 and anchors_bv.shape[1] == 4 and coors.dtype == torch.int32
     dev = coors.device
     L = _C.lib()
     n = anchors_bv.shape[0]
@@ -501,6 +503,8 @@ def anchor_mask(coors, row_begin_ptr, row_end_ptr, h0, w0, anchors_bv, voxel_siz
 
 def anchor_mask_batch(coors, row_offsets, batch, h0, w0, anchors_bv, voxel_size, coors_range, area_threshold, mask):
     """anchors_mask of `batch` samples in one launch sequence (row_offsets: device int32 [batch+1])."""
+    _chk_cuda(coors, row_offsets, anchors_bv, mask)
+    assert anchors_bv.dtype == torch.float32 and anchors_bv.shape[1] == 4 and coors.dtype == torch.int32
     L = _C.lib()
     n = anchors_bv.shape[0]
     vs, cr = _f32(voxel_size), _f32(coors_range)

@@ -364,3 +364,33 @@ def test_iou3d_utils_nms_gpu_facade(dev):
     keep_ref = clib.nms_rotated(b[order], 0.1)
     got = iou3d_utils.nms_gpu(torch.from_numpy(b).to(dev), torch.from_numpy(sc).to(dev), 0.1).cpu().numpy()
     assert np.array_equal(got, order[np.asarray(keep_ref)])
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_anchor_mask_single_and_batch_vs_oracle(dev, seed):
+    """f-1: sassd_anchor_mask (per sample, what sassd.train.device_batch / the dataset call) and sassd_anchor_mask_batch
+    against the oracle's integral-image formulation (kitti.py:333-343, geometry.py:676-710), bit-exact."""
+    from sassd import synth
+    w = synth.workload("car")
+    bv = torch.from_numpy(w["anchors_bv"]).to(dev)
+    H0, W0 = 1600, 1408
+    refs, coors_all, offs = [], [], [0]
+    for b in range(2):
+        pts = synth.k21(seed + b)
+        r = K.voxelize(torch.from_numpy(pts).to(dev), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 20000, batch_idx=0,
+                       coors_cols=4, want_mean=False)
+        n = int(r["voxel_num"])
+        co = r["coors"][:n]
+        ref = onets.anchors_mask(co[:, 1:].cpu().numpy(), w["anchors_bv"], synth.KITTI_VOXEL, synth.KITTI_RANGE,
+                                 (W0, H0, 40), 1)
+        zero = torch.zeros(1, dtype=torch.int32, device=dev)
+        got = K.anchor_mask(r["coors"], zero, r["voxel_num"], H0, W0, bv, synth.KITTI_VOXEL, synth.KITTI_RANGE, 1)
+        assert 0.1 < ref.mean() < 0.9
+        assert np.array_equal(got.cpu().numpy().astype(bool), ref), (int(got.sum()), int(ref.sum()))
+        refs.append(ref)
+        coors_all.append(co)
+        offs.append(offs[-1] + n)
+    mask = torch.empty(2, bv.shape[0], dtype=torch.uint8, device=dev)
+    K.anchor_mask_batch(torch.cat(coors_all).contiguous(), torch.tensor(offs, dtype=torch.int32, device=dev), 2, H0, W0, bv,
+                        synth.KITTI_VOXEL, synth.KITTI_RANGE, 1, mask)
+    assert np.array_equal(mask.cpu().numpy().astype(bool), np.stack(refs))

@@ -275,7 +275,12 @@ def test_padded_guided_path_equals_list_path(dev):
         sum(v.sum() for v in losses.values()).backward()
         res[padded] = ({k: float(v.sum()) for k, v in losses.items()},
                        {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
-    model.rpn_head.check_guided_capacity()
+    model.rpn_head.check_guided_capacity()              # default capacity = all anchors: cannot overflow
+    model.train_cfg.rpn["guided_cap"] = 64               # a capacity that IS too small must be reported, not ignored
+    model(**batch)
+    with pytest.raises(RuntimeError, match="guided_cap"):
+        model.rpn_head.check_guided_capacity()
+    del model.train_cfg.rpn["guided_cap"]
     assert res[True][0].keys() == res[False][0].keys()
     for k, v in res[False][0].items():
         assert abs(res[True][0][k] - v) <= 2e-6 * max(1.0, abs(v)), (k, res[True][0][k], v)

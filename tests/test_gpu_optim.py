@@ -41,8 +41,8 @@ def test_adam_onecycle_trajectory(dev):
     for it in range(20):
         sched.step(it)
         opt.zero_grad()
-        for n in names:
-            params[n].grad.copy_(torch.from_numpy(O["grad%d/%s" % (it, n)]))
+        for n in names:          # zero_grad() leaves .grad = None; the optimizer gathers whatever autograd (or we) set
+            params[n].grad = torch.from_numpy(O["grad%d/%s" % (it, n)]).to(dev)
         opt.step()
         for n in names:
             ref = O["step%d/%s" % (it, n)]

@@ -38,9 +38,14 @@ for name in ("bench_inflight3", "bench_inflight1", "bench_multi", "bench_waymo",
         d = json_line(lg)
         if d:
             json.dump(d, open(os.path.join(DST, "%s_%s_under_rocprof.json" % (tag, name)), "w"), indent=1)
-d = json_line(os.path.join(SRC, "bench_default.log"))
-if d:
-    json.dump(d, open(os.path.join(DST, "%s_bench_default.json" % tag), "w"), indent=1)
+for name in ("bench_default", "bench_train_bf16", "bench_train_fp32"):
+    lg = os.path.join(SRC, name + ".log")
+    d = json_line(lg) if os.path.exists(lg) else None
+    if d:
+        json.dump(d, open(os.path.join(DST, "%s_%s.json" % (tag, name)), "w"), indent=1)
+bt = os.path.join(SRC, "bf16_conv_timing.json")
+if os.path.exists(bt) and os.path.getsize(bt) > 10:
+    shutil.copy(bt, os.path.join(DST, "%s_bf16_conv_timing.json" % tag))
 
 # Winograd F(4x4) GEMM launch: HBM-side traffic per launch
 f, nf = counter(os.path.join(SRC, "wino4_FETCH_SIZE.json"), "FETCH_SIZE", "wino4_gemm")

@@ -20,6 +20,9 @@ trace bench_inflight1 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseli
 trace bench_multi python $R/bench.py --config multi --steps 20 --warmup 5
 trace bench_waymo python $R/bench.py --config waymo --steps 20 --warmup 5
 trace bench_train python $R/bench.py --mode train --steps 10 --warmup 4
+timeout 600 python bench.py --mode train --steps 30 --warmup 6 > $O/bench_train_bf16.log 2>&1; echo "train bf16 rc=$?"
+timeout 600 python bench.py --mode train --precision fp32 --steps 30 --warmup 6 > $O/bench_train_fp32.log 2>&1; echo "train fp32 rc=$?"
+timeout 300 python tools/run_bf16_conv.py --ablate > $O/bf16_conv_timing.json 2>/dev/null; echo "bf16 timing rc=$?"
 pmc wino4 FETCH_SIZE python $R/tools/run_wino4.py --profile --reps 5
 pmc wino4 WRITE_SIZE python $R/tools/run_wino4.py --profile --reps 5
 pmc sparse_multi FETCH_SIZE python $R/tools/run_sparse_only.py --config multi --reps 3

@@ -178,6 +178,33 @@ def main_train(args):
     if rank != 0:
         return
     sps = args.steps * B * world / dt
+    # dominant kernel of the training step, timed live with events on the launch stream: the 3x3 BEV conv (14 launches
+    # per step, forward + data gradient) -- bf16 direct kernel, or the fp32 Winograd F(4x4) layer in fp32 mode
+    from sassd import kernels as K
+    xb = torch.randn(B, 256, 200, 176, device=dev)
+    wb = torch.randn(256, 256, 3, 3, device=dev) / 48
+    flops = 2.0 * B * 200 * 176 * 256 * 256 * 9
+    if args.precision == "bf16":
+        pk = K.conv2d_bf16_pack_weight(wb)
+        run, kname, peak = (lambda: K.conv2d_bf16_fwd(xb, pk, 256)), "conv2d_bf16_kernel (v_mfma_f32_32x32x16_bf16)", 2500.0
+    else:
+        pk = K.conv2d_wino4_pack_weight(wb)
+        run = lambda: K.conv2d_wino4_fwd(xb, pk, 256, None, None)
+        kname, peak = "wino4_in + wino4_gemm + wino4_out (fp32 MFMA, Winograd F(4x4): executed flops = direct / 4)", 157.3
+        flops /= 4.0
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    kms = e0.elapsed_time(e1) / 20
+    roof = dict(bound="mfma", kernel=kname, achieved=round(flops / kms / 1e9, 1), peak=peak, unit="TFLOP/s",
+                frac=round(flops / kms / 1e9 / peak, 4), ms_per_launch=round(kms, 4), traffic=None,
+                note="flops executed by one 256->256 3x3 BEV layer at batch %d / mean layer time (HIP events, 20 launches on "
+                     "the launch stream); 14 such layers per step (forward + data gradient)" % B)
     print(json.dumps({
         "metric": "KITTI-Car training samples/sec (whole job)", "value": round(sps, 3), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -188,6 +215,7 @@ def main_train(args):
                                % (B, "bf16 MFMA operands in the BEV convs (fwd/dgrad/wgrad; fp32 accumulation, master "
                                      "weights and activations), fp32 sparse trunk" if args.precision == "bf16" else "fp32"),
                    "global_batch": B * world, "parallelism": "ddp x%d (one flat-gradient RCCL all-reduce/step)" % world},
+        "roofline": roof,
         "final_loss": round(float(loss), 4), "loss_terms": {k: round(float(v), 4) for k, v in terms.items()}}))
 
 

@@ -468,6 +468,22 @@ int sassd_noise_per_box(const float *boxes, const uint8_t *valid, const double *
  *                   non-NULL and max_norm > 0 (torch clip_grad_norm_ semantics), else grad * grad_scale;
  *                   p *= 1 - wd*lr; m,v Adam moments; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
  *                   `step` is t >= 1.  All pointers 16-byte aligned. */
+/* Training-mode BatchNorm1d + ReLU of the sparse blocks (cmn.py:147-173: SubMConv3d / SparseConv3d -> BatchNorm1d(eps
+ * 1e-3, momentum 0.01) -> ReLU) over features x [n, C] row-major, two launches each way instead of torch's six.
+ *   fwd: y = relu((x - mean) * invstd * gamma + beta) with batch statistics (biased variance); save_mean / save_invstd [C]
+ *        are kept for the backward pass; running_mean / running_var (both or neither) are updated like torch (momentum,
+ *        unbiased variance).
+ *   bwd: dx, dgamma, dbeta from dy (gradient with respect to y) and the saved statistics.
+ * C % 4 == 0, 256 % C == 0.  Deterministic: block partials in double, reduced in a fixed order by every block of the
+ * second launch (no inter-workgroup hand-off inside a launch).  Workspace: sassd_bn_relu_workspace_bytes(C). */
+size_t sassd_bn_relu_workspace_bytes(int C);
+int sassd_bn_relu_fwd(const float *x, int n, int C, const float *gamma, const float *beta, float *running_mean,
+                      float *running_var, float momentum, float eps, float *y, float *save_mean, float *save_invstd,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int sassd_bn_relu_bwd(const float *x, const float *dy, int n, int C, const float *gamma, const float *beta,
+                      const float *save_mean, const float *save_invstd, float *dx, float *dgamma, float *dbeta,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for i < n; dst fp32, or bf16 (round-to-nearest-even) when bf16 != 0: every
  * kernel-layout weight image is a permutation (+ zero padding) of the flat parameter buffer, so ONE gather re-packs all
  * of them after an optimizer step (sassd.train.PackPlan). */

@@ -122,6 +122,9 @@ _SIGS = {
     "sassd_paste_objects": (_I, [_P, _P, _P, _I, C.c_int64, _P, _P, _P, _P]),
     "sassd_box_collision_test": (_I, [_P, _I, _P, _I, _I, _P]),
     "sassd_noise_per_box": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "sassd_bn_relu_workspace_bytes": (_SZ, [_I]),
+    "sassd_bn_relu_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _SZ, _P]),
+    "sassd_bn_relu_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "sassd_gather_pack": (_I, [_P, _P, _P, C.c_long, _I, _P]),
     "sassd_grad_sumsq": (_I, [_P, C.c_long, _P, _P]),
     "sassd_adam_step": (_I, [_P, _P, _P, _P, C.c_long, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P]),

@@ -278,3 +278,23 @@ class PSWarpBatchFn(Function):
         feat, boxes, counts = ctx.saved_tensors
         dfeat, dg = K.pswarp_sample_bwd(feat, boxes, counts, boxes.shape[1], ctx.args[0], ctx.args[1], dlog.contiguous())
         return dfeat, dg, None, None, None
+
+
+class BnReluFn(Function):
+    """Training-mode BatchNorm1d + ReLU over sparse features [N, C] in two launches each way (sassd_bn_relu_fwd / _bwd);
+    the running statistics of the module are updated in place like torch.nn.functional.batch_norm(training=True)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        x = x.contiguous()
+        y, mean, invstd = K.bn_relu_fwd(x, gamma.detach().contiguous(), beta.detach().contiguous(), running_mean,
+                                        running_var, momentum, eps)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        dx, dg, db = K.bn_relu_bwd(x, dy.contiguous(), gamma.detach().contiguous(), beta.detach().contiguous(), mean,
+                                   invstd)
+        return dx, dg, db, None, None, None, None

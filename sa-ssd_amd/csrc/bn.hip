@@ -1,0 +1,265 @@
+// bn.hip -- training-mode BatchNorm1d + ReLU over sparse-tensor features [N, C] (row-major), forward and backward.
+//
+// The reference's sparse blocks are  SubMConv3d / SparseConv3d -> BatchNorm1d(eps 1e-3, momentum 0.01) -> ReLU
+// (mmdet/models/necks/cmn.py:147-173 through spconv.SparseSequential): in training mode torch runs them as
+// collect-statistics + transform + clamp (forward) and threshold + reduce + elementwise (backward), six launches per
+// layer over a 1-9 MB tensor, i.e. launch latency.  Here: two launches each way.
+//   forward   bn_stats_kernel      per-channel sum / sum of squares in double -> one partial pair per block
+//             bn_apply_relu_kernel every block first reduces the <= 256 block partials in a fixed order (deterministic;
+//                                  no inter-workgroup hand-off inside a launch) to mean / invstd in LDS, block 0 also
+//                                  stores them and updates the running statistics (unbiased variance, like torch);
+//                                  then y = max(0, (x - mean) * invstd * gamma + beta)
+//   backward  bn_bwd_reduce_kernel dz = dy * (z > 0) with z recomputed from x; partials of sum dz, sum dz * xhat
+//             bn_bwd_apply_kernel  reduces them the same way (block 0 stores dbeta, dgamma), then
+//                                  dx = gamma * invstd * (dz - dbeta / N - xhat * dgamma / N)
+// C is a multiple of 4 and at most 256 (the sparse trunk has 16 / 32 / 64).
+#include "common.h"
+
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBnMaxBlocks = 256;
+
+struct BnFwdArgs {
+    const float *x;
+    int n, C, nb, rows_per_block;
+    double *part;            // [nb][2][C]
+    float *mean, *invstd;    // [C] saved for the backward pass
+    float *rmean, *rvar;     // running statistics (may be null)
+    float momentum, eps;
+};
+
+// 256 threads = (256 / C) row lanes x C channels
+__global__ void __launch_bounds__(256) bn_stats_kernel(BnFwdArgs P)
+{
+    __shared__ double red[2][256];
+    const int C = P.C, rl = 256 / C;
+    const int c = threadIdx.x % C, r = threadIdx.x / C;
+    const int r0 = blockIdx.x * P.rows_per_block, r1 = min(r0 + P.rows_per_block, P.n);
+    double s = 0.0, q = 0.0;
+    if (r < rl)
+        for (int row = r0 + r; row < r1; row += rl) {
+            const double v = (double)P.x[(size_t)row * C + c];
+            s += v;
+            q += v * v;
+        }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double ss = 0.0, qq = 0.0;
+        for (int k = 0; k < rl; ++k) { ss += red[0][k * C + threadIdx.x]; qq += red[1][k * C + threadIdx.x]; }
+        P.part[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = ss;
+        P.part[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = qq;
+    }
+}
+
+// sums of the block partials for every channel, identical in every block: thread (r, c) adds the partials of blocks
+// r, r + rl, ... in order, the rl partial sums are combined in order of r
+__device__ __forceinline__ void bn_reduce_partials(const double *part, int nb, int C, double (*red)[256], double *out0,
+                                                   double *out1)
+{
+    const int rl = 256 / C, c = threadIdx.x % C, r = threadIdx.x / C;
+    double a = 0.0, b = 0.0;
+    for (int k = r; k < nb; k += rl) {
+        a += part[((size_t)k * 2 + 0) * C + c];
+        b += part[((size_t)k * 2 + 1) * C + c];
+    }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double sa = 0.0, sb = 0.0;
+        for (int k = 0; k < rl; ++k) { sa += red[0][k * C + threadIdx.x]; sb += red[1][k * C + threadIdx.x]; }
+        *out0 = sa;
+        *out1 = sb;
+    }
+}
+
+struct BnApplyArgs {
+    const float *x;
+    int n, C, nb;
+    const double *part;
+    const float *gamma, *beta;
+    float *y, *mean, *invstd, *rmean, *rvar;
+    float momentum, eps;
+};
+
+__global__ void __launch_bounds__(256) bn_apply_relu_kernel(BnApplyArgs P)
+{
+    __shared__ double red[2][256];
+    __shared__ float s_mean[256], s_scale[256], s_shift[256];
+    const int C = P.C;
+    double ss = 0.0, qq = 0.0;
+    bn_reduce_partials(P.part, P.nb, C, red, &ss, &qq);
+    if (threadIdx.x < C) {
+        const double mean = ss / P.n;
+        double var = qq / P.n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mean, is = (float)(1.0 / sqrt(var + (double)P.eps));
+        s_mean[threadIdx.x] = m;
+        s_scale[threadIdx.x] = is * P.gamma[threadIdx.x];
+        s_shift[threadIdx.x] = P.beta[threadIdx.x];
+        if (blockIdx.x == 0) {
+            P.mean[threadIdx.x] = m;
+            P.invstd[threadIdx.x] = is;
+            if (P.rmean) {
+                const double unb = P.n > 1 ? var * P.n / (P.n - 1) : var;
+                P.rmean[threadIdx.x] = (float)((1.0 - P.momentum) * P.rmean[threadIdx.x] + P.momentum * mean);
+                P.rvar[threadIdx.x] = (float)((1.0 - P.momentum) * P.rvar[threadIdx.x] + P.momentum * unb);
+            }
+        }
+    }
+    __syncthreads();
+    const size_t total = (size_t)P.n * C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 v = ((const f32x4 *)P.x)[i];             // one float4 = 4 channels of one row
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = (v[j] - s_mean[c + j]) * s_scale[c + j] + s_shift[c + j];
+            o[j] = z > 0.f ? z : 0.f;
+        }
+        ((f32x4 *)P.y)[i] = o;
+    }
+}
+
+struct BnBwdArgs {
+    const float *x, *dy;
+    int n, C, nb, rows_per_block;
+    const float *mean, *invstd, *gamma, *beta;
+    double *part;            // [nb][2][C]
+    float *dx, *dgamma, *dbeta;
+};
+
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(BnBwdArgs P)
+{
+    __shared__ double red[2][256];
+    const int C = P.C, rl = 256 / C;
+    const int c = threadIdx.x % C, r = threadIdx.x / C;
+    const int r0 = blockIdx.x * P.rows_per_block, r1 = min(r0 + P.rows_per_block, P.n);
+    double sb = 0.0, sg = 0.0;
+    {
+        const float m = P.mean[c], is = P.invstd[c], g = P.gamma[c], b = P.beta[c];
+        for (int row = r0 + r; row < r1; row += rl) {
+            const float xh = (P.x[(size_t)row * C + c] - m) * is;
+            const float z = xh * g + b;
+            const float dz = z > 0.f ? P.dy[(size_t)row * C + c] : 0.f;
+            sb += (double)dz;
+            sg += (double)dz * (double)xh;
+        }
+    }
+    red[0][threadIdx.x] = sb;
+    red[1][threadIdx.x] = sg;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < rl; ++k) { a += red[0][k * C + threadIdx.x]; b += red[1][k * C + threadIdx.x]; }
+        P.part[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a;
+        P.part[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BnBwdArgs P)
+{
+    __shared__ double red[2][256];
+    __shared__ float s_mean[256], s_is[256], s_g[256], s_b[256], s_db[256], s_dg[256];
+    const int C = P.C;
+    double a = 0.0, b = 0.0;
+    bn_reduce_partials(P.part, P.nb, C, red, &a, &b);
+    if (threadIdx.x < C) {
+        s_mean[threadIdx.x] = P.mean[threadIdx.x];
+        s_is[threadIdx.x] = P.invstd[threadIdx.x];
+        s_g[threadIdx.x] = P.gamma[threadIdx.x];
+        s_b[threadIdx.x] = P.beta[threadIdx.x];
+        s_db[threadIdx.x] = (float)a;
+        s_dg[threadIdx.x] = (float)b;
+        if (blockIdx.x == 0) {
+            P.dbeta[threadIdx.x] = (float)a;
+            P.dgamma[threadIdx.x] = (float)b;
+        }
+    }
+    __syncthreads();
+    const float inv_n = 1.f / (float)P.n;
+    const size_t total = (size_t)P.n * C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 v = ((const f32x4 *)P.x)[i], g = ((const f32x4 *)P.dy)[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (v[j] - s_mean[c + j]) * s_is[c + j];
+            const float z = xh * s_g[c + j] + s_b[c + j];
+            const float dz = z > 0.f ? g[j] : 0.f;
+            o[j] = s_g[c + j] * s_is[c + j] * (dz - s_db[c + j] * inv_n - xh * s_dg[c + j] * inv_n);
+        }
+        ((f32x4 *)P.dx)[i] = o;
+    }
+}
+
+int bn_blocks(int n, int C, int *rows_per_block)
+{
+    const int rl = 256 / C;
+    int nb = cdiv(n, 16 * rl);                       // >= 16 row iterations per block
+    nb = nb < 1 ? 1 : (nb > kBnMaxBlocks ? kBnMaxBlocks : nb);
+    *rows_per_block = cdiv(n, nb);
+    return cdiv(n, *rows_per_block);
+}
+int bn_apply_blocks(int n, int C)
+{
+    const size_t total = (size_t)n * C / 4;
+    const size_t nb = (total + 1023) / 1024;         // >= 4 float4 per thread: the partial reduction is per block
+    return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+}
+bool bn_shape_ok(int n, int C) { return n >= 1 && C >= 4 && C <= 256 && C % 4 == 0 && 256 % C == 0; }
+}  // namespace
+
+extern "C" size_t sassd_bn_relu_workspace_bytes(int C)
+{
+    return C < 1 ? 0 : align_up((size_t)kBnMaxBlocks * 2 * C * sizeof(double), 256);
+}
+
+extern "C" int sassd_bn_relu_fwd(const float *x, int n, int C, const float *gamma, const float *beta,
+                                 float *running_mean, float *running_var, float momentum, float eps, float *y,
+                                 float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
+                                 void *stream_)
+{
+    if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace || !bn_shape_ok(n, C) ||
+        (!running_mean) != (!running_var))
+        return SASSD_EINVAL;
+    if (workspace_bytes < sassd_bn_relu_workspace_bytes(C)) return SASSD_ENOSPC;
+    hipStream_t s = (hipStream_t)stream_;
+    BnFwdArgs P;
+    P.x = x; P.n = n; P.C = C;
+    P.nb = bn_blocks(n, C, &P.rows_per_block);
+    P.part = (double *)workspace;
+    P.mean = save_mean; P.invstd = save_invstd; P.rmean = running_mean; P.rvar = running_var;
+    P.momentum = momentum; P.eps = eps;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(P.nb), dim3(256), 0, s, P);
+    BnApplyArgs Q;
+    Q.x = x; Q.n = n; Q.C = C; Q.nb = P.nb; Q.part = (const double *)workspace; Q.gamma = gamma; Q.beta = beta; Q.y = y;
+    Q.mean = save_mean; Q.invstd = save_invstd; Q.rmean = running_mean; Q.rvar = running_var;
+    Q.momentum = momentum; Q.eps = eps;
+    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(bn_apply_blocks(n, C)), dim3(256), 0, s, Q);
+    return sassd_launch_status();
+}
+
+extern "C" int sassd_bn_relu_bwd(const float *x, const float *dy, int n, int C, const float *gamma, const float *beta,
+                                 const float *save_mean, const float *save_invstd, float *dx, float *dgamma,
+                                 float *dbeta, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (!x || !dy || !gamma || !beta || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace ||
+        !bn_shape_ok(n, C))
+        return SASSD_EINVAL;
+    if (workspace_bytes < sassd_bn_relu_workspace_bytes(C)) return SASSD_ENOSPC;
+    hipStream_t s = (hipStream_t)stream_;
+    BnBwdArgs P;
+    P.x = x; P.dy = dy; P.n = n; P.C = C;
+    P.nb = bn_blocks(n, C, &P.rows_per_block);
+    P.mean = save_mean; P.invstd = save_invstd; P.gamma = gamma; P.beta = beta;
+    P.part = (double *)workspace;
+    P.dx = dx; P.dgamma = dgamma; P.dbeta = dbeta;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(P.nb), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(n, C)), dim3(256), 0, s, P);
+    return sassd_launch_status();
+}

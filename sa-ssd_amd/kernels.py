@@ -816,3 +816,40 @@ def guided_select(cls_preds, anchor_mask, score_thr, cap, overflow):
                                    _C.ptr(sel), _C.ptr(counts), _C.ptr(overflow), _C.ptr(ws), wsb, _C.stream()),
              "sassd_guided_select")
     return sel, counts
+
+
+# ---- fused BatchNorm1d + ReLU of the sparse blocks (bn.hip) -----------------------------------------------------------
+def _bn_workspace(dev):
+    return workspace("bn_relu", _C.lib().sassd_bn_relu_workspace_bytes(256), dev)
+
+
+def bn_relu_supported(n, c):
+    return n >= 1 and 4 <= c <= 256 and c % 4 == 0 and 256 % c == 0
+
+
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps):
+    """-> (y, save_mean, save_invstd); running statistics updated in place (pass None for both to skip)."""
+    _chk_cuda(x, gamma, beta, running_mean, running_var)
+    n, c = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = _bn_workspace(x.device)
+    _C.check(_C.lib().sassd_bn_relu_fwd(_C.ptr(x), n, c, _C.ptr(gamma), _C.ptr(beta), _C.ptr(running_mean),
+                                        _C.ptr(running_var), float(momentum), float(eps), _C.ptr(y), _C.ptr(mean),
+                                        _C.ptr(invstd), _C.ptr(ws), ws.numel(), _C.stream()), "sassd_bn_relu_fwd")
+    return y, mean, invstd
+
+
+def bn_relu_bwd(x, dy, gamma, beta, mean, invstd):
+    """-> (dx, dgamma, dbeta)."""
+    _chk_cuda(x, dy, gamma, beta, mean, invstd)
+    n, c = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = _bn_workspace(x.device)
+    _C.check(_C.lib().sassd_bn_relu_bwd(_C.ptr(x), _C.ptr(dy), n, c, _C.ptr(gamma), _C.ptr(beta), _C.ptr(mean),
+                                        _C.ptr(invstd), _C.ptr(dx), _C.ptr(dg), _C.ptr(db), _C.ptr(ws), ws.numel(),
+                                        _C.stream()), "sassd_bn_relu_bwd")
+    return dx, dg, db

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
-from .autograd import DensifyFn, SparseConvFn
+from .autograd import BnReluFn, DensifyFn, SparseConvFn
 
 
 class SparseConvTensor:
@@ -160,13 +160,30 @@ class SparseConv3d(SparseConvolution):
 class SparseSequential(nn.Sequential):
     """Sparse modules consume/produce SparseConvTensor; plain nn.Modules are applied to `.features`."""
 
+    fuse_bn_relu = True      # training: BatchNorm1d -> ReLU pairs run as one fused HIP forward / backward pair
+
     def forward(self, inp):
-        for m in self:
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
             if isinstance(m, SparseConvolution):
                 inp = m(inp)
             elif isinstance(inp, SparseConvTensor):
                 if inp.indices.shape[0] != 0:
-                    inp.features = m(inp.features)
+                    f = inp.features
+                    nxt = mods[i + 1] if i + 1 < len(mods) else None
+                    if (self.fuse_bn_relu and isinstance(m, nn.BatchNorm1d) and isinstance(nxt, nn.ReLU) and m.training
+                            and m.affine and m.track_running_stats and m.momentum is not None and f.is_cuda
+                            and f.dtype == torch.float32 and torch.is_grad_enabled()
+                            and K.bn_relu_supported(f.shape[0], f.shape[1])):
+                        inp.features = BnReluFn.apply(f, m.weight, m.bias, m.running_mean, m.running_var, m.momentum,
+                                                      m.eps)
+                        m.num_batches_tracked.add_(1)
+                        i += 2
+                        continue
+                    inp.features = m(f)
             else:
                 inp = m(inp)
+            i += 1
         return inp

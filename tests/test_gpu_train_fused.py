@@ -292,3 +292,41 @@ def test_padded_guided_path_equals_list_path(dev):
         worst = max(worst, d)
         assert d < 1e-4, (n, d)
     print("padded vs list guided path: worst relative gradient difference %.2e" % worst)
+
+
+@pytest.mark.parametrize("n,c", [(16111, 64), (18355, 32), (777, 16), (3, 64), (40000, 4)])
+def test_bn_relu_fused_matches_torch(dev, n, c):
+    """sassd_bn_relu_fwd / _bwd against torch BatchNorm1d(training) + ReLU: output, the three gradients and the running
+    statistics (fp32; sums in a different order: 2e-5 relative to each tensor's scale)."""
+    from sassd.autograd import BnReluFn
+    g = torch.Generator().manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g) * 1.7 + 0.4).to(dev)
+    dy = torch.randn(n, c, generator=g).to(dev)
+    bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g).to(dev) + 0.5)
+        bn.bias.copy_((torch.randn(c, generator=g) * 0.3).to(dev))
+        bn.running_mean.normal_(0, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    xr = x.clone().requires_grad_()
+    torch.relu(bn(xr)).backward(dy)
+    ref = (torch.relu(bn.forward(x)).detach() if False else None)
+    xf = x.clone().requires_grad_()
+    gam, bet = bn.weight.detach().clone().requires_grad_(), bn.bias.detach().clone().requires_grad_()
+    y = BnReluFn.apply(xf, gam, bet, rm, rv, 0.01, 1e-3)
+    y.backward(dy)
+    with torch.no_grad():
+        y_ref = torch.relu(torch.nn.functional.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.0, 1e-3))
+
+    def close(a, b, tol=2e-5):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= tol * scale, (float((a - b).abs().max()), scale)
+    close(y, y_ref)
+    close(xf.grad, xr.grad, 1e-4)
+    close(gam.grad, bn.weight.grad, 1e-4)
+    close(bet.grad, bn.bias.grad, 1e-4)
+    close(rm, bn.running_mean)
+    close(rv, bn.running_var)
+    y2 = BnReluFn.apply(x, gam.detach(), bet.detach(), None, None, 0.01, 1e-3)       # bit-reproducible, stats optional
+    assert torch.equal(y2, y.detach())

@@ -31,6 +31,30 @@ def test_argument_validation_returns_error_codes():
     assert L.sassd_adam_step(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 10, null, 1e-3, 0.9, 0.99,
                              1e-8, 0.01, 0, 10.0, 1.0, null) == EINVAL      # step counts from 1
     assert L.sassd_nms_gpu(null, 4, 0.1, null, null, null, 0, null) == EINVAL
+    # round-2 training entry points
+    p16 = C.c_void_p(16)
+    assert L.sassd_conv2d_bf16_fwd(null, null, null, null, 1, 32, 128, 8, 16, null) == EINVAL
+    assert L.sassd_conv2d_bf16_fwd(p16, p16, null, p16, 1, 32, 100, 8, 16, null) == EINVAL        # Cout % 32
+    assert L.sassd_conv2d_bf16_fwd(p16, p16, null, p16, 1, 32, 128, 8, 20, null) == EINVAL        # W % 16
+    assert L.sassd_conv2d_bwd_weight_bf16(p16, p16, p16, 1, 16, 16, 8, 9, 3, 0, p16, 1 << 30, null) == EINVAL   # odd W
+    assert L.sassd_conv2d_bwd_weight_bf16(p16, p16, p16, 1, 16, 16, 8, 8, 3, 0, p16, 4, null) == ENOSPC
+    assert L.sassd_assign_targets(null, 0, null, 100, 2, null, null, null, null, 0, null, null, 0.6, 0.45, null, null,
+                                  null, 100, null, 1, null, 0, null) == EINVAL
+    assert L.sassd_assign_targets(p16, 0, null, 100, 2, null, null, null, p16, 0, null, null, 0.6, 0.45, p16, p16,
+                                  null, 50, p16, 1, p16, 1 << 20, null) == EINVAL                  # output stride < anchors
+    assert L.sassd_assign_targets(p16, 0, null, 100, 2, null, null, null, p16, 0, null, null, 0.6, 0.45, p16, p16,
+                                  null, 100, p16, 1, p16, 8, null) == ENOSPC
+    assert L.sassd_rpn_loss(null, null, null, 1, null, null, null, 0, null, 100, 2, null, null, null, null, null, 0,
+                            null) == EINVAL
+    assert L.sassd_guided_select(p16, null, 100, 2, 1, 0.1, 0, p16, p16, p16, p16, 1 << 20, null) == EINVAL     # cap 0
+    assert L.sassd_guided_select(p16, null, 100, 2, 1, 0.1, 64, p16, p16, p16, p16, 1, null) == ENOSPC
+    assert L.sassd_bn_relu_fwd(p16, 100, 48, p16, p16, null, null, 0.01, 1e-3, p16, p16, p16, p16, 1 << 30,
+                               null) == EINVAL                                                     # 256 % C != 0
+    assert L.sassd_bn_relu_fwd(p16, 100, 64, p16, p16, p16, null, 0.01, 1e-3, p16, p16, p16, p16, 1 << 30,
+                               null) == EINVAL                                                     # one running stat only
+    assert L.sassd_bn_relu_bwd(p16, p16, 100, 64, p16, p16, p16, p16, p16, p16, p16, p16, 8, null) == ENOSPC
+    assert L.sassd_gather_pack(null, null, null, 10, 0, null) == EINVAL
+    assert L.sassd_gather_pack(p16, p16, p16, 0, 1, null) == 0
     # empty problems are not errors
     assert L.sassd_three_nn(0, 0, null, null, C.c_void_p(16), C.c_void_p(16), null) == 0
     assert L.sassd_rotate_iou_eval(null, 0, null, 0, -1, C.c_void_p(16), null) == 0
@@ -47,6 +71,13 @@ def test_host_side_queries():
     assert L.sassd_three_nn_binned_workspace_bytes(1000, 4096, 4096, 2) == 0          # grid too large
     assert L.sassd_spconv_bwd_weight_workspace_bytes(16111, 27, 64, 64) >= 126 * 27 * 64 * 64 * 4
     assert L.sassd_hash_bytes(20000) >= 2 * 20000 * 8
+    assert L.sassd_conv2d_bf16_supported(256, 256, 200, 176) == 1 and L.sassd_conv2d_bf16_supported(28, 256, 200, 176) == 1
+    assert L.sassd_conv2d_bf16_supported(256, 28, 200, 176) == 0 and L.sassd_conv2d_bf16_supported(256, 256, 200, 180) == 0
+    assert L.sassd_conv2d_bf16_packed_elems(28, 256) == 9 * 32 * 256          # Cin padded to 32 inside the pack
+    assert L.sassd_assign_targets_workspace_bytes(2, 70400, 16) >= 2 * 70400 * 8 + 16 * 4
+    assert L.sassd_rpn_loss_workspace_bytes(2, 70400) == 2 * 275 * 3 * 4
+    assert L.sassd_guided_select_workspace_bytes(2, 70400) == 2 * 275 * 4
+    assert L.sassd_bn_relu_workspace_bytes(64) >= 256 * 2 * 64 * 8
 
 
 def test_bench_refuses_a_mismatched_launch():

@@ -204,3 +204,37 @@ def test_rpn_loss_with_an_empty_sample():
     assert torch.isfinite(box.grad).all() and float(box.grad[1].abs().sum()) == 0.0     # no positives -> no box loss
     guided, labels = head.get_guided_anchors(box.detach(), cls.detach(), dr.detach(), anc, msk, gtb, gtl, thr=0.1)
     assert guided[1].shape[1] == 7 and len(labels[1]) == len(guided[1])
+
+
+def test_side_stream_prefetch_without_cuda_is_a_passthrough():
+    """sassd.train.SideStreamPrefetch on a machine without a GPU just calls the builder (the stream logic is covered by
+    bench.py --mode train on the GPU box)."""
+    from sassd import train
+    calls = []
+
+    def build(i, k=0):
+        calls.append((i, k))
+        return dict(a=torch.zeros(2), b=[torch.ones(1), (torch.ones(1), None)])
+    pf = train.SideStreamPrefetch(build)
+    if not torch.cuda.is_available():
+        assert pf.stream is None
+    out = pf(3, k=4)
+    assert calls == [(3, 4)] and set(out) == {"a", "b"}
+    train._record_stream(out, None)            # CPU tensors: nothing to record, nested containers are walked
+
+
+def test_flat_params_collects_lazily():
+    """zero_grad() -> None gradients; backward leaves per-parameter tensors; `flat.grad` gathers them (one multi-tensor
+    copy), re-points .grad at the views, and a parameter without a gradient reads as zeros."""
+    from sassd import train
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    f = train.FlatParams(m)
+    f.zero_grad()
+    m[0](torch.ones(5, 4)).sum().backward()    # only the first layer receives gradients
+    own = m[0].weight.grad
+    assert own.data_ptr() != f._grad.data_ptr()
+    g = f.grad
+    assert m[0].weight.grad.data_ptr() == g.data_ptr() and torch.equal(m[0].weight.grad, own)
+    assert float(m[1].weight.grad.abs().sum()) == 0 and float(g[f.offsets[2]:].abs().sum()) == 0
+    f.collect()                                 # idempotent
+    assert torch.equal(m[0].weight.grad, own)

@@ -160,7 +160,12 @@ class SparseConv3d(SparseConvolution):
 class SparseSequential(nn.Sequential):
     """Sparse modules consume/produce SparseConvTensor; plain nn.Modules are applied to `.features`."""
 
-    fuse_bn_relu = True      # training: BatchNorm1d -> ReLU pairs run as one fused HIP forward / backward pair
+    # Opt-in: run training-mode BatchNorm1d -> ReLU pairs as one fused HIP forward / backward pair (sassd_bn_relu_*,
+    # 2 launches each way instead of 6; +2 % training throughput).  Off by default: its statistics are accumulated in
+    # double, which moves the result AWAY from the reference's fp32 torch BatchNorm by enough to fail the tightest
+    # whole-step parity case (three-class half-grid: 2.5e-3 instead of < 2e-3 on the tensors behind the sparse trunk, and
+    # one borderline guided anchor selected differently).  The unit tests hold the kernels to torch at 2e-5 / 1e-4.
+    fuse_bn_relu = False
 
     def forward(self, inp):
         mods = list(self)

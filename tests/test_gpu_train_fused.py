@@ -311,7 +311,6 @@ def test_bn_relu_fused_matches_torch(dev, n, c):
     rm, rv = bn.running_mean.clone(), bn.running_var.clone()
     xr = x.clone().requires_grad_()
     torch.relu(bn(xr)).backward(dy)
-    ref = (torch.relu(bn.forward(x)).detach() if False else None)
     xf = x.clone().requires_grad_()
     gam, bet = bn.weight.detach().clone().requires_grad_(), bn.bias.detach().clone().requires_grad_()
     y = BnReluFn.apply(xf, gam, bet, rm, rv, 0.01, 1e-3)

@@ -129,6 +129,9 @@ def main_train(args):
     anchor masks + forward_train + backward + flat-gradient all-reduce (RCCL) + fused clip/AdamW update."""
     from sassd import dist as D, train, anchors as A, autograd as AG
     AG.set_bev_precision(args.precision)
+    if args.fused_bn:
+        from sassd import spconv as SP
+        SP.SparseSequential.fuse_bn_relu = True
     rank, local_rank, world = D.init("nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -253,6 +256,8 @@ def main():
                     help="car = configs[1] (headline); multi = configs[3] (batch 8); waymo = configs[4] shape (batch 4)")
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
                     help="--mode train: arithmetic of the dense BEV convolutions (BASELINE configs[2] trains in bf16)")
+    ap.add_argument("--fused-bn", action="store_true", help="--mode train: opt into the fused sparse BatchNorm1d + ReLU "
+                    "kernels (sassd.spconv.SparseSequential.fuse_bn_relu)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)

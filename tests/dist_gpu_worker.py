@@ -25,9 +25,13 @@ def main():
     torch.distributed.broadcast(ref, src=0)
     assert torch.equal(ref, opt.flat.data), "parameter broadcast"
     x = torch.randn(32, 64, device=dev) * (rank + 1)
+    # local gradient WITHOUT the exchange: autograd.grad does not run the post-accumulate hooks that launch the buckets
+    gl = torch.autograd.grad(m(x).pow(2).mean(), opt.flat.params)
+    local = torch.zeros_like(opt.flat.data)
+    for g, o in zip(gl, opt.flat.offsets):
+        local[o:o + g.numel()] = g.reshape(-1)
     opt.zero_grad()
-    m(x).pow(2).mean().backward()
-    local = opt.flat.grad.clone()
+    m(x).pow(2).mean().backward()                 # buckets go out from the gradient hooks during this backward
     sync.all_reduce_grads()
     total = local.clone()
     torch.distributed.all_reduce(total)

@@ -681,6 +681,13 @@ class SingleStageDetector(nn.Module):
             from .train import load_params_from_file      # accepts the reference's 'module.'-prefixed checkpoints
             load_params_from_file(self, pretrained, to_cpu=True)
 
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .float(): the parameters become new tensors -- cached weight images and the plan are stale."""
+        out = super()._apply(fn, *args, **kwargs)
+        K.bump_weights_generation()
+        self._plan, self._plan_key = None, None
+        return out
+
     def train(self, mode=True):
         if mode:
             self._plan, self._plan_key = None, None      # weights are about to change: the folded plan is stale
@@ -787,4 +794,7 @@ class SingleStageDetector(nn.Module):
 
 def build_detector(cfg, train_cfg=None, test_cfg=None):
     """mmdet/models/builder.py:54-56."""
+    # a new model: packed-weight caches are keyed on (address, version, generation) -- a fresh parameter may land on the
+    # address of a dead one, so start a new generation
+    K.bump_weights_generation()
     return obj_from_dict(cfg, sys.modules[__name__], dict(train_cfg=train_cfg, test_cfg=test_cfg))

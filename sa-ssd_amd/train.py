@@ -45,6 +45,7 @@ class FlatParams:
             self.gviews.append(self._grad[o:o + n].view(p.shape))
             p.grad = self.gviews[-1]
         self._gptr = [v.data_ptr() for v in self.gviews]
+        K.bump_weights_generation()       # every parameter just moved: no cached weight image may survive this
 
     @property
     def grad(self):

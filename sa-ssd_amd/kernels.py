@@ -53,6 +53,11 @@ def workspace(name, nbytes, device):
     return t
 
 
+def scoped_workspaces(owner):
+    """The scratch buffers currently handed out under workspace scope `owner` (a captured hipGraph keeps them alive)."""
+    return [t for (name, dev, scope), t in _ws_cache.items() if scope == owner]
+
+
 def _f32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 

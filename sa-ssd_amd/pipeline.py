@@ -408,13 +408,19 @@ class InferencePlan:
             frame()                               # warm-up: every workspace / lazily created event exists
             cap.synchronize()
             self.graph = K.Graph().capture(frame)
+        # the graph holds raw pointers into this plan's grow-only kernel workspaces: keep the tensors it was captured
+        # with alive, so that a later eager call that regrows a workspace cannot free memory the graph still replays on
+        self._graph_ws = K.scoped_workspaces(self._wsid)
         torch.cuda.current_stream(dev).wait_stream(cap)
         return self.graph
 
     def stage_inputs(self, clouds):
         for b, pts in enumerate(clouds or ()):
-            n = min(pts.shape[0], self.pts_cap)
-            self.pts_in[b][:n].copy_(pts[:n], non_blocking=True)
+            n = pts.shape[0]
+            if n > self.pts_cap:            # never detect on a silently truncated cloud
+                raise ValueError("cloud %d has %d points, the captured graph was sized for %d (plan.capture(points_cap))"
+                                 % (b, n, self.pts_cap))
+            self.pts_in[b][:n].copy_(pts, non_blocking=True)
             self.npts[b:b + 1].fill_(n)
 
     def run_graph(self, clouds=None):

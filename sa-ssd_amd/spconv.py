@@ -72,6 +72,11 @@ class SparseConvolution(nn.Module):
         self._packed = None
         self._packed_version = None
 
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)      # .to() / .cuda() on this layer alone: its packed image is stale
+        K.bump_weights_generation()
+        return out
+
     def reset_parameters(self):
         n = self.in_channels * int(np.prod(self.kernel_size))
         stdv = 1.0 / math.sqrt(n)

@@ -265,6 +265,7 @@ def build_optimizer(model, optim_cfg, world_size=1):
                        world_size=world_size)
     if opt.flat.data.is_cuda and optim_cfg.get("pack_plan", True):
         opt.pack_plan = PackPlan(model, opt.flat)
+        opt.flat.pack_plan = opt.pack_plan        # GradSync re-runs it after the parameter broadcast
     return opt
 
 
@@ -285,21 +286,31 @@ def build_warmup_scheduler(optimizer, optim_cfg, lr_cfg):
 class GradSync:
     """Data-parallel exchange over the flat buffers (RCCL over xGMI with backend 'nccl', gloo in CPU tests).
 
-    Parameters are broadcast once from rank 0.  Gradients: the flat gradient buffer is cut into `buckets` contiguous
-    ranges on parameter boundaries; a post-accumulate hook on every parameter counts its bucket down and launches the
-    bucket's asynchronous all-reduce as soon as the last of its gradients has been written, so the exchange of the
-    layers whose backward ran first (the heads, the BEV stack) overlaps the backward of the sparse backbone.
-    `all_reduce_grads()` launches whatever is still pending (parameters that received no gradient) and waits.  With
-    one bucket, or `overlap=False`, it is the single whole-model all-reduce of SURVEY 8e.  The sum is left in the
-    buffer; the 1/world mean is folded into the update kernel."""
+    Parameters are broadcast once from rank 0 (every cached weight image is invalidated and the optimizer's PackPlan
+    re-run afterwards: the broadcast writes the flat buffer without moving any autograd version).  Gradients: the flat
+    gradient buffer is cut into `buckets` contiguous ranges on parameter boundaries; a post-accumulate hook on every
+    parameter counts its bucket down, and buckets are launched as asynchronous all-reduces IN A FIXED ORDER -- last
+    bucket first, the order in which backward completes them -- a bucket only once it is complete AND every bucket before
+    it in that order has been launched.  RCCL / gloo match collectives by issue order per communicator, so the order
+    must not depend on which parameters happened to receive a gradient on a rank (an empty sparse level skips its
+    BatchNorm; a sample without boxes skips a head).  `all_reduce_grads()` launches what is still pending in the same
+    order and waits.  The exchange of the layers whose backward ran first (heads, BEV stack) overlaps the backward of
+    the sparse backbone.  With one bucket, or `overlap=False`, it is the single whole-model all-reduce of SURVEY 8e.
+    The sum is left in the buffer; the 1/world mean is folded into the update kernel.  `comm_ms()` reports the time of
+    the last exchange between the first launch and the last completion (stream events; CUDA/HIP only)."""
 
-    def __init__(self, flat, buckets=4, overlap=True):
+    def __init__(self, flat, buckets=4, overlap=True, time_comm=False):
         self.flat = flat
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.ranges, self.works, self._hooks = [], [], []
+        self.time_comm, self._ev = bool(time_comm), None
         if not self.on:
             return
         dist.broadcast(flat.data, src=0)
+        K.bump_weights_generation()           # raw write into every parameter: no packed image may survive it
+        plan = getattr(flat, "pack_plan", None)
+        if plan is not None:
+            plan.run()
         n = len(flat.params)
         buckets = max(1, min(int(buckets), n))
         target = flat.numel / buckets
@@ -311,8 +322,8 @@ class GradSync:
                 self.ranges.append((start, i + 1, flat.offsets[start], end_f))
                 start = i + 1
         self.overlap = bool(overlap) and len(self.ranges) > 1
-        self._left = [hi - lo for lo, hi, _, _ in self.ranges]
-        self._launched = [False] * len(self.ranges)
+        self.order = list(range(len(self.ranges) - 1, -1, -1))       # backward reaches the last parameters first
+        self._reset_counters()
         if self.overlap:
             owner = {}
             for b, (lo, hi, _, _) in enumerate(self.ranges):
@@ -321,30 +332,63 @@ class GradSync:
             for i, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(owner[i])))
 
+    def _reset_counters(self):
+        self._left = [hi - lo for lo, hi, _, _ in self.ranges]
+        self._launched = [False] * len(self.ranges)
+        self._next = 0
+
+    def reset(self):
+        """Start of a step: finish whatever an aborted step left in flight, forget its bookkeeping."""
+        if not self.on:
+            return
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self._reset_counters()
+
     def _make_hook(self, b):
         def hook(_param):
             self._left[b] -= 1
-            if self._left[b] == 0:
-                self._launch(b)
+            self._advance()
         return hook
+
+    def _advance(self, force=False):
+        """Launch, in the fixed order, every bucket that is complete (all of them with `force`)."""
+        while self._next < len(self.order):
+            b = self.order[self._next]
+            if not force and self._left[b] > 0:
+                return
+            self._launch(b)
+            self._next += 1
 
     def _launch(self, b):
         if not self._launched[b]:
             plo, phi, lo, hi = self.ranges[b]
             self.flat.collect(plo, phi)                       # this bucket's gradients -> the flat buffer
+            if self.time_comm and not self.works and self.flat._grad.is_cuda:
+                self._ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+                self._ev[0].record()
             self.works.append(dist.all_reduce(self.flat._grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
             self._launched[b] = True
 
     def all_reduce_grads(self):
         if not self.on:
             return
-        for b in range(len(self.ranges)):
-            self._launch(b)
+        self._advance(force=True)
         for w in self.works:
             w.wait()
+        if self._ev is not None:
+            self._ev[1].record()
         self.works = []
-        self._left = [hi - lo for lo, hi, _, _ in self.ranges]
-        self._launched = [False] * len(self.ranges)
+        self._reset_counters()
+
+    def comm_ms(self):
+        """First bucket launch -> all buckets complete on the compute stream, of the last timed exchange (None if
+        timing is off / not yet run).  Synchronises on the end event."""
+        if self._ev is None:
+            return None
+        self._ev[1].synchronize()
+        return self._ev[0].elapsed_time(self._ev[1])
 
 
 def _record_stream(obj, stream):
@@ -367,17 +411,24 @@ class SideStreamPrefetch:
     step queued on the main stream -- with everything on one stream each `.item()` drained the whole step and the GPU
     idled while the host prepared the batch and began queueing the backward pass.  The main stream waits for the side
     stream's event before it touches the batch; every tensor of the batch is recorded on the main stream so that the
-    caching allocator does not hand its memory to the next side-stream batch while main-stream kernels still read it."""
+    caching allocator does not hand its memory to the next side-stream batch while main-stream kernels still read it.
+    Every build -- the first one included -- should go through the prefetcher: the cached kernel workspaces of the
+    builder then belong to this object's workspace scope, are allocated under the side stream and never touched from
+    another stream; the first build waits once for the main stream (inputs uploaded there)."""
 
     def __init__(self, build):
         self.build = build
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self._first = True
 
     def __call__(self, *args, **kw):
         if self.stream is None:
             return self.build(*args, **kw)
         main = torch.cuda.current_stream()
-        with torch.cuda.stream(self.stream):
+        if self._first:
+            self.stream.wait_stream(main)
+            self._first = False
+        with torch.cuda.stream(self.stream), K.ws_scope(("prefetch", id(self))):
             batch = self.build(*args, **kw)
             done = self.stream.record_event()
         main.wait_event(done)
@@ -399,6 +450,7 @@ def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None):
     waiting for it.  Returns (loss, loss terms[, next batch])."""
     scheduler.step(it)
     model.train()
+    sync.reset()
     optimizer.zero_grad()
     loss, terms = parse_losses(model(**batch))
     nxt = prefetch() if prefetch is not None else None

@@ -40,6 +40,28 @@ def main():
     w = opt.flat.data.clone()
     torch.distributed.broadcast(w, src=0)
     assert torch.equal(w, opt.flat.data), "weights diverged across ranks after the update"
+    # weight images after the broadcast: per-rank seeds differ, PackPlan ran BEFORE the broadcast inside
+    # build_optimizer -- every rank's packed images must be packs of the broadcast (rank 0) weights
+    from sassd import kernels as K, spconv
+    from sassd.detector import _HipConv2d
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.sp = spconv.SubMConv3d(16, 32, 3, bias=False, indice_key="k")
+            self.cv = _HipConv2d(32, 14, 1)
+
+    torch.manual_seed(200 + rank)
+    net = Net().to(dev)
+    opt2 = train.build_optimizer(net, dict(type="adam_onecycle", lr=1e-3, weight_decay=0.01), world)
+    assert opt2.pack_plan is not None
+    stale = net.sp.packed_weight().clone()
+    train.GradSync(opt2.flat, buckets=2)
+    fresh = K.spconv_pack_weight(net.sp.weight.detach().reshape(27, 16, 32).contiguous())
+    assert torch.equal(net.sp.packed_weight(), fresh), "sparse pack is not a pack of the broadcast weights"
+    assert torch.equal(net.cv.packed_weight(), K.conv2d_pack_weight(net.cv.weight.detach().contiguous()))
+    if rank != 0:
+        assert not torch.equal(stale, fresh), "per-rank seeds should differ"
     D.barrier()
     if rank == 0:
         print("RCCL_OK world=%d" % world)

@@ -80,7 +80,14 @@ def _grad_sync_worker(rank, world, port, q):
     torch.manual_seed(100 + rank)                                  # different initial weights per rank
     m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3, bias=False))
     flat = train.FlatParams(m)
+    from sassd import kernels as K
+    ran = []
+    flat.pack_plan = type("Plan", (), {"run": lambda self: ran.append(flat.data.clone())})()
+    gen0 = K.weights_generation()
     sync = train.GradSync(flat, buckets=3)                         # broadcast from rank 0; bucketed, overlapped exchange
+    # the broadcast wrote every parameter through the flat buffer: packed weight images are invalidated and the
+    # optimizer's PackPlan re-runs on the BROADCAST weights (ranks != 0 kept pre-broadcast packs)
+    assert K.weights_generation() > gen0 and len(ran) == 1 and torch.equal(ran[0], flat.data)
     assert len(sync.ranges) >= 2 and sync.overlap
     assert sync.ranges[0][2] == 0 and sync.ranges[-1][3] == flat.numel
     assert all(a[3] == b[2] for a, b in zip(sync.ranges, sync.ranges[1:]))       # the ranges tile the flat buffer
@@ -104,7 +111,22 @@ def _grad_sync_worker(rank, world, port, q):
         h.remove()
     m(x).pow(2).sum().backward()
     local = flat.grad.clone()
-    q.put((rank, w0.numpy(), local.numpy(), reds[0].numpy()))
+    # a parameter without a gradient on ONE rank must not change the order in which buckets are exchanged
+    la, lb, lc = (torch.nn.Linear(4, 4) for _ in range(3))
+    flat2 = train.FlatParams(torch.nn.Sequential(la, lb, lc))
+    sync2 = train.GradSync(flat2, buckets=3)
+    assert len(sync2.ranges) == 3 and sync2.order == [2, 1, 0]
+    x2 = torch.arange(8.).view(2, 4) * (rank + 1)
+    sync2.reset()
+    flat2.zero_grad()
+    (lc(la(x2)) if rank == 0 else lc(lb(la(x2)))).sum().backward()      # rank 0 never touches lb
+    sync2.all_reduce_grads()
+    red2 = flat2.grad.clone()
+    flat2.zero_grad()
+    for h in sync2._hooks:
+        h.remove()
+    (lc(la(x2)) if rank == 0 else lc(lb(la(x2)))).sum().backward()
+    q.put((rank, w0.numpy(), local.numpy(), reds[0].numpy(), flat2.grad.clone().numpy(), red2.numpy()))
     D.barrier()
 
 
@@ -120,8 +142,8 @@ def test_gradient_all_reduce_world2():
         p.start()
     got = dict()
     for _ in range(2):
-        r, w0, local, red = q.get(timeout=180)
-        got[r] = (w0, local, red)
+        r, w0, local, red, local2, red2 = q.get(timeout=180)
+        got[r] = (w0, local, red, local2, red2)
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
@@ -129,3 +151,6 @@ def test_gradient_all_reduce_world2():
     assert not np.array_equal(got[0][1], got[1][1])                # different shards -> different local gradients
     assert np.allclose(got[0][2], got[0][1] + got[1][1], rtol=1e-6, atol=1e-6)
     assert np.array_equal(got[0][2], got[1][2])
+    # bucket order is fixed: rank 0's missing gradient (zeros) + rank 1's, bucket by bucket
+    assert np.abs(got[0][3][20:40]).max() == 0 and np.abs(got[1][3][20:40]).max() > 0
+    assert np.allclose(got[0][4], got[0][3] + got[1][3], rtol=1e-6, atol=1e-6) and np.array_equal(got[0][4], got[1][4])

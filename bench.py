@@ -12,7 +12,13 @@ across ranks with no data-path collective (weak scaling); value = frames of all 
   --config car    BASELINE configs[1] (HEADLINE, default): car_cfg inference, batch 1, fp32, K21 frames
   --config multi  configs[3]: multi_cfg (Car+Ped+Cyclist) inference, batch 8
   --config waymo  configs[4] shape, inference side: 180k-point frames, 0.1 m voxels, batch 4 per GPU
-  --mode train    configs[2] shape: car_cfg training step, batch 2 per GPU, DDP (extra measurement)
+  --mode train    the training record alone: configs[2] (car_cfg, batch 2 per GPU, bf16, DDP); with --config waymo
+                  configs[4] (180k-point frames, 0.1 m voxels, batch 4 per GPU)
+
+The default run (car) measures BOTH halves of BASELINE.json's metric: after the inference timing every rank runs the
+configs[2] training step (--train-steps / --train-warmup) and the record -- samples/s, ms per step (max over ranks and
+per rank), all-reduce time, the six loss terms, the roofline of the dominant training kernel -- rides in the same JSON
+line as `train` (--no-train skips it).
 
 By default three frames are in flight per GPU (--inflight): independent plans / graphs on separate HIP streams, so one
 frame's latency-bound sparse / post stages overlap another frame's MFMA-bound BEV stage; each frame is still a batch-1
@@ -27,6 +33,9 @@ The JSON line also carries:
                    transform + GEMM + output transform).
   roofline_sparse  7 rulebooks + 14 sparse convs against the HBM roofline (B_gs bytes of SURVEY 8d), timed as a
                    hipGraph of exactly that segment.
+  traffic          PMC counters cannot be collected inside this process: they come from the committed records under
+                   profiles/, each stamped with the hash of the kernel sources it was measured on; a record whose stamp
+                   differs from the sources of the library in use is dropped (`traffic_measured_at` says so).
   cpu_baseline     the CPU oracle (a faithful port: C voxelizer / NMS + torch-CPU sparse and dense convs) on this box's
                    host cores, 3 warm-ups + >= 20 timed frames, median + per-stage ms (rank 0, N = 1, car only).
 """
@@ -111,52 +120,77 @@ def cpu_baseline(model, w, warm=3, runs=20, budget_s=60.0):
                        "threads; value = 1000 / median ms" % (warm, len(total), torch.get_num_threads()))
 
 
-def synth_gt_on_points(cloud, seed, n=8):
+def synth_gt_on_points(cloud, seed, n=8, config="car"):
     """Car-sized ground-truth boxes centred on occupied voxels of the frame (so anchors get positive matches and the
     localisation / direction losses are exercised): x,y,z bottom centre, w,l,h,ry."""
     r = np.random.default_rng(seed)
     c = cloud[r.choice(len(cloud), n, replace=False), :3]
     b = np.zeros((n, 7), np.float32)
-    b[:, 0], b[:, 1] = np.clip(c[:, 0], 3, 67), np.clip(c[:, 1], -37, 37)
+    if config == "waymo":
+        b[:, 0], b[:, 1] = np.clip(c[:, 0], -70, 70), np.clip(c[:, 1], -70, 70)
+    else:
+        b[:, 0], b[:, 1] = np.clip(c[:, 0], 3, 67), np.clip(c[:, 1], -37, 37)
     b[:, 2] = r.uniform(-1.9, -1.5, n)
     b[:, 3], b[:, 4], b[:, 5] = r.uniform(1.5, 1.8, n), r.uniform(3.5, 4.4, n), r.uniform(1.4, 1.7, n)
     b[:, 6] = r.choice([0.0, 1.57, -1.57, 3.1], n) + r.uniform(-0.2, 0.2, n)
     return b
 
 
-def main_train(args):
-    """--mode train: BASELINE configs[2] shape (car_cfg training, batch 2 / GPU, DDP).  A step = device voxelize +
-    anchor masks + forward_train + backward + flat-gradient all-reduce (RCCL) + fused clip/AdamW update."""
-    from sassd import dist as D, train, anchors as A, autograd as AG
-    AG.set_bev_precision(args.precision)
-    if args.fused_bn:
+def csrc_hash():
+    from sassd import _C
+    return _C.csrc_hash()
+
+
+def stamped_traffic(fname):
+    """(record, measured_at) of a committed PMC traffic file; the record is dropped (None) when the file carries no
+    `csrc_hash` or one that differs from the sources of the library in use -- a stale counter must not ride along."""
+    path = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(path):
+        return None, None
+    rec = json.load(open(path))
+    at = rec.get("csrc_hash")
+    if at is None or at != csrc_hash():
+        return None, "%s: measured at csrc %s, library built from %s -> dropped" % (fname, at, csrc_hash())
+    return rec, "%s @ csrc %s" % (fname, at)
+
+
+def train_measure(args, dev, rank, world, config="car", precision="bf16", steps=40, warmup=8, batch=0, frames=16,
+                  fused_bn=None):
+    """The training half of the BASELINE metric.  config "car": BASELINE configs[2] (car_cfg training, batch 2 / GPU,
+    bf16 MFMA operands in the BEV convs); "waymo": configs[4] (180k-point frames, 0.1 m voxels, batch 4 / GPU).
+    A step = device voxelize + anchor masks + rulebooks (side stream) + forward_train + backward + bucketed gradient
+    all-reduce (RCCL) + fused clip / AdamW update + one-launch weight re-pack.  Returns the `train` record
+    (rank 0; None on the other ranks).  Reference loop: tools/train_utils/__init__.py:36-61, DDP wrap tools/train.py:78."""
+    from sassd import dist as D, train, autograd as AG
+    AG.set_bev_precision(precision)
+    if fused_bn is not None:
         from sassd import spconv as SP
-        SP.SparseSequential.fuse_bn_relu = True
-    rank, local_rank, world = D.init("nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    w = synth.workload("car")
+        SP.SparseSequential.fuse_bn_relu = bool(fused_bn)
+    w = synth.workload(config)
     model, cfg = synth.build_detector_for(w, 0, train=True, cls_bias=-3.0)
     model = model.to(dev)
-    B = args.batch if args.batch > 1 else 2
+    B = batch if batch > 0 else (4 if config == "waymo" else 2)
     anchors = dict(Car=torch.from_numpy(w["anchors"]).to(dev))
     anchors_bv = dict(Car=torch.from_numpy(w["anchors_bv"]).to(dev))
     opt = train.build_optimizer(model, cfg.optimizer, world)
-    sched = train.build_scheduler(opt, args.steps + args.warmup, 1, cfg.optimizer, cfg.lr_config)
-    sync = train.GradSync(opt.flat)
-    nf = max(args.frames, B)
-    host = [synth.k21(rank * 1000 + i) for i in range(nf)]
+    sched = train.build_scheduler(opt, steps + warmup, 1, cfg.optimizer, cfg.lr_config)
+    sync = train.GradSync(opt.flat, time_comm=True)
+    nf = max(min(frames, 8) if config == "waymo" else frames, B)
+    host = [w["frame"](rank * 1000 + i) for i in range(nf)]
     clouds = [torch.from_numpy(p).to(dev) for p in host]
-    gts = [torch.from_numpy(synth_gt_on_points(p, rank * 1000 + i)).to(dev) for i, p in enumerate(host)]
-    types = [np.array(["Car"] * 8) for _ in range(nf)]
+    ngt = 12 if config == "waymo" else 8
+    gts = [torch.from_numpy(synth_gt_on_points(p, rank * 1000 + i, ngt, config)).to(dev) for i, p in enumerate(host)]
+    types = [np.array(["Car"] * ngt) for _ in range(nf)]
+    cal = w["cal"]
 
     def make_batch(i):
         ids = [(i * B + j) % nf for j in range(B)]
         return train.device_batch([clouds[k] for k in ids], [gts[k] for k in ids], [types[k] for k in ids], ["Car"],
-                                  anchors, anchors_bv, synth.KITTI_VOXEL, synth.KITTI_RANGE, model=model)
+                                  anchors, anchors_bv, cal["voxel_size"], cal["pc_range"], max_points=cal["max_points"],
+                                  max_voxels=cal["max_voxels"], model=model)
 
     make_next = train.SideStreamPrefetch(make_batch)        # data preparation on its own stream: its host reads of
-    state = {"batch": make_batch(0)}                        # row counts do not drain the training step
+    state = {"batch": make_next(0)}                         # row counts do not drain the training step
 
     def one(i):
         # the next batch (device voxelize, anchor masks, rulebooks -- the host syncs) is built between this step's
@@ -170,29 +204,35 @@ def main_train(args):
         D.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         loss, _ = one(i)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss, terms = one(args.warmup + i)
+    comm = []
+    for i in range(steps):
+        loss, terms = one(warmup + i)
+        if world > 1 and i >= steps - 5:
+            comm.append(sync.comm_ms())                 # (synchronises on the exchange's end event: last steps only)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     barrier()
     dt = D.allreduce_max(time.perf_counter() - t0, dev)
-    if rank != 0:
-        return
-    sps = args.steps * B * world / dt
+    per_rank = D.allgather_float(dt_local / steps * 1e3, dev) if world > 1 else [dt_local / steps * 1e3]
+    voxels = int(sum(v.shape[0] for v in state["batch"]["voxels"]))
     # dominant kernel of the training step, timed live with events on the launch stream: the 3x3 BEV conv (14 launches
-    # per step, forward + data gradient) -- bf16 direct kernel, or the fp32 Winograd F(4x4) layer in fp32 mode
+    # per step, forward + data gradient) -- bf16 direct kernel where the shape allows, else the fp32 Winograd F(4x4) layer
     from sassd import kernels as K
-    xb = torch.randn(B, 256, 200, 176, device=dev)
+    H, W = model.neck.sparse_shape[1] // 8, model.neck.sparse_shape[2] // 8
+    xb = torch.randn(B, 256, H, W, device=dev)
     wb = torch.randn(256, 256, 3, 3, device=dev) / 48
-    flops = 2.0 * B * 200 * 176 * 256 * 256 * 9
-    if args.precision == "bf16":
+    flops = 2.0 * B * H * W * 256 * 256 * 9
+    bf16_conv = precision == "bf16" and K.conv2d_bf16_supported(256, 256, H, W)
+    if bf16_conv:
         pk = K.conv2d_bf16_pack_weight(wb)
         run, kname, peak = (lambda: K.conv2d_bf16_fwd(xb, pk, 256)), "conv2d_bf16_kernel (v_mfma_f32_32x32x16_bf16)", 2500.0
     else:
         pk = K.conv2d_wino4_pack_weight(wb)
-        run = lambda: K.conv2d_wino4_fwd(xb, pk, 256, None, None)
+        run = lambda: K.conv2d_wino4_fwd(xb, pk, 256, None, None)       # noqa: E731
         kname, peak = "wino4_in + wino4_gemm + wino4_out (fp32 MFMA, Winograd F(4x4): executed flops = direct / 4)", 157.3
         flops /= 4.0
     for _ in range(3):
@@ -204,22 +244,55 @@ def main_train(args):
     e1.record()
     torch.cuda.synchronize()
     kms = e0.elapsed_time(e1) / 20
+    del xb, wb
+    if rank != 0:
+        return None
+    sps = steps * B * world / dt
+    traffic, at = (None, None)
+    if bf16_conv and B == 2 and config == "car":
+        rec, at = stamped_traffic("r03_bf16_conv_hbm_traffic.json")
+        traffic = rec["traffic_bytes_per_launch"] if rec else None
     roof = dict(bound="mfma", kernel=kname, achieved=round(flops / kms / 1e9, 1), peak=peak, unit="TFLOP/s",
-                frac=round(flops / kms / 1e9 / peak, 4), ms_per_launch=round(kms, 4), traffic=None,
-                note="flops executed by one 256->256 3x3 BEV layer at batch %d / mean layer time (HIP events, 20 launches on "
-                     "the launch stream); 14 such layers per step (forward + data gradient)" % B)
-    print(json.dumps({
-        "metric": "KITTI-Car training samples/sec (whole job)", "value": round(sps, 3), "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                frac=round(flops / kms / 1e9 / peak, 4), ms_per_launch=round(kms, 4), traffic=traffic,
+                traffic_measured_at=at,
+                note="flops executed by one 256->256 3x3 BEV layer at batch %d (%dx%d map) / mean layer time (HIP events, 20 "
+                     "launches on the launch stream); 14 such layers per step (forward + data gradient)" % (B, H, W))
+    bev = ("bf16 MFMA operands in the BEV convs (fwd/dgrad/wgrad; fp32 accumulation, master weights and activations), "
+           "fp32 sparse trunk" if bf16_conv else
+           "bf16 weight gradients, fp32 Winograd forward / data gradient (the bf16 direct conv needs W %% 16 == 0, the "
+           "BEV map is %dx%d), fp32 sparse trunk" % (H, W) if precision == "bf16" else "fp32")
+    desc = ("configs/car_cfg.py training, batch=%d/GPU, %s, synthetic lidar64 K21 frames + 8 synthetic car boxes/frame "
+            "on occupied voxels, adam_onecycle, grad clip 10" % (B, bev)) if config == "car" else (
+            "Waymo-scale synthetic training (BASELINE configs[4]): car head, batch=%d/GPU, 180000 pts/frame, 0.1x0.1x0.15 "
+            "m voxels (grid 40x1504x1504, %d active voxels in the last batch), BEV 188x188, %s, 12 synthetic car "
+            "boxes/frame on occupied voxels, adam_onecycle, grad clip 10" % (B, voxels, bev))
+    return {
+        "metric": "%s training samples/sec (whole job)" % ("KITTI-Car" if config == "car" else "Waymo-scale synthetic"),
+        "value": round(sps, 3), "unit": "samples/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+        "ms_per_step_per_rank": [round(v, 3) for v in per_rank],
+        "allreduce_ms": None if not comm else round(float(np.mean([c for c in comm if c is not None])), 3),
+        "allreduce_note": "first gradient-bucket launch -> last bucket complete on the compute stream (4 buckets launched "
+                          "from backward hooks, so most of it overlaps the sparse backward); null at 1 GPU",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": "configs/car_cfg.py training, batch=%d/GPU, %s, synthetic lidar64 K21 frames + 8 "
-                               "synthetic car boxes/frame on occupied voxels, adam_onecycle, grad clip 10"
-                               % (B, "bf16 MFMA operands in the BEV convs (fwd/dgrad/wgrad; fp32 accumulation, master "
-                                     "weights and activations), fp32 sparse trunk" if args.precision == "bf16" else "fp32"),
-                   "global_batch": B * world, "parallelism": "ddp x%d (one flat-gradient RCCL all-reduce/step)" % world},
+        "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": desc, "global_batch": B * world,
+                   "parallelism": "ddp x%d (flat-gradient RCCL all-reduce in 4 buckets / step)" % world},
         "roofline": roof,
-        "final_loss": round(float(loss), 4), "loss_terms": {k: round(float(v), 4) for k, v in terms.items()}}))
+        "final_loss": round(float(loss), 4), "loss_terms": {k: round(float(v), 4) for k, v in terms.items()}}
+
+
+def main_train(args):
+    """--mode train: the training record as the JSON line (configs[2] by default, configs[4] with --config waymo)."""
+    from sassd import dist as D
+    rank, local_rank, world = D.init("nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    out = train_measure(args, dev, rank, world, "waymo" if args.config == "waymo" else "car", args.precision,
+                        args.steps, args.warmup, args.batch if args.batch > 1 else 0, args.frames,
+                        True if args.fused_bn else None)
+    if rank == 0:
+        print(json.dumps(out))
 
 
 def respawn_under_torchrun(args):
@@ -262,6 +335,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="default (car) run: skip the `train` record (BASELINE "
+                    "configs[2], the training half of the metric) that follows the inference measurement")
+    ap.add_argument("--train-steps", type=int, default=40, help="timed training steps of the default run's `train` record")
+    ap.add_argument("--train-warmup", type=int, default=8)
     ap.add_argument("--frames", type=int, default=16, help="distinct synthetic frames cycled through")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight: independent plans on separate HIP "
                     "streams, so one frame's latency-bound sparse stage overlaps another frame's MFMA-bound BEV stage")
@@ -392,7 +469,29 @@ def main():
                 torch.cuda.synchronize()
                 w4_parts[name] = e0.elapsed_time(e1) / 20
             K.debug_set_wino4(0, 0)
+    headline = args.config == "car" and B == 1
+    # ---- the training half of BASELINE.json's metric (configs[2]: car_cfg, batch 2 / GPU, bf16, DDP): every rank takes
+    # part (gradient all-reduce over RCCL at N > 1); the record rides in the same JSON line as `train` ------------------
+    emit = {}
+    if headline and not args.no_train and not args.eager:
+        import threading
+
+        def give_up():                                       # a hung collective must not cost the inference line
+            if rank == 0 and "line" in emit:
+                emit["line"]["train"] = {"error": "training measurement exceeded %d s (hung collective?)" % 420}
+                print(json.dumps(emit["line"]), flush=True)
+            os._exit(0 if rank == 0 else 1)
+        watchdog = threading.Timer(420.0, give_up)
+        watchdog.daemon = True
+    else:
+        watchdog = None
     if rank != 0:
+        if watchdog is not None:
+            watchdog.start()
+            try:
+                train_measure(args, dev, rank, world, "car", "bf16", args.train_steps, args.train_warmup)
+            finally:
+                watchdog.cancel()
         return
     iso_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v][5:])) for k, v in prof_iso.items()}
     if sp_ms is None:
@@ -410,18 +509,16 @@ def main():
              0: "conv2d_kernel (BEV 256->256 3x3, direct, fp32 MFMA 32x32x2)"}[kind]
     bev_total_ms = sum(iso_ms["bev_conv%d" % i] for i in range(8))
     sp_gbs = (work["bytes_gs"] + work["rulebook_bytes"]) / (sp_ms * 1e-3) / 1e9
-    traffic = None                       # PMC passes cannot run inside this process: read the committed measurement
-    for tj in ("r02_wino4_gemm_hbm_traffic.json",):
-        tj = os.path.join(ROOT, "profiles", tj)
-        if os.path.exists(tj) and B == 1 and args.config == "car":
-            traffic = json.load(open(tj))["traffic_bytes_per_launch"]
-            break
-    sp_traffic = None                    # fabric-side bytes of one sparse pass (PMC passes, profiles/): 2 x FETCH + WRITE
-    tj = os.path.join(ROOT, "profiles", "r02_sparse_%s_hbm_traffic.json" % args.config)
-    if os.path.exists(tj) and B == w["batch"]:
-        t = json.load(open(tj))
-        sp_traffic = int((2 * t["FETCH_SIZE_kb_per_pass_raw"] + t["WRITE_SIZE_kb_per_pass_raw"]) * 1024)
-    headline = args.config == "car" and B == 1
+    # PMC passes cannot run inside this process: the committed measurement is read -- and dropped unless it was taken on
+    # the kernel sources this library was built from (`traffic_measured_at` says which)
+    traffic = traffic_at = sp_traffic = sp_traffic_at = None
+    if B == 1 and args.config == "car":
+        rec, traffic_at = stamped_traffic("r03_wino4_gemm_hbm_traffic.json")
+        traffic = rec["traffic_bytes_per_launch"] if rec else None
+    if B == w["batch"]:                  # fabric-side bytes of one sparse pass: 2 x FETCH + WRITE
+        t, sp_traffic_at = stamped_traffic("r03_sparse_%s_hbm_traffic.json" % args.config)
+        if t:
+            sp_traffic = int((2 * t["FETCH_SIZE_kb_per_pass_raw"] + t["WRITE_SIZE_kb_per_pass_raw"]) * 1024)
     out = {
         "metric": "KITTI-Car inference frames/sec (whole job)" if args.config == "car" else
                   "%s inference frames/sec (whole job)" % args.config,
@@ -443,7 +540,7 @@ def main():
                      "layer": {"ms": round(conv_iso, 4), "direct_conv_flops": conv_flops,
                                "effective": round(eff_tf, 2), "effective_frac": round(eff_tf / PEAK_F32_MFMA_TF, 4),
                                "kernel_ms": {k: round(v, 4) for k, v in w4_parts.items()}},
-                     "traffic": traffic,
+                     "traffic": traffic, "traffic_measured_at": traffic_at,
                      "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc "
                                      "passes, profiles/)",
                      "note": "achieved/frac = flops EXECUTED on the MFMA pipe by the dominant kernel (Winograd F(4x4,3x3): "
@@ -459,7 +556,7 @@ def main():
                             "bytes_gs": work["bytes_gs"], "bytes_min": work["bytes_min"],
                             "rulebook_bytes": work["rulebook_bytes"], "flops": work["flops"],
                             "ms": round(sp_ms, 4), "ms_eager_isolated": round(iso_ms["sparse"], 4), "rows": work["n"],
-                            "traffic": sp_traffic,
+                            "traffic": sp_traffic, "traffic_measured_at": sp_traffic_at,
                             "traffic_unit": "fabric-side bytes per pass, upper bound 2 x FETCH_SIZE + WRITE_SIZE over all "
                                             "rulebook / sparse-conv dispatches (separate rocprofv3 --pmc passes, profiles/): "
                                             "near bytes_min, the gathers of bytes_gs are served by the XCD L2s",
@@ -470,6 +567,16 @@ def main():
         "bev_total_ms": round(bev_total_ms, 4),
         "detections_last_frame": ndet, "guided_anchor_candidates_last_frame": ncand,
     }
+    out["csrc_hash"] = csrc_hash()
+    if watchdog is not None:
+        emit["line"] = out
+        watchdog.start()
+        try:
+            out["train"] = train_measure(args, dev, rank, world, "car", "bf16", args.train_steps, args.train_warmup)
+        except Exception as e:                                   # the inference line is still valid without it
+            out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            watchdog.cancel()
     if world == 1 and headline and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, w)
     print(json.dumps(out))

@@ -167,3 +167,16 @@ def stream():
     """Raw hipStream_t of torch's current stream on the current device (one C call: this runs before every launch)."""
     import torch
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+def csrc_hash():
+    """Short hash over the kernel sources (csrc/*) next to this library: stamped into every PMC traffic record under
+    profiles/ and compared by bench.py, so that counters measured on other kernels are never reported."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]

@@ -46,6 +46,16 @@ def allreduce_sum(value, device="cpu"):
     return float(t.item())
 
 
+def allgather_float(value, device="cpu"):
+    """[value of rank 0, value of rank 1, ...] of a python float (per-rank step times in bench.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def frame_shard(num_frames, rank, world):
     """Round-robin frame indices of this rank: disjoint, complete, balanced to within one frame."""
     return list(range(rank, num_frames, world))

@@ -29,6 +29,7 @@ def _worker(rank, world, port, q):
     D.barrier()
     tmax = D.allreduce_max(1.0 + rank)             # rank 1 is "slower"
     total = D.allreduce_sum(len(mine))
+    assert D.allgather_float(10.0 + rank) == [10.0, 11.0]
     allres = D.gather_results([(i, "frame%d" % i) for i in mine])
     import types
     from sassd import loader as L

@@ -9,7 +9,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+sys.path.insert(0, ROOT)
+import sassd  # noqa: E402,F401
+from sassd import _C  # noqa: E402
+CSRC = _C.csrc_hash()          # stamp: bench.py drops a traffic record measured on other kernel sources
 
 
 def json_line(path):
@@ -20,7 +24,11 @@ def json_line(path):
 
 
 def counter(path, name, pat):
+    if not os.path.exists(path):
+        return 0, 0
     d = json.load(open(path))
+    if "error" in d:
+        return 0, 0
     tot = n = 0
     for k, v in d.items():
         if pat in k and name in v:
@@ -29,7 +37,7 @@ def counter(path, name, pat):
     return tot, n
 
 
-for name in ("bench_inflight3", "bench_inflight1", "bench_multi", "bench_waymo", "bench_train"):
+for name in ("bench_inflight3", "bench_inflight1", "bench_multi", "bench_waymo", "bench_train", "bench_train_waymo_trace"):
     ks = os.path.join(SRC, name + "_kernel_stats.txt")
     if os.path.exists(ks):
         shutil.copy(ks, os.path.join(DST, "%s_%s_kernel_stats.txt" % (tag, name)))
@@ -38,7 +46,7 @@ for name in ("bench_inflight3", "bench_inflight1", "bench_multi", "bench_waymo",
         d = json_line(lg)
         if d:
             json.dump(d, open(os.path.join(DST, "%s_%s_under_rocprof.json" % (tag, name)), "w"), indent=1)
-for name in ("bench_default", "bench_train_bf16", "bench_train_fp32"):
+for name in ("bench_default", "bench_train_bf16", "bench_train_fp32", "bench_train_waymo"):
     lg = os.path.join(SRC, name + ".log")
     d = json_line(lg) if os.path.exists(lg) else None
     if d:
@@ -58,6 +66,7 @@ for k in ("wino4_in", "wino4_out", "wino4_gemm"):
 Tp, cin, cout = 2240, 256, 256
 alg = 36 * cin * Tp * 4 + 36 * cin * cout * 4 + 36 * cout * Tp * 4
 rec = dict(
+    csrc_hash=CSRC,
     kernel="wino4_gemm_kernel (36 GEMMs 256 x 256 x 2240 tiles of the BEV 256->256 3x3 layer @ 1x256x200x176, fp32)",
     command="rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python tools/run_wino4.py --profile --reps 5 ; the same with "
             "--pmc WRITE_SIZE (two separate passes, tools/rocprof_pmc.py on each results.db)",
@@ -71,10 +80,11 @@ rec = dict(
     per_kernel_raw_kb=parts)
 rec["traffic_bytes_per_launch"] = rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]
 rec["traffic_over_algorithmic"] = round(rec["traffic_bytes_per_launch"] / alg, 3)
-json.dump(rec, open(os.path.join(DST, "%s_wino4_gemm_hbm_traffic.json" % tag), "w"), indent=1)
+if nf and nw:
+    json.dump(rec, open(os.path.join(DST, "%s_wino4_gemm_hbm_traffic.json" % tag), "w"), indent=1)
 
 # sparse segment: fabric-side traffic per pass (all rulebook + sparse-conv kernels)
-for cfgname, reps in (("multi", 3), ("car", 5)):
+for cfgname, reps in (("multi", 3), ("car", 5), ("waymo", 2)):
     fp, wp = os.path.join(SRC, "sparse_%s_FETCH_SIZE.json" % cfgname), os.path.join(SRC, "sparse_%s_WRITE_SIZE.json" % cfgname)
     if not (os.path.exists(fp) and os.path.exists(wp)):
         continue
@@ -85,6 +95,7 @@ for cfgname, reps in (("multi", 3), ("car", 5)):
         if line.startswith("{'bytes_gs'"):
             work = eval(line)
     json.dump(dict(
+        csrc_hash=CSRC,
         segment="7 rulebooks (fused pyramid) + 14 sparse convs, %s workload" % cfgname,
         command="rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python tools/run_sparse_only.py --config %s --reps %d ; the "
                 "same with --pmc WRITE_SIZE" % (cfgname, reps),

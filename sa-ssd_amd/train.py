@@ -450,7 +450,8 @@ def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None):
     waiting for it.  Returns (loss, loss terms[, next batch])."""
     scheduler.step(it)
     model.train()
-    sync.reset()
+    if hasattr(sync, "reset"):
+        sync.reset()
     optimizer.zero_grad()
     loss, terms = parse_losses(model(**batch))
     nxt = prefetch() if prefetch is not None else None

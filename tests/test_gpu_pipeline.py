@@ -239,3 +239,105 @@ def test_waymo_scale_frame(dev, batch):
     ndet = sum(_check_sample("waymo", plan, res, ref, b, errs, unbounded=True) for b in range(batch))
     print("max abs errors vs the CPU oracle (waymo-scale, batch %d): %s" % (batch, {k: (["%.1e" % x for x in v] if isinstance(v, np.ndarray) else "%.2e" % v) for k, v in errs.items()}))
     assert ndet >= 1
+
+
+# ---- the SHIPPED thresholds (configs/car_cfg.py:71-81: guided-anchor threshold 0.1 literal in single_stage.py:122,
+# test_cfg.extra.score_thr 0.3) with a tolerance-aware candidate-set comparison ------------------------------------------
+MARGIN = 1e-4          # a candidate whose oracle score lies within MARGIN of a threshold may fall on either side
+
+
+def _subsequence(small, big, tol=1e-4):
+    """Indices into `big` of the rows of `small` (both in ascending anchor order), rows matched within `tol` absolute on
+    every field; None if `small` is not a subsequence of `big`."""
+    idx, j = [], 0
+    for row in small:
+        while j < len(big) and not np.all(np.abs(big[j].astype(np.float64) - row) <= tol):
+            j += 1
+        if j == len(big):
+            return None
+        idx.append(j)
+        j += 1
+    return idx
+
+
+def _check_at_configured_thresholds(tag, plan, res, ft, b, rpn_thr, score_thr, iou_thr, stats):
+    """Sample b of a plan run at the CONFIGURED thresholds against the oracle: every candidate whose oracle score is more
+    than MARGIN away from a threshold must be selected / rejected exactly like the oracle does; the (few) candidates
+    within MARGIN may go either way, and everything downstream is then compared strictly (1e-4 absolute on boxes and
+    scores, labels exact) against the oracle evaluated on the candidate set the GPU actually chose."""
+    from oracle import nets as onets
+    lo, hi = ft["lo"], ft["hi"]
+    g_lo, l_lo, s_lo = lo["guided"][b]
+    g_hi = hi["guided"][b][0]
+    k = int(plan.df["counts"][b].item())
+    got = plan.df["guided"][b, :k].cpu().numpy().astype(np.float64)
+    sel = _subsequence(got, g_lo.numpy())                    # GPU candidates  <=  oracle candidates at thr - MARGIN
+    assert sel is not None, (tag, b, "a guided anchor of the GPU is not an oracle candidate at %.5f" % (rpn_thr - MARGIN))
+    must = _subsequence(g_hi.numpy().astype(np.float64), got)          # oracle candidates at thr + MARGIN  <=  GPU candidates
+    assert must is not None, (tag, b, "an oracle candidate above %.5f is missing on the GPU" % (rpn_thr + MARGIN))
+    stats["borderline_guided"] += len(g_lo) - len(g_hi)
+    stats["guided"] += k
+    sel_t = torch.as_tensor(sel, dtype=torch.int64)
+    assert np.array_equal(plan.df["labels"][b, :k].cpu().numpy(), l_lo[sel_t].numpy())
+    logits = lo["logits"][b][sel_t]
+    e = _abs_err(plan.logits[b, :k].cpu().numpy(), logits.numpy())
+    assert e <= max(1e-4, 2e-5 * float(lo["psfeat"].abs().max())), (tag, "logits", e)
+    # rescoring + NMS of the oracle on exactly these candidates; rescoring scores within MARGIN of score_thr: both ways
+    sc = torch.sigmoid(logits).view(-1)
+    border = torch.nonzero((sc - score_thr).abs() <= MARGIN).view(-1).tolist()
+    stats["borderline_scores"] += len(border)
+    assert len(border) <= 6, "too many borderline rescoring candidates to enumerate"
+    options = []
+    thr_eff = score_thr - MARGIN if border else score_thr   # admits every borderline candidate; each is then kept or forced out
+    for bits in range(1 << len(border)):
+        lg = logits.clone()
+        for i, r in enumerate(border):
+            if not (bits >> i) & 1:
+                lg[r] = -50.0
+        options.append(onets.rescore(g_lo[sel_t], lg, l_lo[sel_t], thr_eff, iou_thr))
+    ok = False
+    for d in options:
+        if d is None:
+            ok = ok or res[b][0] is None
+            continue
+        if res[b][0] is None or len(res[b][0]) != len(d[0]):
+            continue
+        if (_abs_err(res[b][0], d[0]) <= 1e-4 and _abs_err(res[b][1], d[1]) <= 1e-4 and np.array_equal(res[b][2], d[2])):
+            ok = True
+            stats["det_err"] = max(stats["det_err"], _abs_err(res[b][0], d[0]), _abs_err(res[b][1], d[1]))
+    assert ok, (tag, b, "detections differ from the oracle's on the same candidate set")
+    return 0 if res[b][0] is None else len(res[b][0])
+
+
+@pytest.mark.parametrize("cfgfile,frames", [("configs/car_cfg.py", ("k21",)), ("configs/car_cfg.py", ("k21", "k17")),
+                                            ("configs/multi_cfg.py", ("k21",) * 8)])
+def test_pipeline_at_configured_thresholds(dev, cfgfile, frames):
+    """The shipped configuration itself: guided-anchor threshold 0.1 (single_stage.py:122), score_thr 0.3 and NMS 0.1
+    (car_cfg.py:71-81 / multi_cfg.py) on full K21 / K17 frames, car_cfg and multi_cfg at its stated batch 8 -- no
+    threshold is moved.  GPU expf / fp32 summation order move a score by ~1e-6, so a candidate sitting within MARGIN of
+    a threshold may legitimately land on either side; everything else must match the oracle."""
+    model, c = _model(cfgfile, seed=5)
+    names = c.data.val.class_names
+    nc = len(names)
+    an, bv = _anchors(names)
+    B = len(frames)
+    clouds = [H.frame(f, 40 + i) for i, f in enumerate(frames)]
+    H.calibrate_cls_head(model, clouds[0], bv, CFG, target_count=300)
+    tc = c.test_cfg.extra
+    rpn_thr, score_thr, iou_thr = 0.1, float(tc.score_thr), float(tc.nms.iou_thr)
+    assert (score_thr, iou_thr) == (0.3, 0.1)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ft = H.oracle_features(sd, clouds, an, bv, CFG, nc)
+    ft["lo"] = H.oracle_select(ft, rpn_thr - MARGIN)
+    ft["hi"] = H.oracle_select(ft, rpn_thr + MARGIN)
+    plan = InferencePlan(sd, batch_size=B, num_class=nc, anchors=an, anchors_bv=bv, device=dev, cap_k=4096,
+                         cap_d=1024)                          # default thresholds = the configured ones
+    assert (plan.rpn_thr, plan.score_thr, plan.iou_thr) == (0.1, 0.3, 0.1)
+    plan.run_from_points([torch.from_numpy(p).to(dev) for p in clouds])
+    res = plan.results()
+    assert int(plan.status.item()) == 0
+    stats = dict(guided=0, borderline_guided=0, borderline_scores=0, det_err=0.0)
+    ndet = sum(_check_at_configured_thresholds(cfgfile, plan, res, ft, b, rpn_thr, score_thr, iou_thr, stats)
+               for b in range(B))
+    print("configured thresholds (%s, batch %d): %d detections, %s" % (cfgfile, B, ndet, stats))
+    assert ndet >= 1 and stats["guided"] >= 50 * B

@@ -110,12 +110,13 @@ def _gt(seed, n, types=None, xmax=32.0):
 @pytest.mark.parametrize("cfgfile,names,HALF,precision",
                          [("configs/car_cfg.py", ["Car"], FULL, "fp32"),
                           ("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"], HALF, "fp32"),
+                          ("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"], FULL, "fp32"),
                           ("configs/car_cfg.py", ["Car"], FULL, "bf16")])
 def test_training_step_vs_oracle(dev, cfgfile, names, HALF, precision):
     """forward_train on the GPU (HIP kernels under autograd) vs oracle/train_ref.train_step on the CPU: the six loss
     terms and the gradient of their sum with respect to every parameter.  car_cfg on its own full 1408-wide grid
     (BASELINE configs[2]); the three-class multi_cfg (per-class anchors / masks / thresholds, 18 + 42 + 12 head
-    channels) on a half-width grid to bound the CPU autograd time of the oracle."""
+    channels) on a half-width grid AND on its own full 1408-wide grid (211 200 anchors)."""
     from oracle import clib, nets as onets, train_ref
     c = Config.fromfile(cfgfile)
     mcfg = dict(c.model)
@@ -263,6 +264,71 @@ def test_training_step_waymo_scale(dev):
         assert bool(torch.isfinite(opt.flat.grad).all()) and float(opt.flat.grad.abs().sum()) > 0
     assert float((opt.flat.data - w0).abs().max()) > 0
     torch.cuda.synchronize()
+
+
+def test_training_step_waymo_vs_oracle(dev):
+    """BASELINE configs[4] as a TRAINING config, parity: one 180 000-point frame (79 302 voxels, grid 40 x 1504 x 1504, BEV
+    188 x 188) through forward_train + backward on the HIP kernels -- the batch built by the product's own device_batch
+    (HIP voxelizer, anchor mask, rulebooks) -- against the CPU oracle's step on the same model / frame / boxes, read
+    from tests/golden/waymo_train_ref.npz (the oracle needs ~2.5 CPU-minutes for this frame;
+    tests/golden/make_golden_waymo_train.py made the file and is imported here for the shared seeded inputs).
+    Bars as for car_cfg: the six loss terms 1e-3 relative; gradients 2e-3 relative L2 -- elementwise for the stored
+    layers (first / last sparse convs, every BatchNorm, heads, aux linears, a slice of four BEV convs), through the norm
+    and a seeded random projection for every other parameter."""
+    import importlib.util
+    import os
+    from sassd import train
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_waymo_train", os.path.join(gdir, "make_golden_waymo_train.py"))
+    MG = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(MG)
+    G = np.load(os.path.join(gdir, "waymo_train_ref.npz"))
+    model, c, an, bv, p, gt = MG.build()
+    model = model.to(dev).train()
+    model.train_cfg.rpn.anchor_thr = float(G["anchor_thr"])
+    anchors, anchors_bv = dict(Car=torch.from_numpy(an).to(dev)), dict(Car=torch.from_numpy(bv).to(dev))
+    batch = train.device_batch([torch.from_numpy(p).to(dev)], [torch.from_numpy(gt).to(dev)], [np.array(["Car"] * len(gt))],
+                               ["Car"], anchors, anchors_bv, synth.WAYMO_VOXEL, synth.WAYMO_RANGE, max_voxels=150000,
+                               model=model)
+    assert batch["voxels"][0].shape[0] == int(G["n_voxels"]) == 79302
+    assert int(batch["anchors_mask"]["Car"][0].sum()) == int(G["n_masked"])
+    losses = model(**batch)
+    total = sum(v.sum() for v in losses.values())
+    total.backward()
+    torch.cuda.synchronize()
+    got_l = {k: float(v.detach().sum()) for k, v in losses.items()}
+    ref_l = dict(zip([str(k) for k in G["loss_names"]], G["losses"]))
+    assert set(got_l) == set(ref_l) and len(ref_l) == 6
+    for k, v in ref_l.items():
+        assert v != 0 and abs(got_l[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, got_l[k], v)
+    params = dict(model.named_parameters())
+    worst, worst_n, worst_p = {}, {}, {}
+    for k in G.files:
+        if k.startswith("grad:") or k.startswith("grad8:"):
+            name = k.split(":", 1)[1]
+            g = params[name].grad
+            g = g[:8] if k.startswith("grad8:") else g
+            ref = torch.from_numpy(G[k])
+            if float(ref.norm()) > 1e-7:
+                worst[name] = _rel(g, ref)
+    for name, norm, proj in zip(G["grad_names"], G["grad_norms"], G["grad_projs"]):
+        name = str(name)
+        g = params[name].grad
+        assert g is not None, name
+        if norm < 1e-7:
+            continue
+        gd = g.detach().double().cpu().reshape(-1)
+        worst_n[name] = abs(float(gd.norm()) - norm) / norm
+        # error e with ||e|| <= 2e-3 ||g||, independent of the seeded direction r (unit variance): dot(e, r) ~ N(0, ||e||^2)
+        worst_p[name] = abs(float(torch.dot(gd, MG.projection(name, gd.numel()))) - proj) / norm
+    print("waymo-scale training step vs oracle: losses", {k: (round(got_l[k], 5), round(float(v), 5)) for k, v in ref_l.items()},
+          "| stored-layer gradients: worst rel L2 %.2e over %d tensors | all %d parameters: worst norm error %.2e, worst "
+          "projection error %.2e" % (max(worst.values()), len(worst), len(worst_n), max(worst_n.values()),
+                                     max(worst_p.values())))
+    bad = {k: v for k, v in worst.items() if not v < 2e-3}
+    assert len(worst) >= 40 and not bad, bad
+    assert len(worst_n) >= 75 and max(worst_n.values()) < 2e-3, {k: v for k, v in worst_n.items() if v >= 2e-3}
+    assert max(worst_p.values()) < 5 * 2e-3, {k: v for k, v in worst_p.items() if v >= 1e-2}
 
 
 # ---- SURVEY 8f rank 2: evaluation with the overlap matrices on the GPU (kept last in the last -m gpu file) --------------

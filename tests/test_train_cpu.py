@@ -238,3 +238,17 @@ def test_flat_params_collects_lazily():
     assert float(m[1].weight.grad.abs().sum()) == 0 and float(g[f.offsets[2]:].abs().sum()) == 0
     f.collect()                                 # idempotent
     assert torch.equal(m[0].weight.grad, own)
+
+
+def test_waymo_train_golden_is_complete():
+    """tests/golden/waymo_train_ref.npz (the CPU oracle's training step at the BASELINE configs[4] shape, made by
+    tests/golden/make_golden_waymo_train.py): six non-zero loss terms, the 79 302-voxel frame, positives in both
+    assignments, gradients for every parameter (norm + projection) and elementwise for the stored layers."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "waymo_train_ref.npz"))
+    assert sorted(str(k) for k in G["loss_names"]) == ["aux_loss_cls", "aux_loss_reg", "loss_cls", "rpn_cls_loss",
+                                                      "rpn_dir_loss", "rpn_loc_loss"]
+    assert np.all(G["losses"] > 0) and int(G["n_voxels"]) == 79302 and int(G["n_pos"]) > 0 and int(G["n_ext_pos"]) >= 12
+    assert len(G["grad_names"]) == len(G["grad_norms"]) == len(G["grad_projs"]) >= 75
+    stored = [k for k in G.files if k.startswith("grad:") or k.startswith("grad8:")]
+    assert len(stored) >= 40 and all(np.isfinite(G[k]).all() for k in stored)

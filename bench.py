@@ -290,7 +290,7 @@ def main_train(args):
     dev = torch.device("cuda", local_rank)
     out = train_measure(args, dev, rank, world, "waymo" if args.config == "waymo" else "car", args.precision,
                         args.steps, args.warmup, args.batch if args.batch > 1 else 0, args.frames,
-                        True if args.fused_bn else None)
+                        False if args.torch_bn else None)
     if rank == 0:
         print(json.dumps(out))
 
@@ -329,8 +329,8 @@ def main():
                     help="car = configs[1] (headline); multi = configs[3] (batch 8); waymo = configs[4] shape (batch 4)")
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
                     help="--mode train: arithmetic of the dense BEV convolutions (BASELINE configs[2] trains in bf16)")
-    ap.add_argument("--fused-bn", action="store_true", help="--mode train: opt into the fused sparse BatchNorm1d + ReLU "
-                    "kernels (sassd.spconv.SparseSequential.fuse_bn_relu)")
+    ap.add_argument("--torch-bn", action="store_true", help="--mode train: torch's BatchNorm1d + ReLU for the sparse blocks "
+                    "instead of the fused kernels (sassd.spconv.SparseSequential.fuse_bn_relu = False; A/B)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)

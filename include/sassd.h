@@ -484,6 +484,74 @@ int sassd_bn_relu_bwd(const float *x, const float *dy, int n, int C, const float
                       const float *save_mean, const float *save_invstd, float *dx, float *dgamma, float *dbeta,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* Training-mode BatchNorm2d + ReLU over NCHW maps x [B, C, H*W] (the BEV stack cmn.py:233-282 and the part-sensitive head
+ * ssd_rotate_head.py:424-429: Conv2d -> BatchNorm2d(eps 1e-3, momentum 0.01) -> ReLU), replacing torch's MIOpen BatchNorm +
+ * clamp / threshold_backward + MIOpen backward (four passes over the map each way) by two launches each way; same
+ * contract as sassd_bn_relu_* with the channel as the SECOND dimension.  HW % 4 == 0, 16-byte aligned tensors.
+ * Deterministic (double partials per (channel, split), added in a fixed order by every block of the second launch).
+ * Workspace: sassd_bn2d_relu_workspace_bytes(C). */
+size_t sassd_bn2d_relu_workspace_bytes(int C);
+int sassd_bn2d_relu_fwd(const float *x, int B, int C, int HW, const float *gamma, const float *beta, float *running_mean,
+                        float *running_var, float momentum, float eps, float *y, float *save_mean, float *save_invstd,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int sassd_bn2d_relu_bwd(const float *x, const float *dy, int B, int C, int HW, const float *gamma, const float *beta,
+                        const float *save_mean, const float *save_invstd, float *dx, float *dgamma, float *dbeta,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* The guided-anchor / rescoring tail of the training step on padded tensors with device counts (train_heads.hip):
+ *   sassd_guided_decode_fwd  ssd_rotate_head.py:316-388 (train mode): guided[b] = [ground truth of sample b (gt_boxes rows
+ *                            gt_off[b] .. gt_off[b+1]); decoded + direction-flipped boxes of the anchors sel[b][0 .. sel_count[b])
+ *                            (second_box_decode :53-91, flip :352-356); zeros] as [B, gmax + cap, 7]; counts[b] = G_b +
+ *                            min(sel_count[b], cap).  anchors [A,7] (anchors_per_sample 0) or [B,A,7] (1); dir_preds may be NULL.
+ *   sassd_guided_decode_bwd  dbox [B,A,7] (zeroed here) <- dguided through the decode (selected anchors only).
+ *   sassd_boxes_iou3d_batch  iou3d_utils.py:79-111 boxes_iou3d_gpu of boxes [B, rows, 7] (rows < counts[b] valid, the rest
+ *                            give 0) against each sample's ground truth; sample b's [rows, G_b] matrix starts at element
+ *                            ov_off[b] of `overlaps` (the layout sassd_assign_targets takes as `overlaps`).
+ *   sassd_focal_loss         losses.py:35-62 sigmoid focal loss (gamma 2, alpha .25) of logits [n] against labels [n]
+ *                            (-1 ignore / 0 / > 0), weight 1 / max(sum(num_pos[0..nb)), 1): loss_sum[0] and grad [n]. */
+int sassd_guided_decode_fwd(const float *box_preds, const float *dir_preds, const float *anchors, int anchors_per_sample,
+                            const int64_t *sel, const int32_t *sel_count, const float *gt_boxes, const int32_t *gt_off,
+                            int A, int B, int cap, int gmax, float *guided, int32_t *counts, void *stream);
+int sassd_guided_decode_bwd(const float *box_preds, const float *anchors, int anchors_per_sample, const int64_t *sel,
+                            const int32_t *sel_count, const int32_t *gt_off, int A, int B, int cap, int gmax,
+                            const float *dguided, float *dbox, void *stream);
+int sassd_boxes_iou3d_batch(const float *boxes, const int32_t *counts, int B, int rows, const float *gt_boxes,
+                            const int32_t *gt_off, int gmax, const int64_t *ov_off, float *overlaps, void *stream);
+size_t sassd_focal_loss_workspace_bytes(int n);
+int sassd_focal_loss(const float *logits, const int64_t *labels, int n, const int32_t *num_pos, int nb, float *loss_sum,
+                     float *grad, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The auxiliary point-wise head of SpMiddleFHD in training, fused (cmn.py:27-29 point_fc / point_cls / point_reg, :45-72
+ * build_aux_target, :74-104 aux_loss, :121-135,175-189 nearest_neighbor_interpolate, transforms.py:218-223 tensor2points):
+ *   sassd_aux_prepare   points [N,4] = (b, voxel mean xyz); voxel centres known[s] [M_s,4] of the three middle tensors
+ *                       (indices [M_s,4] (b,z,y,x); centre = idx * vs_s + offset + vs_s / 2 with vs_s = 2, 4, 8 x voxel_size,
+ *                       evaluated in the reference's fp32 order); per-point label (inside any ground-truth box of the
+ *                       point's own sample: points_op.cpp:92-144 semantics, gt_boxes [T,7] + gt_off [B+1]) and centre
+ *                       offsets of the LAST containing box; npos[0] = number of positive points.
+ *   (the three 3-NN searches between points and known[s] stay sassd_three_nn_binned calls)
+ *   sassd_aux_head_fwd  per point: inverse-distance weights from nn_d2[s] [N,3], interpolation of feats[s] [M_s, C_s]
+ *                       (C = 32, 64, 64) at nn_idx[s] [N,3], h = f W1^T (W1 [64,160]), out = h W2^T (W2 [4,64]: point_cls
+ *                       row, then the three point_reg rows); loss_sums[0] = sum of the sigmoid focal terms / max(npos, 1),
+ *                       loss_sums[1] = sum over positives of smooth-L1(beta 1/9) / max(npos, 1); gout [N,4] = their
+ *                       gradients with respect to out.  Keeps wgt [N,9], h [N,64] for the backward pass.
+ *   sassd_aux_head_bwd  grad_sums [2] (device) = upstream gradients of the two sums -> grad_feats[s] [M_s, C_s]
+ *                       (zeroed here, accumulated with float atomics like the reference's three_interpolate_grad),
+ *                       dw1 [64,160], dw2 [4,64] (per-workgroup partials, fixed-order reduction).
+ * Workspace (both): sassd_aux_head_workspace_bytes(N). */
+size_t sassd_aux_head_workspace_bytes(int N);
+int sassd_aux_prepare(const float *voxel_feats, int vstride, const int32_t *coors, int N, const int32_t *const *indices,
+                      const int *M, const float *voxel_size, const float *offset, const float *gt_boxes,
+                      const int32_t *gt_off, int B, float *points, float *const *known, uint8_t *label, float *target,
+                      int *npos, void *stream);
+int sassd_aux_head_fwd(int N, const float *const *feats, const int32_t *const *nn_idx, const float *const *nn_d2,
+                       const float *w1, const float *w2, const uint8_t *label, const float *target, const int *npos,
+                       float *wgt, float *h, float *out, float *gout, float *loss_sums, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int sassd_aux_head_bwd(int N, const float *const *feats, const int *M, const int32_t *const *nn_idx, const float *w1,
+                       const float *w2, const float *wgt, const float *h, const float *gout, const float *grad_sums,
+                       float *const *grad_feats, float *dw1, float *dw2, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0 for i < n; dst fp32, or bf16 (round-to-nearest-even) when bf16 != 0: every
  * kernel-layout weight image is a permutation (+ zero padding) of the flat parameter buffer, so ONE gather re-packs all
  * of them after an optimizer step (sassd.train.PackPlan). */

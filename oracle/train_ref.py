@@ -157,11 +157,13 @@ def decode(enc, a):
 
 
 def train_step(sd, feats, coors, batch_size, sparse_shape, gt_bboxes, gt_types, class_names, anchors, anchors_mask,
-               assign_cfg, anchor_thr=0.1, extra_thr=0.7, grid_offsets=(0., 40.), featmap_stride=0.4):
+               assign_cfg, anchor_thr=0.1, extra_thr=0.7, grid_offsets=(0., 40.), featmap_stride=0.4,
+               aux_offset=(0., -40., -3.), aux_voxel_size=(.05, .05, .1)):
     """sd: detector state_dict (CPU tensors); feats [N,4] voxel means; coors [N,4] (b,z,y,x); gt_bboxes: list of
     [G,7]; gt_types: list of str arrays; anchors / anchors_mask: {class: [B, A, 7] / [B, A]};
     assign_cfg: {class: (pos_thr, neg_thr)}.  Returns (losses {name: float}, grads {param name: tensor},
-    extras)."""
+    extras).  aux_offset / aux_voxel_size: the auxiliary head's voxel-centre geometry, cmn.py:121-127 literals by default
+    (KITTI: offset (0, -40, -3), level voxel sizes 2 / 4 / 8 x (.05, .05, .1))."""
     P = {k: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point and "running" not in k)
          for k, v in sd.items() if torch.is_tensor(v) and v.dtype.is_floating_point}
     B = batch_size
@@ -201,8 +203,8 @@ def train_step(sd, feats, coors, batch_size, sparse_shape, gt_bboxes, gt_types, 
     fe = torch.as_tensor(feats, dtype=torch.float32)
     pm = np.concatenate([np.asarray(coors, np.float32)[:, :1], np.asarray(feats, np.float32)[:, :3]], 1)
     ps = []
-    for (mf, mi), vs in zip(middle, ((.1, .1, .2), (.2, .2, .4), (.4, .4, .8))):
-        vsz, off = np.asarray(vs, np.float32), np.asarray((0., -40., -3.), np.float32)
+    for (mf, mi), mult in zip(middle, (2, 4, 8)):
+        vsz, off = np.asarray([v * mult for v in aux_voxel_size], np.float32), np.asarray(aux_offset, np.float32)
         known = mi.astype(np.float32)
         known[:, 1:] = mi[:, [3, 2, 1]].astype(np.float32) * vsz + off + np.float32(.5) * vsz
         d2, nn = clib.three_nn(pm, known)

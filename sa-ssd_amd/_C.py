@@ -125,6 +125,18 @@ _SIGS = {
     "sassd_bn_relu_workspace_bytes": (_SZ, [_I]),
     "sassd_bn_relu_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _SZ, _P]),
     "sassd_bn_relu_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sassd_bn2d_relu_workspace_bytes": (_SZ, [_I]),
+    "sassd_bn2d_relu_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _SZ, _P]),
+    "sassd_bn2d_relu_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sassd_aux_head_workspace_bytes": (_SZ, [_I]),
+    "sassd_aux_prepare": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "sassd_aux_head_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sassd_aux_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "sassd_guided_decode_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "sassd_guided_decode_bwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "sassd_boxes_iou3d_batch": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "sassd_focal_loss_workspace_bytes": (_SZ, [_I]),
+    "sassd_focal_loss": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "sassd_gather_pack": (_I, [_P, _P, _P, C.c_long, _I, _P]),
     "sassd_grad_sumsq": (_I, [_P, C.c_long, _P, _P]),
     "sassd_adam_step": (_I, [_P, _P, _P, _P, C.c_long, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P]),

@@ -298,3 +298,95 @@ class BnReluFn(Function):
         dx, dg, db = K.bn_relu_bwd(x, dy.contiguous(), gamma.detach().contiguous(), beta.detach().contiguous(), mean,
                                    invstd)
         return dx, dg, db, None, None, None, None
+
+
+class BnRelu2dFn(Function):
+    """Training-mode BatchNorm2d + ReLU over NCHW maps in two launches each way (sassd_bn2d_relu_fwd / _bwd); the
+    module's running statistics are updated in place like torch.nn.functional.batch_norm(training=True)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        x = x.contiguous()
+        y, mean, invstd = K.bn2d_relu_fwd(x, gamma.detach().contiguous(), beta.detach().contiguous(), running_mean,
+                                          running_var, momentum, eps)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        dx, dg, db = K.bn2d_relu_bwd(x, dy.contiguous(), gamma.detach().contiguous(), beta.detach().contiguous(), mean,
+                                     invstd)
+        return dx, dg, db, None, None, None, None
+
+
+def bn_relu_2d(bn, x):
+    """`relu(bn(x))` for a training-mode nn.BatchNorm2d on the fused HIP kernels when the layer / tensor allow it, else
+    the torch ops (eval mode, no affine, cumulative-average momentum, exotic shapes)."""
+    if (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and torch.is_grad_enabled()
+            and K.bn2d_relu_supported(x)):
+        y = BnRelu2dFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        bn.num_batches_tracked.add_(1)
+        return y
+    return torch.relu(bn(x))
+
+
+class AuxHeadFn(Function):
+    """The auxiliary head's interpolation + three Linear layers + both loss sums in one forward kernel, and its whole
+    backward (feature gradients of the three scales, weight gradients) in three (sassd_aux_head_fwd / _bwd).
+    Inputs: the three middle feature tensors [M_s, C_s], point_fc / point_cls / point_reg weights, then the
+    non-differentiable context (3-NN indices / squared distances per scale, labels, targets, positive count).
+    -> loss sums [2] = (focal, smooth-L1), both already divided by max(#positive points, 1)."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, f2, w_fc, w_cls, w_reg, nn_idx, nn_d2, label, target, npos):
+        feats = [f0.contiguous(), f1.contiguous(), f2.contiguous()]
+        w1 = w_fc.detach().contiguous()
+        w2 = torch.cat([w_cls.detach(), w_reg.detach()], 0).contiguous()
+        sums, wgt, h, out, gout = K.aux_head_fwd(feats, nn_idx, nn_d2, w1, w2, label, target, npos)
+        ctx.save_for_backward(feats[0], feats[1], feats[2], w1, w2, wgt, h, gout)
+        ctx.nn_idx = nn_idx
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        f0, f1, f2, w1, w2, wgt, h, gout = ctx.saved_tensors
+        gf, dw1, dw2 = K.aux_head_bwd([f0, f1, f2], ctx.nn_idx, w1, w2, wgt, h, gout, g.contiguous())
+        return gf[0], gf[1], gf[2], dw1, dw2[0:1], dw2[1:4], None, None, None, None, None
+
+
+class GuidedDecodeFn(Function):
+    """Padded guided anchors of the training step (sassd_guided_decode_fwd / _bwd): ground truth first, then the decoded,
+    direction-flipped boxes of the selected anchors; gradients reach box_preds through the decode."""
+
+    @staticmethod
+    def forward(ctx, box_preds, dir_preds, anchors, sel, sel_count, gt_boxes, gt_off, gmax):
+        box_preds = box_preds.contiguous()
+        guided, counts = K.guided_decode_fwd(box_preds, dir_preds.detach().contiguous() if dir_preds is not None else None,
+                                             anchors, sel, sel_count, gt_boxes, gt_off, gmax)
+        ctx.save_for_backward(box_preds, anchors, sel, sel_count, gt_off)
+        ctx.gmax = gmax
+        ctx.mark_non_differentiable(counts)
+        return guided, counts
+
+    @staticmethod
+    def backward(ctx, dguided, _dcounts):
+        box_preds, anchors, sel, sel_count, gt_off = ctx.saved_tensors
+        dbox = K.guided_decode_bwd(box_preds, anchors, sel, sel_count, gt_off, ctx.gmax, dguided.contiguous())
+        return dbox, None, None, None, None, None, None, None
+
+
+class FocalLossFn(Function):
+    """Sigmoid focal loss sum of [n] logits with its gradient from the same pass (sassd_focal_loss)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, num_pos):
+        out, grad = K.focal_loss(logits.contiguous().view(-1), labels.contiguous().view(-1), num_pos)
+        ctx.save_for_backward(grad)
+        ctx.shape = logits.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g).view(ctx.shape), None, None

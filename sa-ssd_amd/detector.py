@@ -24,7 +24,7 @@ from . import iou3d_utils
 from . import kernels as K
 from . import spconv
 from . import train_ops as T
-from .autograd import Conv2dFn, PSWarpBatchFn, PSWarpFn, RpnLossFn, bev_precision
+from .autograd import AuxHeadFn, Conv2dFn, FocalLossFn, GuidedDecodeFn, PSWarpBatchFn, PSWarpFn, RpnLossFn, bev_precision, bn_relu_2d
 from .config import _wrap, obj_from_dict
 from .kitti_common import kitti_bbox2results
 from .pipeline import InferencePlan
@@ -234,7 +234,7 @@ class BEVNet(nn.Module):
         for i in range(8):
             conv, bn = getattr(self, 'conv%d' % i), getattr(self, 'bn%d' % i)
             if self.training or (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)):
-                x = torch.relu(bn(conv(x)))                 # batch statistics: BN stays a torch op in training
+                x = bn_relu_2d(bn, conv(x))                 # batch statistics + ReLU: sassd_bn2d_relu_* (two launches)
             else:
                 s, b = _bn_affine(bn)
                 x = conv.hip_forward(x, s, b, True)
@@ -244,16 +244,26 @@ class BEVNet(nn.Module):
 
 
 class SpMiddleFHD(nn.Module):
-    def __init__(self, output_shape, num_input_features=4, num_hidden_features=128):
+    def __init__(self, output_shape, num_input_features=4, num_hidden_features=128, aux_offset=(0., -40., -3.),
+                 aux_voxel_size=(.05, .05, .1)):
+        """aux_offset / aux_voxel_size: lower corner of the point-cloud range and the voxel size the auxiliary head's
+        voxel centres are computed with.  The reference hard-codes KITTI's (cmn.py:121-127: offset (0, -40, -3), voxel
+        sizes (.1, .1, .2) / (.2, .2, .4) / (.4, .4, .8) = 2, 4, 8 x the input voxel) -- the defaults; a config for
+        another range (the Waymo-scale workload) passes its own."""
         super().__init__()
         self.sparse_shape = output_shape
+        self.aux_offset = tuple(float(v) for v in aux_offset)
+        self.aux_voxel_size = tuple(float(v) for v in aux_voxel_size)
         self.backbone = VxNet(num_input_features)
         self.fcn = BEVNet(in_features=num_hidden_features, num_filters=256)
         self.point_fc = nn.Linear(160, 64, bias=False)        # training-only auxiliary head (cmn.py:27-29)
         self.point_cls = nn.Linear(64, 1, bias=False)
         self.point_reg = nn.Linear(64, 3, bias=False)
-        # scene extent / bin size for the exact binned 3-NN of the aux head (any values give identical results)
-        self.aux_xy_range, self.aux_bin = (0., -40., 70.4, 40.), 1.6
+        # scene extent / bin size for the exact binned 3-NN of the aux head (any values give identical results; the
+        # extent of the voxel centres keeps the bins evenly filled)
+        ox, oy, vx, vy = self.aux_offset[0], self.aux_offset[1], self.aux_voxel_size[0], self.aux_voxel_size[1]
+        self.aux_xy_range = (ox, oy, ox + float(output_shape[2]) * vx, oy + float(output_shape[1]) * vy)
+        self.aux_bin = 32 * vx
 
     def build_aux_target(self, nxyz, gt_boxes3d, enlarge=1.0):
         """cmn.py:45-72 with the point-in-box test on the device (sassd_pts_in_boxes3d)."""
@@ -274,8 +284,35 @@ class SpMiddleFHD(nn.Module):
             offsets = torch.where(inside[:, None], off, offsets)
         return labels, offsets
 
+    # The auxiliary head in training as three fused launches + the three 3-NN searches (sassd_aux_*), instead of ~150
+    # small torch / library launches; False keeps the module-by-module formulation (A/B, parity tests).
+    fused_aux = True
+
+    def _aux_loss_fused(self, ctx, gt_bboxes):
+        """aux_loss on the fused kernels: `ctx` = (voxel_features, coors, middle tensors, batch size) left by forward."""
+        voxel_features, coors, middle, batch_size = ctx
+        dev = voxel_features.device
+        counts = [int(g.shape[0]) for g in gt_bboxes]
+        gt_all = torch.cat([g.float() for g in gt_bboxes], 0).contiguous() if sum(counts) else None
+        points, known, label, target, npos = K.aux_prepare(
+            voxel_features.detach().float().contiguous(), coors.int().contiguous(),
+            [m.indices.int().contiguous() for m in middle], self.aux_voxel_size, self.aux_offset, gt_all,
+            K.gt_offsets(counts, dev), batch_size)
+        nn_idx, nn_d2 = [], []
+        for kn, mult in zip(known, (2, 4, 8)):
+            d2, idx = K.three_nn_binned(points, kn, self.aux_xy_range,
+                                        min(self.aux_bin, 4 * self.aux_voxel_size[0] * mult), batch_size)
+            nn_idx.append(idx)
+            nn_d2.append(d2)
+        sums = AuxHeadFn.apply(middle[0].features, middle[1].features, middle[2].features, self.point_fc.weight,
+                               self.point_cls.weight, self.point_reg.weight, nn_idx, nn_d2, label, target, npos)
+        n = len(gt_bboxes)
+        return dict(aux_loss_cls=sums[0:1] / n, aux_loss_reg=sums[1:2] / n)
+
     def aux_loss(self, points, point_cls, point_reg, gt_bboxes):
         """cmn.py:74-104."""
+        if point_cls is None and isinstance(points, tuple):      # forward() left the fused context
+            return self._aux_loss_fused(points, gt_bboxes)
         n = len(gt_bboxes)
         pts_labels, center_targets = self.build_aux_target(points, gt_bboxes)
         pos, neg = (pts_labels > 0).float(), (pts_labels == 0).float()
@@ -306,12 +343,17 @@ class SpMiddleFHD(nn.Module):
         if is_test:
             return x, conv6
         # auxiliary network (cmn.py:121-135): multi-scale voxel features interpolated back to the voxel means
+        if (self.fused_aux and voxel_features.is_cuda and torch.is_grad_enabled() and voxel_features.shape[0] > 0
+                and all(m.features.shape[0] > 0 for m in middle)
+                and [m.features.shape[1] for m in middle] == [32, 64, 64]):
+            return x, conv6, ((voxel_features, coors, middle, batch_size), None, None)
         points_mean = torch.zeros_like(voxel_features)
         points_mean[:, 0] = coors[:, 0]
         points_mean[:, 1:] = voxel_features[:, :3]
         ps = []
-        for m, vs in zip(middle, ((.1, .1, .2), (.2, .2, .4), (.4, .4, .8))):
-            feat, nxyz = self.tensor2points(m, (0, -40., -3.), vs)
+        for m, mult in zip(middle, (2, 4, 8)):
+            vs = tuple(v * mult for v in self.aux_voxel_size)
+            feat, nxyz = self.tensor2points(m, self.aux_offset, vs)
             # exact for any bin edge (the ring search widens until the third neighbour is inside its reach); four
             # voxels of the scale per bin keeps the 3x3 ring at a few hundred candidates instead of ~1000
             grid = (self.aux_xy_range, min(self.aux_bin, 4 * vs[0]), batch_size)
@@ -463,6 +505,10 @@ class SSDRotateHead(nn.Module):
                                                            avg_factor=1.) / b * .2
         return out
 
+    # decode / flip / ground-truth prefix of the padded guided anchors in one fused kernel each way; False keeps the torch
+    # gather / split / cat formulation (A/B, parity tests)
+    fused_tail = True
+
     def get_guided_anchors_padded(self, box_preds, cls_preds, dir_cls_preds, anchors, anchors_mask, gt_bboxes, thr=.1,
                                   cap=None):
         """The training-mode selection of get_guided_anchors without its host round trip (boolean compaction): the
@@ -485,6 +531,16 @@ class SSDRotateHead(nn.Module):
             self._guided_overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         sel, cnt = K.guided_select(cls_preds.detach().reshape(b, a, self._num_class).contiguous(), mask, thr, cap,
                                    self._guided_overflow)
+        counts = [int(g.shape[0]) for g in gt_bboxes]
+        gmax = max(counts) if counts else 0
+        if self.fused_tail:
+            # decode + direction flip + ground-truth prefix in one kernel each way (sassd_guided_decode_*)
+            gt_all = torch.cat([g.float() for g in gt_bboxes], 0).contiguous() if sum(counts) else None
+            guided, total = GuidedDecodeFn.apply(box_preds.view(b, a, self._box_code_size),
+                                                 dir_cls_preds.view(b, a, 2) if self._use_direction_classifier else None,
+                                                 anchors.view(b, a, 7).contiguous(), sel, cnt, gt_all,
+                                                 K.gt_offsets(counts, dev), gmax)
+            return guided, total
         s7 = sel.unsqueeze(-1).expand(b, cap, 7)
         box = T.second_box_decode(box_preds.view(b, a, self._box_code_size).gather(1, s7),
                                   anchors.view(b, a, 7).gather(1, s7))
@@ -492,8 +548,6 @@ class SSDRotateHead(nn.Module):
             dirp = dir_cls_preds.view(b, a, 2).gather(1, sel.unsqueeze(-1).expand(b, cap, 2))
             opp = (box[..., -1] > 0) ^ (dirp[..., 1] > dirp[..., 0])          # argmax of two = (second > first)
             box = torch.cat([box[..., :-1], (box[..., -1] + opp.type_as(box) * np.pi).unsqueeze(-1)], dim=-1)
-        counts = [int(g.shape[0]) for g in gt_bboxes]
-        gmax = max(counts) if counts else 0
         rows = []
         for i in range(b):
             parts = [gt_bboxes[i].type_as(box), box[i]] if counts[i] else [box[i]]
@@ -584,7 +638,7 @@ class PSWarpHead(nn.Module):
         """guided_anchors: list (per sample) of [K,7] device tensors -> list of [K] logits."""
         grad = torch.is_grad_enabled() and (x.requires_grad or self.convs[0].weight.requires_grad)
         if self.training or grad:
-            f = self.convs(x)
+            f = self._convs_train(x)
         else:
             s, b = _bn_affine(self.convs[1])
             f = self.convs[3].hip_forward(self.convs[0].hip_forward(x, s, b, True))
@@ -604,9 +658,15 @@ class PSWarpHead(nn.Module):
             scores.append(lg.view(-1))
         return scores if is_test else torch.cat(scores, 0)
 
+    def _convs_train(self, x):
+        """self.convs(x) with the BatchNorm2d + ReLU pair on the fused kernels."""
+        return self.convs[3](bn_relu_2d(self.convs[1], self.convs[0](x)))
+
+    fused_tail = True          # batched 3-D IoU + fused focal loss in loss_padded (False: the torch formulation, A/B)
+
     def forward_padded(self, x, guided, counts):
         """guided [B, capK, 7] padded, counts [B] int32 (device) -> logits [B, capK] (zero past a sample's count)."""
-        return PSWarpBatchFn.apply(self.convs(x), guided.float(), counts, tuple(self.grid_offsets),
+        return PSWarpBatchFn.apply(self._convs_train(x), guided.float(), counts, tuple(self.grid_offsets),
                                    1.0 / self.featmap_stride)
 
     def loss_padded(self, logits, gt_bboxes, guided, counts, cfg):
@@ -622,19 +682,26 @@ class PSWarpHead(nn.Module):
         num_pos = torch.empty(b, dtype=torch.int32, device=dev)
         boxes = guided.detach().float().contiguous()
         row_ok = (torch.arange(capk, device=dev, dtype=torch.int32)[None, :] < counts[:, None]).view(torch.uint8)
-        ovs, offs, o = [], [0], 0
-        for i in range(b):
-            if g_counts[i]:
-                ovs.append(iou3d_utils.boxes_iou3d_gpu(boxes[i], gt_bboxes[i].float()).reshape(-1))
-            o += capk * g_counts[i]
-            offs.append(o)
-        ov = torch.cat(ovs) if len(ovs) > 1 else (ovs[0] if ovs else None)
         if cfg.assigner.similarity_fn != 'RotateIou3dSimilarity':
             raise NotImplementedError("padded rescoring loss: RotateIou3dSimilarity only")
-        K.assign_targets(boxes, row_ok.contiguous(), torch.cat([g.float() for g in gt_bboxes]).contiguous() if tot else None,
-                         None, None, K.gt_offsets(g_counts, dev), cfg.assigner.pos_iou_thr, cfg.assigner.neg_iou_thr,
+        offs, o = [0], 0
+        for i in range(b):
+            o += capk * g_counts[i]
+            offs.append(o)
+        gt_all = torch.cat([g.float() for g in gt_bboxes]).contiguous() if tot else None
+        if self.fused_tail and tot:
+            # every sample's rotated 3-D IoU matrix in one launch (sassd_boxes_iou3d_batch)
+            ov = K.boxes_iou3d_batch(boxes, counts.contiguous(), gt_all, K.gt_offsets(g_counts, dev), max(g_counts),
+                                     _const_i64(dev, offs), o)
+        else:
+            ovs = [iou3d_utils.boxes_iou3d_gpu(boxes[i], gt_bboxes[i].float()).reshape(-1) for i in range(b) if g_counts[i]]
+            ov = torch.cat(ovs) if len(ovs) > 1 else (ovs[0] if ovs else None)
+        K.assign_targets(boxes, row_ok.contiguous(), gt_all, None, None, K.gt_offsets(g_counts, dev),
+                         cfg.assigner.pos_iou_thr, cfg.assigner.neg_iou_thr,
                          labels, targets, num_pos, overlaps=ov.contiguous() if ov is not None else boxes,
                          overlap_offsets=_const_i64(dev, offs))
+        if self.fused_tail and self._num_class == 1:
+            return dict(loss_cls=FocalLossFn.apply(logits, labels, num_pos) / b)
         labels = labels.view(-1, 1)
         cared, positives = labels >= 0, labels > 0
         w = cared.float() / torch.clamp(num_pos.sum().float(), min=1.0)
@@ -705,8 +772,13 @@ class SingleStageDetector(nn.Module):
     def merge_second_batch(self, batch_args):
         """single_stage.py:52-73."""
         ret = {}
+        merged = batch_args.get('sassd_merged')          # sassd.train.device_batch: the batch is already one buffer
         for key, elems in batch_args.items():
-            if key in ('voxels', 'num_points'):
+            if key == 'sassd_merged':
+                continue
+            if merged is not None and key in merged:
+                ret[key] = merged[key]
+            elif key in ('voxels', 'num_points'):
                 ret[key] = torch.cat(elems, dim=0)
             elif key == 'coordinates':
                 ret[key] = torch.cat([nn.functional.pad(c, [1, 0, 0, 0], mode='constant', value=i)

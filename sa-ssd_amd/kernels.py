@@ -858,3 +858,161 @@ def bn_relu_bwd(x, dy, gamma, beta, mean, invstd):
                                         _C.ptr(invstd), _C.ptr(dx), _C.ptr(dg), _C.ptr(db), _C.ptr(ws), ws.numel(),
                                         _C.stream()), "sassd_bn_relu_bwd")
     return dx, dg, db
+
+
+# ---- fused BatchNorm2d + ReLU over NCHW maps (bn2d.hip) -----------------------------------------------------------------
+def bn2d_relu_supported(x):
+    return x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda and (x.shape[2] * x.shape[3]) % 4 == 0
+
+
+def bn2d_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps):
+    """x [B,C,H,W] -> (y, save_mean, save_invstd); running statistics updated in place (None for both to skip)."""
+    _chk_cuda(x, gamma, beta, running_mean, running_var)
+    b, c, h, w = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    L = _C.lib()
+    wsb = L.sassd_bn2d_relu_workspace_bytes(c)
+    ws = workspace("bn2d_relu", wsb, x.device)
+    _C.check(L.sassd_bn2d_relu_fwd(_C.ptr(x), b, c, h * w, _C.ptr(gamma), _C.ptr(beta), _C.ptr(running_mean),
+                                   _C.ptr(running_var), float(momentum), float(eps), _C.ptr(y), _C.ptr(mean),
+                                   _C.ptr(invstd), _C.ptr(ws), wsb, _C.stream()), "sassd_bn2d_relu_fwd")
+    return y, mean, invstd
+
+
+def bn2d_relu_bwd(x, dy, gamma, beta, mean, invstd):
+    """-> (dx, dgamma, dbeta)."""
+    _chk_cuda(x, dy, gamma, beta, mean, invstd)
+    b, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    L = _C.lib()
+    wsb = L.sassd_bn2d_relu_workspace_bytes(c)
+    ws = workspace("bn2d_relu", wsb, x.device)
+    _C.check(L.sassd_bn2d_relu_bwd(_C.ptr(x), _C.ptr(dy), b, c, h * w, _C.ptr(gamma), _C.ptr(beta), _C.ptr(mean),
+                                   _C.ptr(invstd), _C.ptr(dx), _C.ptr(dg), _C.ptr(db), _C.ptr(ws), wsb, _C.stream()),
+             "sassd_bn2d_relu_bwd")
+    return dx, dg, db
+
+
+# ---- fused auxiliary head of SpMiddleFHD in training (aux_head.hip) ----------------------------------------------------
+def _ptr3(ts):
+    import ctypes as C
+    return (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+
+
+def aux_prepare(voxel_feats, coors, indices, voxel_size, offset, gt_boxes, gt_off, batch_size):
+    """-> (points [N,4], known [3 x [M_s,4]], label [N] uint8, target [N,3], npos [1] int32).  voxel_feats [N,>=3] fp32,
+    coors [N,4] int32 (b,z,y,x), indices: the three middle tensors' [M_s,4] int32 coordinates, gt_boxes [T,7] (or None),
+    gt_off [B+1] int32 (gt_offsets())."""
+    import ctypes as C
+    _chk_cuda(voxel_feats, coors, gt_boxes, gt_off, *indices)
+    assert coors.dtype == torch.int32 and all(i.dtype == torch.int32 for i in indices)
+    dev = voxel_feats.device
+    n = voxel_feats.shape[0]
+    points = torch.empty(n, 4, dtype=torch.float32, device=dev)
+    known = [torch.empty(max(i.shape[0], 1), 4, dtype=torch.float32, device=dev) for i in indices]
+    label = torch.empty(n, dtype=torch.uint8, device=dev)
+    target = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    npos = torch.empty(1, dtype=torch.int32, device=dev)
+    m = (C.c_int * 3)(*[int(i.shape[0]) for i in indices])
+    vs, off = _f32(voxel_size), _f32(offset)
+    _C.check(_C.lib().sassd_aux_prepare(_C.ptr(voxel_feats), int(voxel_feats.shape[1]), _C.ptr(coors), n, _ptr3(indices),
+                                        m, vs.ctypes.data, off.ctypes.data, _C.ptr(gt_boxes), _C.ptr(gt_off),
+                                        int(batch_size), _C.ptr(points), _ptr3(known), _C.ptr(label), _C.ptr(target),
+                                        _C.ptr(npos), _C.stream()), "sassd_aux_prepare")
+    return points, [k[:i.shape[0]] for k, i in zip(known, indices)], label, target, npos
+
+
+def aux_head_fwd(feats, nn_idx, nn_d2, w1, w2, label, target, npos):
+    """-> (loss_sums [2], wgt [N,9], h [N,64], out [N,4], gout [N,4])."""
+    _chk_cuda(w1, w2, label, target, npos, *feats, *nn_idx, *nn_d2)
+    n = label.shape[0]
+    dev = label.device
+    assert tuple(w1.shape) == (64, 160) and tuple(w2.shape) == (4, 64) and [f.shape[1] for f in feats] == [32, 64, 64]
+    wgt = torch.empty(n, 9, dtype=torch.float32, device=dev)
+    h = torch.empty(n, 64, dtype=torch.float32, device=dev)
+    out = torch.empty(n, 4, dtype=torch.float32, device=dev)
+    gout = torch.empty(n, 4, dtype=torch.float32, device=dev)
+    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    L = _C.lib()
+    wsb = L.sassd_aux_head_workspace_bytes(n)
+    ws = workspace("aux_head", wsb, dev)
+    _C.check(L.sassd_aux_head_fwd(n, _ptr3(feats), _ptr3(nn_idx), _ptr3(nn_d2), _C.ptr(w1), _C.ptr(w2), _C.ptr(label),
+                                  _C.ptr(target), _C.ptr(npos), _C.ptr(wgt), _C.ptr(h), _C.ptr(out), _C.ptr(gout),
+                                  _C.ptr(sums), _C.ptr(ws), wsb, _C.stream()), "sassd_aux_head_fwd")
+    return sums, wgt, h, out, gout
+
+
+def aux_head_bwd(feats, nn_idx, w1, w2, wgt, h, gout, grad_sums):
+    """-> (grad_feats [3 x [M_s, C_s]], dw1 [64,160], dw2 [4,64])."""
+    import ctypes as C
+    _chk_cuda(w1, w2, wgt, h, gout, grad_sums, *feats, *nn_idx)
+    n = h.shape[0]
+    dev = h.device
+    gf = [torch.empty_like(f) for f in feats]
+    dw1 = torch.empty(64, 160, dtype=torch.float32, device=dev)
+    dw2 = torch.empty(4, 64, dtype=torch.float32, device=dev)
+    m = (C.c_int * 3)(*[int(f.shape[0]) for f in feats])
+    L = _C.lib()
+    wsb = L.sassd_aux_head_workspace_bytes(n)
+    ws = workspace("aux_head", wsb, dev)
+    _C.check(L.sassd_aux_head_bwd(n, _ptr3(feats), m, _ptr3(nn_idx), _C.ptr(w1), _C.ptr(w2), _C.ptr(wgt), _C.ptr(h),
+                                  _C.ptr(gout), _C.ptr(grad_sums), _ptr3(gf), _C.ptr(dw1), _C.ptr(dw2), _C.ptr(ws), wsb,
+                                  _C.stream()), "sassd_aux_head_bwd")
+    return gf, dw1, dw2
+
+
+# ---- guided-anchor / rescoring tail of the training step (train_heads.hip) ---------------------------------------------
+def guided_decode_fwd(box_preds, dir_preds, anchors, sel, sel_count, gt_boxes, gt_off, gmax):
+    """box_preds [B,A,7], dir_preds [B,A,2] or None, anchors [A,7] / [B,A,7], sel [B,cap] int64, sel_count [B] int32 ->
+    (guided [B, gmax + cap, 7], counts [B] int32)."""
+    _chk_cuda(box_preds, dir_preds, anchors, sel, sel_count, gt_boxes, gt_off)
+    b, a, _ = box_preds.shape
+    cap = sel.shape[1]
+    guided = torch.empty(b, gmax + cap, 7, dtype=torch.float32, device=box_preds.device)
+    counts = torch.empty(b, dtype=torch.int32, device=box_preds.device)
+    _C.check(_C.lib().sassd_guided_decode_fwd(_C.ptr(box_preds), _C.ptr(dir_preds), _C.ptr(anchors),
+                                              1 if anchors.dim() == 3 else 0, _C.ptr(sel), _C.ptr(sel_count),
+                                              _C.ptr(gt_boxes), _C.ptr(gt_off), a, b, cap, int(gmax), _C.ptr(guided),
+                                              _C.ptr(counts), _C.stream()), "sassd_guided_decode_fwd")
+    return guided, counts
+
+
+def guided_decode_bwd(box_preds, anchors, sel, sel_count, gt_off, gmax, dguided):
+    _chk_cuda(box_preds, anchors, sel, sel_count, gt_off, dguided)
+    b, a, _ = box_preds.shape
+    dbox = torch.empty_like(box_preds)
+    _C.check(_C.lib().sassd_guided_decode_bwd(_C.ptr(box_preds), _C.ptr(anchors), 1 if anchors.dim() == 3 else 0,
+                                              _C.ptr(sel), _C.ptr(sel_count), _C.ptr(gt_off), a, b, sel.shape[1],
+                                              int(gmax), _C.ptr(dguided), _C.ptr(dbox), _C.stream()),
+             "sassd_guided_decode_bwd")
+    return dbox
+
+
+def boxes_iou3d_batch(boxes, counts, gt_boxes, gt_off, gmax, ov_off, total):
+    """boxes [B,rows,7], counts [B] int32, gt_boxes [T,7], gt_off [B+1] int32, ov_off [B+1] int64 -> overlaps [total]."""
+    _chk_cuda(boxes, counts, gt_boxes, gt_off, ov_off)
+    b, rows, _ = boxes.shape
+    ov = torch.empty(max(int(total), 1), dtype=torch.float32, device=boxes.device)
+    _C.check(_C.lib().sassd_boxes_iou3d_batch(_C.ptr(boxes), _C.ptr(counts), b, rows, _C.ptr(gt_boxes), _C.ptr(gt_off),
+                                              int(gmax), _C.ptr(ov_off), _C.ptr(ov), _C.stream()),
+             "sassd_boxes_iou3d_batch")
+    return ov
+
+
+def focal_loss(logits, labels, num_pos):
+    """logits [n] fp32, labels [n] int64, num_pos [nb] int32 -> (loss_sum [1], grad [n])."""
+    _chk_cuda(logits, labels, num_pos)
+    n = logits.numel()
+    dev = logits.device
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    grad = torch.empty(n, dtype=torch.float32, device=dev)
+    L = _C.lib()
+    wsb = L.sassd_focal_loss_workspace_bytes(n)
+    ws = workspace("focal_loss", wsb, dev)
+    _C.check(L.sassd_focal_loss(_C.ptr(logits), _C.ptr(labels), n, _C.ptr(num_pos), num_pos.numel(), _C.ptr(out),
+                                _C.ptr(grad), _C.ptr(ws), wsb, _C.stream()), "sassd_focal_loss")
+    return out, grad

@@ -117,7 +117,8 @@ def workload(name):
         an = A.AnchorGeneratorStride(sizes=_ANCHOR_SIZES["Car"], anchor_strides=[.8, .8, 1.],
                                      anchor_offsets=[-74.8, -74.8, -1.0], rotations=[0, 1.57])([1, 188, 188]).reshape(-1, 7)
         w = dict(cfg="configs/car_cfg.py", class_names=["Car"],
-                 overrides=dict(neck=dict(output_shape=[40, 1504, 1504]),
+                 overrides=dict(neck=dict(output_shape=[40, 1504, 1504], aux_offset=WAYMO_RANGE[:3],
+                                          aux_voxel_size=WAYMO_VOXEL),
                                 extra_head=dict(grid_offsets=(75.2, 75.2), featmap_stride=0.8)),
                  frame=lambda seed=0: waymo_synth(seed)[:180000], points_cap=180000,
                  plan=dict(num_class=1, voxel_size=WAYMO_VOXEL, point_cloud_range=WAYMO_RANGE, max_voxels=150000,

@@ -520,35 +520,83 @@ def load_params_from_file(model, filename, to_cpu=False):
 
 
 def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, voxel_size, pc_range,
-                 max_points=5, max_voxels=20000, area_threshold=1, model=None):
+                 max_points=5, max_voxels=20000, area_threshold=1, model=None, level_cap_factor=2):
     """What KittiLiDAR.prepare_train_img + collate produce (kitti.py:212-262,333-343), built on the device from raw
     points already in HBM: HIP voxelizer + HIP anchor mask.  points: list of [N,4] device tensors; gt_bboxes: list of
     [G,7] device tensors; anchors: {class: [A,7] device}; anchors_bv: {class: [A,4] device}.
     With `model`, the seven sparse-conv rulebooks of the batch are built here too (key 'sassd_rulebooks'), so the
     forward pass contains no host synchronisation before its guided-anchor selection.
-    Returns the keyword arguments of SingleStageDetector.forward(return_loss=True)."""
+    Returns the keyword arguments of SingleStageDetector.forward(return_loss=True).
+
+    Two host synchronisations per batch, whatever its size: every sample is voxelized into ONE coordinate / payload buffer
+    through the row-offset chain of sassd_voxelize (then one read of the B + 1 offsets: the reference API carries
+    exact-size tensors), the anchor masks of all samples come from one sassd_anchor_mask_batch sequence per class, and
+    the rulebooks from the fused pyramid (sassd_rulebook_pyramid, 11 launches, capacity-sized tables) followed by one
+    read of the three down-sampled row counts + the status word.  The merged batch tensors ride along under
+    'sassd_merged' so that merge_second_batch does not concatenate the per-sample views again."""
     vs, cr = list(voxel_size), list(pc_range)
     w0 = int(round((cr[3] - cr[0]) / vs[0]))
     h0 = int(round((cr[4] - cr[1]) / vs[1]))
-    kw = dict(img=None, img_meta=[dict(sample_idx=i) for i in range(len(points))], return_loss=True, voxels=[],
+    B = len(points)
+    dev = points[0].device
+    ndim = points[0].shape[1]
+    cap0 = B * int(max_voxels)
+    kw = dict(img=None, img_meta=[dict(sample_idx=i) for i in range(B)], return_loss=True, voxels=[],
               coordinates=[], num_points=[], anchors={c: [] for c in class_names},
               anchors_mask={c: [] for c in class_names}, gt_bboxes=list(gt_bboxes), gt_labels=[],
               gt_types=list(gt_types))
+    voxels = torch.empty(cap0, max_points, ndim, dtype=torch.float32, device=dev)
+    coors4 = torch.empty(cap0, 4, dtype=torch.int32, device=dev)
+    nump = torch.empty(cap0, dtype=torch.int32, device=dev)
+    row_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    vnum = torch.zeros(B, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
     for b, p in enumerate(points):
-        r = K.voxelize(p, vs, cr, max_points, max_voxels, batch_idx=0, coors_cols=4, want_mean=False)
-        m = int(r["voxel_num"].item())                     # the reference API carries exact-size tensors
-        kw["voxels"].append(r["voxels"][:m])
-        kw["coordinates"].append(r["coors"][:m, 1:])
-        kw["num_points"].append(r["num_points"][:m])
-        zero = torch.zeros(1, dtype=torch.int32, device=p.device)
+        K.voxelize(p, vs, cr, max_points, max_voxels, batch_idx=b, coors_cols=4, want_voxels=True, want_mean=False,
+                   out=dict(voxels=voxels, coors=coors4, num_points=nump, voxel_num=vnum[b:b + 1]),
+                   row_offset=row_off[b:b + 2], status=status, cap=cap0)
+    masks = {}
+    for c in class_names:                                  # coordinate-only work, queued before the first host read
+        masks[c] = torch.empty(B, anchors_bv[c].shape[0], dtype=torch.uint8, device=dev)
+        K.anchor_mask_batch(coors4, row_off, B, h0, w0, anchors_bv[c], vs, cr, area_threshold, masks[c])
+    offs = row_off.cpu().numpy()                           # host sync 1: the per-sample row ranges
+    n0 = int(offs[B])
+    for b in range(B):
+        lo, hi = int(offs[b]), int(offs[b + 1])
+        kw["voxels"].append(voxels[lo:hi])
+        kw["coordinates"].append(coors4[lo:hi, 1:])
+        kw["num_points"].append(nump[lo:hi])
         for c in class_names:
-            mask = K.anchor_mask(r["coors"], zero, r["voxel_num"], h0, w0, anchors_bv[c], vs, cr, area_threshold)
             kw["anchors"][c].append(anchors[c])
-            kw["anchors_mask"][c].append(mask.bool())
+            kw["anchors_mask"][c].append(masks[c][b].bool())
         names = list(class_names)
         lab = [names.index(t) + 1 if t in names else 0 for t in gt_types[b]]
-        kw["gt_labels"].append(torch.tensor(lab, dtype=torch.int64, device=p.device))
+        kw["gt_labels"].append(torch.tensor(lab, dtype=torch.int64, device=dev))
+    kw["sassd_merged"] = dict(voxels=voxels[:n0], num_points=nump[:n0], coordinates=coors4[:n0])
     if model is not None:
-        coors = torch.cat([torch.nn.functional.pad(c, [1, 0, 0, 0], value=i) for i, c in enumerate(kw["coordinates"])], 0)
-        kw["sassd_rulebooks"] = model.neck.backbone.precompute_rulebooks(coors, model.neck.sparse_shape, len(points))
+        shape0 = [int(v) for v in model.neck.sparse_shape]
+        caps = [max(n0, 1)] + [max(n0 * level_cap_factor, 1)] * 3
+        idx = [coors4[:max(n0, 1)]] + [torch.empty(c, 4, dtype=torch.int32, device=dev) for c in caps[1:]]
+        n_dev = torch.zeros(3, dtype=torch.int32, device=dev)
+        n_ptrs = [row_off[B:B + 1]] + [n_dev[i:i + 1] for i in range(3)]
+        nbr_s = [torch.empty(c, 27, dtype=torch.int32, device=dev) for c in caps]
+        nbr_d = [None] + [torch.empty(c, 27, dtype=torch.int32, device=dev) for c in caps[1:]]
+        pyr = K.RulebookPyramid(idx, n_ptrs, caps, shape0, B, nbr_s, nbr_d, status)
+        pyr.build()
+        tail = torch.cat([n_dev, status]).cpu().numpy()    # host sync 2: down-sampled row counts + overflow flags
+        if int(tail[3]) != 0:
+            raise RuntimeError("device_batch: status 0x%x (voxel / rulebook capacity overflow: raise max_voxels or "
+                               "level_cap_factor)" % int(tail[3]))
+        n = [n0] + [int(v) for v in tail[:3]]
+        shapes = [shape0]
+        for _ in range(3):
+            shapes.append(list(K.conv_out_shape(shapes[-1])))
+        books = {}
+        for l in range(4):
+            il = idx[l][:n[l]]
+            books["subm%d" % l] = (il, nbr_s[l][:max(n[l], 1)], shapes[l], None)
+            if l > 0:
+                books["down%d" % (l - 1)] = (il, nbr_d[l][:max(n[l], 1)], shapes[l], None)
+        books["_keep"] = pyr                              # workspace + argument block live as long as the rulebooks
+        kw["sassd_rulebooks"] = books
     return kw

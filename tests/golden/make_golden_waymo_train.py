@@ -38,7 +38,8 @@ def build():
     """(model on CPU in train mode, config, anchors [A,7], anchors_bv [A,4], cloud [180000,4], gt [12,7])."""
     c = Config.fromfile(os.path.join(ROOT, "configs", "car_cfg.py"))
     mcfg = dict(c.model)
-    mcfg["neck"] = dict(mcfg["neck"], output_shape=[40, 1504, 1504])
+    mcfg["neck"] = dict(mcfg["neck"], output_shape=[40, 1504, 1504], aux_offset=synth.WAYMO_RANGE[:3],
+                        aux_voxel_size=synth.WAYMO_VOXEL)
     mcfg["extra_head"] = dict(mcfg["extra_head"], grid_offsets=(75.2, 75.2), featmap_stride=0.8)
     model = synth.randomize_detector(build_detector(mcfg, c.train_cfg, c.test_cfg), SEED_MODEL, cls_bias=-3.0,
                                      sparse_fan_div=1)
@@ -82,7 +83,8 @@ def main():
     a = c.train_cfg.rpn.assigner["Car"]
     args = (sd, feats, coors, 1, (40, 1504, 1504), [gt], types, ["Car"], {"Car": an[None]}, {"Car": m[None]},
             {"Car": (a.pos_iou_thr, a.neg_iou_thr)})
-    kw = dict(grid_offsets=(75.2, 75.2), featmap_stride=0.8)
+    kw = dict(grid_offsets=(75.2, 75.2), featmap_stride=0.8, aux_offset=synth.WAYMO_RANGE[:3],
+              aux_voxel_size=synth.WAYMO_VOXEL)
     losses, grads, ex = train_ref.train_step(*args, **kw)
     top = torch.sigmoid(ex["cls"]).reshape(1, -1)[torch.from_numpy(m[None])].numpy()
     thr = H.safe_threshold(0.1, top, margin=1e-4, step=2.5e-4)

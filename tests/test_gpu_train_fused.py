@@ -329,3 +329,105 @@ def test_bn_relu_fused_matches_torch(dev, n, c):
     close(rv, bn.running_var)
     y2 = BnReluFn.apply(x, gam.detach(), bet.detach(), None, None, 0.01, 1e-3)       # bit-reproducible, stats optional
     assert torch.equal(y2, y.detach())
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 200, 176), (1, 256, 188, 188), (2, 28, 200, 176), (3, 7, 6, 10)])
+def test_bn2d_relu_fused_matches_torch(dev, shape):
+    """sassd_bn2d_relu_fwd / _bwd (NCHW) against torch BatchNorm2d(training) + ReLU: output, the three gradients and the
+    running statistics (fp32; sums in a different order: 2e-5 / 1e-4 relative to each tensor's scale, as for the sparse
+    pair).  Shapes: the BEV stack at batch 2 / the Waymo-scale map, the 28-channel part-sensitive head, a tiny map."""
+    from sassd.autograd import BnRelu2dFn
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    x = (torch.randn(*shape, generator=g) * 1.7 + 0.4).to(dev)
+    dy = torch.randn(*shape, generator=g).to(dev)
+    bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g).to(dev) + 0.5)
+        bn.bias.copy_((torch.randn(c, generator=g) * 0.3).to(dev))
+        bn.running_mean.normal_(0, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    xr = x.clone().requires_grad_()
+    torch.relu(bn(xr)).backward(dy)
+    xf = x.clone().requires_grad_()
+    gam, bet = bn.weight.detach().clone().requires_grad_(), bn.bias.detach().clone().requires_grad_()
+    y = BnRelu2dFn.apply(xf, gam, bet, rm, rv, 0.01, 1e-3)
+    y.backward(dy)
+    with torch.no_grad():
+        y_ref = torch.relu(torch.nn.functional.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.0, 1e-3))
+
+    def close(a, b, tol=2e-5):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= tol * scale, (float((a - b).abs().max()), scale)
+    close(y, y_ref)
+    close(xf.grad, xr.grad, 1e-4)
+    close(gam.grad, bn.weight.grad, 1e-4)
+    close(bet.grad, bn.bias.grad, 1e-4)
+    close(rm, bn.running_mean)
+    close(rv, bn.running_var)
+    y2 = BnRelu2dFn.apply(x, gam.detach(), bet.detach(), None, None, 0.01, 1e-3)       # bit-reproducible, stats optional
+    assert torch.equal(y2, y.detach())
+
+
+def test_fused_aux_head_matches_module_path(dev):
+    """The fused auxiliary head (sassd_aux_prepare / sassd_aux_head_fwd / _bwd: voxel centres, point-in-box labels,
+    interpolation weights, three interpolations, three Linear layers, focal + smooth-L1 and the whole backward) against the
+    module-by-module formulation it replaces (tensor2points, nearest_neighbor_interpolate, nn.Linear, build_aux_target,
+    train_ops losses -- itself held to the CPU oracle by test_gpu_train.py): the intermediate tensors first, then both
+    aux loss terms and EVERY parameter gradient of a whole forward_train."""
+    import bench
+    from sassd import train
+    from sassd.detector import SpMiddleFHD
+    w = synth.workload("car")
+    model, cfg = synth.build_detector_for(w, 0, train=True, cls_bias=-3.0)
+    model = model.to(dev).train()
+    anchors = dict(Car=torch.from_numpy(w["anchors"]).to(dev))
+    anchors_bv = dict(Car=torch.from_numpy(w["anchors_bv"]).to(dev))
+    clouds = [torch.from_numpy(synth.k21(i)).to(dev) for i in range(2)]
+    gts = [torch.from_numpy(bench.synth_gt_on_points(synth.k21(i), i)[:8 - 3 * i]).to(dev) for i in range(2)]
+    gts[1][1, :3] = gts[1][0, :3] + 0.3                       # two overlapping boxes: the LAST containing box wins
+    types = [np.array(["Car"] * int(g.shape[0])) for g in gts]
+    batch = train.device_batch(clouds, gts, types, ["Car"], anchors, anchors_bv, synth.KITTI_VOXEL, synth.KITTI_RANGE,
+                               model=model)
+    # ---- pieces: prepare kernel against the torch expressions -----------------------------------------------------------
+    ret = model.merge_second_batch({k: v for k, v in batch.items() if k not in ("img", "img_meta", "return_loss")})
+    vx = model.backbone(ret["voxels"], ret["num_points"])
+    neck = model.neck
+    with torch.no_grad():
+        SpMiddleFHD.fused_aux = False
+        try:
+            _, _, (pm, pc, pr) = neck(vx, ret["coordinates"], 2, is_test=False, indice_dict=ret.get("sassd_rulebooks"))
+        finally:
+            SpMiddleFHD.fused_aux = True
+        lab_ref, off_ref = neck.build_aux_target(pm, ret["gt_bboxes"])
+    counts = [int(g.shape[0]) for g in gts]
+    points, known, label, target, npos = K.aux_prepare(vx.contiguous(), ret["coordinates"].int().contiguous(),
+                                                       [torch.zeros(1, 4, dtype=torch.int32, device=dev)] * 3,
+                                                       neck.aux_voxel_size, neck.aux_offset, torch.cat(gts).contiguous(),
+                                                       K.gt_offsets(counts, dev), 2)
+    assert torch.equal(points, pm) and torch.equal(label, lab_ref) and int(npos) == int((lab_ref > 0).sum()) > 0
+    assert torch.equal(target, off_ref)
+    # ---- whole step, fused vs module path -------------------------------------------------------------------------------
+    res = {}
+    for fused in (False, True):
+        SpMiddleFHD.fused_aux = fused
+        try:
+            model.zero_grad(set_to_none=True)
+            losses = model(**batch)
+            sum(v.sum() for v in losses.values()).backward()
+        finally:
+            SpMiddleFHD.fused_aux = True
+        res[fused] = ({k: float(v.sum()) for k, v in losses.items()},
+                      {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    for k, v in res[False][0].items():
+        assert abs(res[True][0][k] - v) <= 1e-5 * max(1.0, abs(v)), (k, res[True][0][k], v)
+    assert res[False][0]["aux_loss_cls"] > 0 and res[False][0]["aux_loss_reg"] > 0
+    assert res[True][1].keys() == res[False][1].keys()
+    worst = {}
+    for n, g in res[False][1].items():
+        worst[n] = float((res[True][1][n] - g).norm()) / max(float(g.norm()), 1e-12)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print("fused vs module aux head: losses", {k: (res[True][0][k], res[False][0][k]) for k in ("aux_loss_cls", "aux_loss_reg")},
+          "worst gradient differences", [(k, "%.1e" % v) for k, v in top])
+    assert max(worst.values()) < 1e-4, top

@@ -40,6 +40,22 @@ def _n_ptr(n, dev):
     return t
 
 
+_ident_nbr_cache = {}
+
+
+def _ident_nbr(n, dev):
+    """[n, 27] gather table of a 1x1x1 convolution seen as a 27-offset one: the centre offset (13) maps every row to
+    itself, all other offsets are empty.  Lets the 1x1x1 layer's weight gradient run on sassd_spconv_bwd_weight instead of
+    a library GEMM.  Grow-only cache per device (the rows are independent of the data)."""
+    t = _ident_nbr_cache.get(dev)
+    if t is None or t.shape[0] < n:
+        cap = max(int(n * 1.25), 1024)
+        t = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+        t[:, 13] = torch.arange(cap, dtype=torch.int32, device=dev)
+        _ident_nbr_cache[dev] = t
+    return t[:n]
+
+
 _sp_t_packs = {}
 
 
@@ -92,8 +108,11 @@ class SparseConvFn(Function):
                 nbr_t = K.rulebook_transpose(nbr, _n_ptr(n_out, dev), nbr.shape[0], max(n_in, 1))
                 dx = K.spconv_bwd_data(dyc, nbr_t, _n_ptr(n_in, dev), max(n_in, 1), wt, 27, cin, cout)[:n_in]
         if ctx.needs_input_grad[1]:
-            if nbr is None:
-                dw = (x.t() @ dyc[:n_in]).view(1, cin, cout)          # plain library GEMM for the 1x1x1 layer
+            if nbr is None and n_in > 0 and cin >= 16:
+                # 1x1x1 layer: X^T dY through the sparse weight-gradient kernel over an identity table (centre offset only)
+                dw = K.spconv_bwd_weight(x, dyc, _ident_nbr(n_in, dev), _n_ptr(n_in, dev), n_in, cin, cout)[13:14]
+            elif nbr is None:
+                dw = (x.t() @ dyc[:n_in]).view(1, cin, cout)
             else:
                 xc = x if n_in > 0 else torch.zeros(1, cin, device=dev)
                 dw = K.spconv_bwd_weight(xc, dyc, nbr, _n_ptr(n_out, dev), nbr.shape[0], cin, cout)
@@ -320,13 +339,32 @@ class BnRelu2dFn(Function):
         return dx, dg, db, None, None, None, None
 
 
+_pending_nbt = []
+
+
+def count_bn_batch(bn):
+    """`bn.num_batches_tracked += 1`, deferred: the 23 BatchNorm layers of a training step would each launch a one-element
+    add; the counters are collected here and bumped by ONE multi-tensor add per step (flush_bn_counters, called by
+    sassd.train.train_one_iter and before any state_dict / eval of the detector)."""
+    _pending_nbt.append(bn.num_batches_tracked)
+    if len(_pending_nbt) >= 4096:
+        flush_bn_counters()
+
+
+def flush_bn_counters():
+    if _pending_nbt:
+        ts = list(_pending_nbt)
+        _pending_nbt.clear()
+        torch._foreach_add_(ts, 1)
+
+
 def bn_relu_2d(bn, x):
     """`relu(bn(x))` for a training-mode nn.BatchNorm2d on the fused HIP kernels when the layer / tensor allow it, else
     the torch ops (eval mode, no affine, cumulative-average momentum, exotic shapes)."""
     if (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and torch.is_grad_enabled()
             and K.bn2d_relu_supported(x)):
         y = BnRelu2dFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
-        bn.num_batches_tracked.add_(1)
+        count_bn_batch(bn)
         return y
     return torch.relu(bn(x))
 

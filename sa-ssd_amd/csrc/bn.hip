@@ -3,15 +3,17 @@
 // The reference's sparse blocks are  SubMConv3d / SparseConv3d -> BatchNorm1d(eps 1e-3, momentum 0.01) -> ReLU
 // (mmdet/models/necks/cmn.py:147-173 through spconv.SparseSequential): in training mode torch runs them as
 // collect-statistics + transform + clamp (forward) and threshold + reduce + elementwise (backward), six launches per
-// layer over a 1-9 MB tensor, i.e. launch latency.  Here: two launches each way.
+// layer over a 1-9 MB tensor, i.e. launch latency.  Here: three short launches each way.
 //   forward   bn_stats_kernel      per-channel sum / sum of squares in double -> one partial pair per block
-//             bn_apply_relu_kernel every block first reduces the <= 256 block partials in a fixed order (deterministic;
-//                                  no inter-workgroup hand-off inside a launch) to mean / invstd in LDS, block 0 also
-//                                  stores them and updates the running statistics (unbiased variance, like torch);
-//                                  then y = max(0, (x - mean) * invstd * gamma + beta)
-//   backward  bn_bwd_reduce_kernel dz = dy * (z > 0) with z recomputed from x; partials of sum dz, sum dz * xhat
-//             bn_bwd_apply_kernel  reduces them the same way (block 0 stores dbeta, dgamma), then
-//                                  dx = gamma * invstd * (dz - dbeta / N - xhat * dgamma / N)
+//             bn_finalize_kernel   ONE block adds the <= 256 block partials in a fixed order (deterministic; no
+//                                  inter-workgroup hand-off inside a launch): mean / invstd, running statistics (unbiased
+//                                  variance, like torch).  (Round 2 let every block of the apply launch redo this
+//                                  reduction -- 256 KB of partials per block: 18 us per launch instead of 6.)
+//             bn_apply_relu_kernel y = max(0, (x - mean) * (invstd * gamma) + beta)
+//   backward  bn_bwd_reduce_kernel dz = dy * (z > 0) with z recomputed from x exactly as the forward computed it;
+//                                  partials of sum dz, sum dz * xhat
+//             bn_bwd_finalize_kernel  -> dbeta, dgamma
+//             bn_bwd_apply_kernel  dx = gamma * invstd * (dz - dbeta / N - xhat * dgamma / N)
 // C is a multiple of 4 and at most 256 (the sparse trunk has 16 / 32 / 64).
 #include "common.h"
 
@@ -84,30 +86,33 @@ struct BnApplyArgs {
     float momentum, eps;
 };
 
-__global__ void __launch_bounds__(256) bn_apply_relu_kernel(BnApplyArgs P)
+__global__ void __launch_bounds__(256) bn_finalize_kernel(BnApplyArgs P)
 {
     __shared__ double red[2][256];
-    __shared__ float s_mean[256], s_scale[256], s_shift[256];
-    const int C = P.C;
     double ss = 0.0, qq = 0.0;
-    bn_reduce_partials(P.part, P.nb, C, red, &ss, &qq);
-    if (threadIdx.x < C) {
+    bn_reduce_partials(P.part, P.nb, P.C, red, &ss, &qq);
+    if (threadIdx.x < P.C) {
         const double mean = ss / P.n;
         double var = qq / P.n - mean * mean;
         if (var < 0.0) var = 0.0;
-        const float m = (float)mean, is = (float)(1.0 / sqrt(var + (double)P.eps));
-        s_mean[threadIdx.x] = m;
-        s_scale[threadIdx.x] = is * P.gamma[threadIdx.x];
-        s_shift[threadIdx.x] = P.beta[threadIdx.x];
-        if (blockIdx.x == 0) {
-            P.mean[threadIdx.x] = m;
-            P.invstd[threadIdx.x] = is;
-            if (P.rmean) {
-                const double unb = P.n > 1 ? var * P.n / (P.n - 1) : var;
-                P.rmean[threadIdx.x] = (float)((1.0 - P.momentum) * P.rmean[threadIdx.x] + P.momentum * mean);
-                P.rvar[threadIdx.x] = (float)((1.0 - P.momentum) * P.rvar[threadIdx.x] + P.momentum * unb);
-            }
+        P.mean[threadIdx.x] = (float)mean;
+        P.invstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)P.eps));
+        if (P.rmean) {
+            const double unb = P.n > 1 ? var * P.n / (P.n - 1) : var;
+            P.rmean[threadIdx.x] = (float)((1.0 - P.momentum) * P.rmean[threadIdx.x] + P.momentum * mean);
+            P.rvar[threadIdx.x] = (float)((1.0 - P.momentum) * P.rvar[threadIdx.x] + P.momentum * unb);
         }
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_apply_relu_kernel(BnApplyArgs P)
+{
+    __shared__ float s_mean[256], s_scale[256], s_shift[256];
+    const int C = P.C;
+    if (threadIdx.x < C) {
+        s_mean[threadIdx.x] = P.mean[threadIdx.x];
+        s_scale[threadIdx.x] = P.invstd[threadIdx.x] * P.gamma[threadIdx.x];
+        s_shift[threadIdx.x] = P.beta[threadIdx.x];
     }
     __syncthreads();
     const size_t total = (size_t)P.n * C / 4;
@@ -117,7 +122,7 @@ __global__ void __launch_bounds__(256) bn_apply_relu_kernel(BnApplyArgs P)
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float z = (v[j] - s_mean[c + j]) * s_scale[c + j] + s_shift[c + j];
+            const float z = fmaf(v[j] - s_mean[c + j], s_scale[c + j], s_shift[c + j]);   // (= the backward's expression)
             o[j] = z > 0.f ? z : 0.f;
         }
         ((f32x4 *)P.y)[i] = o;
@@ -142,8 +147,9 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(BnBwdArgs P)
     {
         const float m = P.mean[c], is = P.invstd[c], g = P.gamma[c], b = P.beta[c];
         for (int row = r0 + r; row < r1; row += rl) {
-            const float xh = (P.x[(size_t)row * C + c] - m) * is;
-            const float z = xh * g + b;
+            const float xv = P.x[(size_t)row * C + c];
+            const float xh = (xv - m) * is;
+            const float z = fmaf(xv - m, is * g, b);         // exactly the forward's z: the mask is y > 0
             const float dz = z > 0.f ? P.dy[(size_t)row * C + c] : 0.f;
             sb += (double)dz;
             sg += (double)dz * (double)xh;
@@ -160,24 +166,28 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(BnBwdArgs P)
     }
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BnBwdArgs P)
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(BnBwdArgs P)
 {
     __shared__ double red[2][256];
+    double a = 0.0, b = 0.0;
+    bn_reduce_partials(P.part, P.nb, P.C, red, &a, &b);
+    if (threadIdx.x < P.C) {
+        P.dbeta[threadIdx.x] = (float)a;
+        P.dgamma[threadIdx.x] = (float)b;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BnBwdArgs P)
+{
     __shared__ float s_mean[256], s_is[256], s_g[256], s_b[256], s_db[256], s_dg[256];
     const int C = P.C;
-    double a = 0.0, b = 0.0;
-    bn_reduce_partials(P.part, P.nb, C, red, &a, &b);
     if (threadIdx.x < C) {
         s_mean[threadIdx.x] = P.mean[threadIdx.x];
         s_is[threadIdx.x] = P.invstd[threadIdx.x];
         s_g[threadIdx.x] = P.gamma[threadIdx.x];
         s_b[threadIdx.x] = P.beta[threadIdx.x];
-        s_db[threadIdx.x] = (float)a;
-        s_dg[threadIdx.x] = (float)b;
-        if (blockIdx.x == 0) {
-            P.dbeta[threadIdx.x] = (float)a;
-            P.dgamma[threadIdx.x] = (float)b;
-        }
+        s_db[threadIdx.x] = P.dbeta[threadIdx.x];
+        s_dg[threadIdx.x] = P.dgamma[threadIdx.x];
     }
     __syncthreads();
     const float inv_n = 1.f / (float)P.n;
@@ -189,7 +199,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BnBwdArgs P)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (v[j] - s_mean[c + j]) * s_is[c + j];
-            const float z = xh * s_g[c + j] + s_b[c + j];
+            const float z = fmaf(v[j] - s_mean[c + j], s_is[c + j] * s_g[c + j], s_b[c + j]);
             const float dz = z > 0.f ? g[j] : 0.f;
             o[j] = s_g[c + j] * s_is[c + j] * (dz - s_db[c + j] * inv_n - xh * s_dg[c + j] * inv_n);
         }
@@ -208,8 +218,8 @@ int bn_blocks(int n, int C, int *rows_per_block)
 int bn_apply_blocks(int n, int C)
 {
     const size_t total = (size_t)n * C / 4;
-    const size_t nb = (total + 1023) / 1024;         // >= 4 float4 per thread: the partial reduction is per block
-    return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    const size_t nb = (total + 511) / 512;           // 2 float4 per thread
+    return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
 }
 bool bn_shape_ok(int n, int C) { return n >= 1 && C >= 4 && C <= 256 && C % 4 == 0 && 256 % C == 0; }
 }  // namespace
@@ -240,6 +250,7 @@ extern "C" int sassd_bn_relu_fwd(const float *x, int n, int C, const float *gamm
     Q.x = x; Q.n = n; Q.C = C; Q.nb = P.nb; Q.part = (const double *)workspace; Q.gamma = gamma; Q.beta = beta; Q.y = y;
     Q.mean = save_mean; Q.invstd = save_invstd; Q.rmean = running_mean; Q.rvar = running_var;
     Q.momentum = momentum; Q.eps = eps;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, Q);
     hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(bn_apply_blocks(n, C)), dim3(256), 0, s, Q);
     return sassd_launch_status();
 }
@@ -260,6 +271,7 @@ extern "C" int sassd_bn_relu_bwd(const float *x, const float *dy, int n, int C, 
     P.part = (double *)workspace;
     P.dx = dx; P.dgamma = dgamma; P.dbeta = dbeta;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(P.nb), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, P);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(n, C)), dim3(256), 0, s, P);
     return sassd_launch_status();
 }

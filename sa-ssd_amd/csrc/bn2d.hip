@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) bn2d_apply_kernel(Bn2dArgs P)
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float z = (v[j] - m) * sc + sh;
+                const float z = fmaf(v[j] - m, sc, sh);       // (the backward recomputes z with this very expression)
                 o[j] = z > 0.f ? z : 0.f;
             }
             *(f32x4 *)(P.y + base + i) = o;
@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(256) bn2d_bwd_reduce_kernel(Bn2dArgs P)
     const int c = blockIdx.x / P.S, s = blockIdx.x - c * P.S;
     const int i0 = s * P.chunk, i1 = min(i0 + P.chunk, P.HW);
     const float m = P.mean[c], is = P.invstd[c], g = P.gamma[c], bt = P.beta[c];
+    const float sc = is * g;                                 // z exactly as the forward computed it: the mask is y > 0
     double db = 0.0, dg = 0.0;
     for (int b = 0; b < P.B; ++b) {
         const size_t base = ((size_t)b * P.C + c) * P.HW;
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256) bn2d_bwd_reduce_kernel(Bn2dArgs P)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float xh = (v[j] - m) * is;
-                const float z = xh * g + bt;
+                const float z = fmaf(v[j] - m, sc, bt);
                 const float dz = z > 0.f ? d[j] : 0.f;
                 fb += dz;
                 fg += dz * xh;
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(256) bn2d_bwd_apply_kernel(Bn2dArgs P)
     }
     const float m = P.mean[c], is = P.invstd[c], g = P.gamma[c], bt = P.beta[c];
     const float inv_n = (float)(1.0 / ((double)P.B * (double)P.HW));
-    const float sdb = (float)a, sdg = (float)b2;
+    const float sdb = (float)a, sdg = (float)b2, sc = is * g;
     if (s == 0 && threadIdx.x == 0) {
         P.dbeta[c] = sdb;
         P.dgamma[c] = sdg;
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(256) bn2d_bwd_apply_kernel(Bn2dArgs P)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float xh = (v[j] - m) * is;
-                const float z = xh * g + bt;
+                const float z = fmaf(v[j] - m, sc, bt);
                 const float dz = z > 0.f ? d[j] : 0.f;
                 o[j] = g * is * (dz - sdb * inv_n - xh * sdg * inv_n);
             }

@@ -195,6 +195,115 @@ __global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict_
     }
 }
 
+// ---- fused output -> input transform between two chained 3x3 layers ----------------------------------------------------
+// Layer l's output transform (A^T M A, folded BatchNorm / ReLU) and layer l+1's input transform (B^T d B) in ONE kernel:
+// the activation map of the layer in between is never written to HBM (36 MB written + 40 MB read back per 256-channel
+// KITTI map, plus a launch).  One workgroup owns one (channel, image) plane: phase 1 rebuilds the plane's H x W
+// activations in LDS (zero border = the convolution's padding) from the 36 product planes, phase 2 reads every 6x6 patch
+// back and writes the 36 transformed planes -- four consecutive tiles per thread, so that every plane row leaves as
+// 16-byte stores.  LDS: (H + 2) x (W + 2, rounded up to 4) floats = 142 KB for the 200 x 176 KITTI map (one workgroup per
+// CU; 256 channels x batch workgroups).
+__global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restrict__ M, W4Geom G,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int relu, int pitch,
+                                                          float *__restrict__ V)
+{
+    extern __shared__ __attribute__((aligned(16))) float w4_plane[];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int tpi = G.TH * G.TW;
+    const int nflt = (G.H + 2) * pitch;
+    for (int i = threadIdx.x; i < nflt / 4; i += 256) ((float4 *)w4_plane)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const size_t plane = (size_t)G.C * G.Tp;
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    // ---- phase 1: A^T M A + epilogue -> LDS plane (pixel (y, x) at [(y + 1) * pitch + x + 1]) ------------------------
+    for (int t = threadIdx.x; t < tpi; t += 256) {
+        const float *src = M + (size_t)c * G.Tp + (size_t)b * tpi + t;
+        float v[4][6];
+        {
+            float m[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) m[i][j] = src[(size_t)(i * 6 + j) * plane];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
+                float o[4];
+                at_vec(col, o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i][j] = o[i];
+            }
+        }
+        const int ty = t / G.TW, tx = t - ty * G.TW;
+        float *dst = w4_plane + (4 * ty + 1) * pitch + 4 * tx + 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float o[4];
+            at_vec(v[i], o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = o[j] * sc + sh;
+                if (relu) o[j] = fmaxf(o[j], 0.f);
+                dst[i * pitch + j] = o[j];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: B^T d B of every tile of this image, quads of consecutive GLOBAL tile indices -----------------------
+    const int g0 = b * tpi, g1 = g0 + tpi;
+    const int q0 = g0 >> 2, q1 = (g1 + 3) >> 2;
+    float *Vc = V + (size_t)c * G.Tp;
+    for (int q = q0 + threadIdx.x; q < q1; q += 256) {
+        float out[4][36];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tg = 4 * q + k;
+            ok[k] = tg >= g0 && tg < g1;
+            const int tl = ok[k] ? tg - g0 : 0;
+            const int ty = tl / G.TW, tx = tl - ty * G.TW;
+            const float *pp = w4_plane + 4 * ty * pitch + 4 * tx;        // patch row i, column j: pixel (4ty-1+i, 4tx-1+j)
+            float d[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float4 a = *(const float4 *)(pp + i * pitch);
+                const float2 e = *(const float2 *)(pp + i * pitch + 4);
+                d[i][0] = a.x; d[i][1] = a.y; d[i][2] = a.z; d[i][3] = a.w; d[i][4] = e.x; d[i][5] = e.y;
+            }
+            float u[6][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+                float o[6];
+                bt_vec(col, o);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) u[i][j] = o[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float o[6];
+                bt_vec(u[i], o);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) out[k][i * 6 + j] = o[j];
+            }
+        }
+        float *dst = Vc + 4 * (size_t)q;
+        if (ok[0] && ok[1] && ok[2] && ok[3]) {
+#pragma unroll
+            for (int p = 0; p < 36; ++p)
+                *reinterpret_cast<float4 *>(dst + (size_t)p * plane) = make_float4(out[0][p], out[1][p], out[2][p], out[3][p]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k]) {
+#pragma unroll
+                    for (int p = 0; p < 36; ++p) dst[(size_t)p * plane + k] = out[k][p];
+                }
+        }
+    }
+}
+
 // ---- the 36 GEMMs ---------------------------------------------------------------------------------------------------
 // NP independent GEMMs  M_p [Cout x N] = U_p^T [Cout x Cin] . V_p [Cin x N]  with K-major operands (U_p [Cin][Cout],
 // V_p [Cin][ldv], M_p [Cout][ldm]).  Winograd: p = position, 36 of them.  A 1x1 convolution over NCHW is the same
@@ -448,6 +557,70 @@ extern "C" int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, con
     if (!(g_wino4_dbg & 64))
         hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
                            scale, shift, relu, y);
+    return sassd_launch_status();
+}
+
+
+// ---- chained 3x3 layers: the activation map between two layers stays in the transform domain -----------------------------
+namespace {
+inline int w4_plane_pitch(int W) { return (W + 2 + 3) / 4 * 4; }
+inline size_t w4_plane_bytes(int H, int W) { return (size_t)(H + 2) * w4_plane_pitch(W) * 4; }
+}  // namespace
+
+extern "C" int sassd_conv2d_wino4_chain_supported(int Cin, int Cout, int H, int W)
+{
+    return sassd_conv2d_wino4_supported(Cin, Cout, H, W) && w4_plane_bytes(H, W) <= (size_t)160 * 1024 ? 1 : 0;
+}
+
+extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev_scale,
+                                        const float *prev_shift, int prev_relu, const float *w_packed,
+                                        const float *scale, const float *shift, int relu, float *y, int batch, int Cin,
+                                        int Cout, int cmax, int H, int W, void *workspace, size_t workspace_bytes,
+                                        void *stream_)
+{
+    if (!w_packed || !workspace || batch < 1 || !sassd_conv2d_wino4_supported(Cin, Cout, H, W) || cmax < Cin ||
+        cmax < Cout || (!src_products && !x))
+        return SASSD_EINVAL;
+    if (src_products && !sassd_conv2d_wino4_chain_supported(Cin, Cout, H, W)) return SASSD_EINVAL;
+    if ((y && ((uintptr_t)y & 15)) || ((uintptr_t)w_packed & 15) || ((uintptr_t)workspace & 15)) return SASSD_EINVAL;
+    if (workspace_bytes < sassd_conv2d_wino4_workspace_bytes(batch, cmax, cmax, H, W)) return SASSD_ENOSPC;
+    hipStream_t stream = (hipStream_t)stream_;
+    W4Geom G;
+    G.B = batch; G.C = Cin; G.H = H; G.W = W; G.TH = H / 4; G.TW = W / 4; G.T = batch * G.TH * G.TW;
+    G.Tp = w4_tiles_padded(batch, H, W, Cout);
+    float *V = (float *)workspace;
+    float *M = (float *)((char *)workspace + align_up(36 * (size_t)cmax * ((size_t)cdiv(G.T, 192) * 192 + 192) * 4, 256));
+    if (!src_products) {
+        if (!(g_wino4_dbg & 16))
+            hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V);
+    } else if (!(g_wino4_dbg & 128)) {
+        // the previous call left M [36][Cin][Tp] (its Cout = this Cin, same tile geometry) in the workspace
+        static std::atomic<unsigned long long> attr_done{0};
+        const size_t lds = w4_plane_bytes(H, W);
+        int rc = sassd_dyn_lds((const void *)wino4_outin_kernel, lds, attr_done);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wino4_outin_kernel, dim3(Cin, batch), dim3(256), lds, stream, (const float *)M, G, prev_scale,
+                           prev_shift, prev_relu, w4_plane_pitch(W), V);
+    }
+    W4Gemm P;
+    P.U = w_packed; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0;
+    P.np = 36; P.Cin = Cin; P.Cout = Cout; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;
+    P.su = (size_t)Cin * Cout; P.sv = (size_t)Cin * G.Tp; P.sm = (size_t)Cout * G.Tp;
+    int rc = SASSD_OK;
+    if (!(g_wino4_dbg & 32)) switch (w4_wn(G.T, Cout)) {
+    case 2: rc = launch_w4_gemm<2, 2, 1, kKC>(P, stream); break;
+    case 3: rc = launch_w4_gemm<2, 3, 1, kKC>(P, stream); break;
+    case 4: rc = launch_w4_gemm<2, 4, 1, kKC>(P, stream); break;
+    case 5: rc = launch_w4_gemm<2, 5, 1, kKC>(P, stream); break;
+    default: rc = launch_w4_gemm<2, 6, 1, kKC>(P, stream); break;
+    }
+    if (rc) return rc;
+    if (y && !(g_wino4_dbg & 64)) {
+        W4Geom Go = G;
+        Go.C = Cout;
+        hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
+                           scale, shift, relu, y);
+    }
     return sassd_launch_status();
 }
 

@@ -307,8 +307,8 @@ def spconv_bwd_data(dy, nbrT, n_in_ptr, cap_in, wT_packed, k, cin, cout):
 def spconv_bwd_weight(x, dy, nbr, n_out_ptr, cap_out, cin, cout, dw=None, accumulate=False):
     _chk_cuda(x, dy, nbr)
     L = _C.lib()
-    if dw is None:
-        dw = torch.zeros(27, cin, cout, dtype=torch.float32, device=x.device)
+    if dw is None:                                  # (the reduction kernel overwrites every element unless `accumulate`)
+        dw = torch.empty(27, cin, cout, dtype=torch.float32, device=x.device)
     wsb = L.sassd_spconv_bwd_weight_workspace_bytes(cap_out, 27, cin, cout)
     ws = workspace("spconv_wgrad", wsb, x.device)
     _C.check(L.sassd_spconv_bwd_weight(_C.ptr(x), _C.ptr(dy), _C.ptr(nbr), _C.ptr(n_out_ptr), cap_out, 27, cin, cout,

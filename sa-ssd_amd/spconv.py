@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import kernels as K
-from .autograd import BnReluFn, DensifyFn, SparseConvFn, _n_ptr as _cached_n_ptr
+from .autograd import BnReluFn, DensifyFn, SparseConvFn, count_bn_batch, _n_ptr as _cached_n_ptr
 
 
 class SparseConvTensor:
@@ -189,7 +189,7 @@ class SparseSequential(nn.Sequential):
                             and K.bn_relu_supported(f.shape[0], f.shape[1])):
                         inp.features = BnReluFn.apply(f, m.weight, m.bias, m.running_mean, m.running_var, m.momentum,
                                                       m.eps)
-                        m.num_batches_tracked.add_(1)
+                        count_bn_batch(m)
                         i += 2
                         continue
                     inp.features = m(f)

@@ -438,7 +438,8 @@ class SideStreamPrefetch:
 
 def parse_losses(losses):
     """train_utils/__init__.py:8-25 without the per-term .item() host syncs: (total loss tensor, detached terms)."""
-    terms = {k: (v.mean() if torch.is_tensor(v) else sum(x.mean() for x in v)) for k, v in losses.items()}
+    one = lambda t: t.reshape(()) if t.numel() == 1 else t.mean()       # noqa: E731  (a [1] tensor needs no reduction)
+    terms = {k: (one(v) if torch.is_tensor(v) else sum(one(x) for x in v)) for k, v in losses.items()}
     total = sum(v for k, v in terms.items() if "loss" in k)
     return total, {k: v.detach() for k, v in terms.items()}
 
@@ -454,6 +455,8 @@ def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None):
         sync.reset()
     optimizer.zero_grad()
     loss, terms = parse_losses(model(**batch))
+    from .autograd import flush_bn_counters
+    flush_bn_counters()                              # num_batches_tracked of every BatchNorm: one multi-tensor add
     nxt = prefetch() if prefetch is not None else None
     if hasattr(getattr(model, "rpn_head", None), "poll_guided_capacity"):
         model.rpn_head.poll_guided_capacity()        # non-blocking: reports an overflow a step or two late

@@ -348,12 +348,15 @@ def test_bn2d_relu_fused_matches_torch(dev, shape):
         bn.running_mean.normal_(0, 0.1)
         bn.running_var.uniform_(0.5, 1.5)
     rm, rv = bn.running_mean.clone(), bn.running_var.clone()
-    xr = x.clone().requires_grad_()
-    torch.relu(bn(xr)).backward(dy)
     xf = x.clone().requires_grad_()
     gam, bet = bn.weight.detach().clone().requires_grad_(), bn.bias.detach().clone().requires_grad_()
     y = BnRelu2dFn.apply(xf, gam, bet, rm, rv, 0.01, 1e-3)
     y.backward(dy)
+    # reference gradients with the kernel's OWN ReLU mask: among 9 M pre-activations one or two lie within fp32 rounding of
+    # zero, where torch's z and the kernel's z may take different signs -- a legitimate O(|dy|) difference in that
+    # element (and in the channel's dgamma / dbeta) that says nothing about the arithmetic
+    xr = x.clone().requires_grad_()
+    (bn(xr) * (y.detach() > 0)).backward(dy)
     with torch.no_grad():
         y_ref = torch.relu(torch.nn.functional.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.0, 1e-3))
 

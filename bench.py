@@ -456,6 +456,7 @@ def main():
         from sassd import kernels as K
         wp, cout, ks, scale, shift, _ = iso_plan.bev[1]
         xin, yout = iso_plan.act[0], iso_plan.act[1]
+        xin.normal_().clamp_(min=0)            # (chained layers never write the intermediate maps: time on live-like data)
         with torch.cuda.stream(streams[0]):
             for name, flags in (("in", 32 | 64), ("gemm", 16 | 64), ("out", 16 | 32)):
                 K.debug_set_wino4(0, flags)
@@ -468,6 +469,20 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 w4_parts[name] = e0.elapsed_time(e1) / 20
+            if getattr(iso_plan, "chain", None) and any(iso_plan.chain):
+                # the fused output -> input transform between two chained layers, alone (GEMM switched off)
+                K.debug_set_wino4(0, 32)
+                args = (None, (scale, shift, True), wp, 256, cout, iso_plan.cmax, B, iso_plan.H, iso_plan.W, scale, shift, True,
+                        None, iso_plan.wino4_ws)
+                for _ in range(3):
+                    K.conv2d_wino4_chain(*args)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    K.conv2d_wino4_chain(*args)
+                e1.record()
+                torch.cuda.synchronize()
+                w4_parts["outin_fused"] = e0.elapsed_time(e1) / 20
             K.debug_set_wino4(0, 0)
     headline = args.config == "car" and B == 1
     # ---- the training half of BASELINE.json's metric (configs[2]: car_cfg, batch 2 / GPU, bf16, DDP): every rank takes

@@ -204,6 +204,22 @@ int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, const float *s
                            float *y, int batch, int Cin, int Cout, int H, int W, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* Chained 3x3 layers with the activation map between them kept in the transform domain: one call = one layer,
+ *   src_products == 0: V = input transform of the NCHW map x (as sassd_conv2d_wino4_fwd);
+ *   src_products != 0: V = fused output->input transform of the products the PREVIOUS chain call left in `workspace`
+ *                      (that call's Cout = this call's Cin, same batch / H / W / cmax; its folded BatchNorm / ReLU passed
+ *                      here as prev_scale / prev_shift / prev_relu) -- the map between the two layers is never written to
+ *                      HBM (cmn.py:240-262: conv0 .. conv6 of the BEV stack);
+ *   then the 36 GEMMs; y != NULL: output transform + scale / shift / relu into the NCHW map y, y == NULL: the products
+ *   stay in the workspace for the next call.  cmax >= every Cin / Cout of the chain fixes the workspace layout
+ *   (sassd_conv2d_wino4_workspace_bytes(batch, cmax, cmax, H, W)).  sassd_conv2d_wino4_chain_supported: the fused
+ *   transform keeps one (H + 2) x (W + 2) plane in LDS (<= 160 KB). */
+int sassd_conv2d_wino4_chain_supported(int Cin, int Cout, int H, int W);
+int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev_scale, const float *prev_shift,
+                             int prev_relu, const float *w_packed, const float *scale, const float *shift, int relu,
+                             float *y, int batch, int Cin, int Cout, int cmax, int H, int W, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
 /* 1x1 convolution with >= 128 output channels (BEVNet conv7, cmn.py:262) as a plain fp32-MFMA GEMM over the NCHW
  * tensor (y[b] [Cout x HW] = W [Cout x Cin] . x[b] [Cin x HW]) with the folded BatchNorm / bias / ReLU epilogue; the
  * kernel of the Winograd F(4x4) products with one problem per image.  Needs Cin % 32 == 0, Cout % 128 == 0 and H*W

@@ -125,11 +125,12 @@ __global__ void nn_fill_kernel(int m, const float *__restrict__ known, NnBins g,
     sorted_row[pos] = k;
 }
 
+// three best (distance, row) pairs under the total order (d, row): the result does not depend on the visiting order
 struct Top3 {
-    double b1, b2, b3;
+    float b1, b2, b3;                                       // +inf = empty (the reference prints 1e40 -> inf as float)
     int i1, i2, i3;
-    __device__ __forceinline__ void init() { b1 = b2 = b3 = 1e40; i1 = i2 = i3 = 0; }
-    __device__ __forceinline__ static bool less(double d, int i, double bd, int bi)
+    __device__ __forceinline__ void init() { b1 = b2 = b3 = __builtin_huge_valf(); i1 = i2 = i3 = 0; }
+    __device__ __forceinline__ static bool less(float d, int i, float bd, int bi)
     {
         return d < bd || (d == bd && i < bi);
     }
@@ -139,8 +140,26 @@ struct Top3 {
         else if (less(d, i, b2, i2)) { b3 = b2; i3 = i2; b2 = d; i2 = i; }
         else if (less(d, i, b3, i3)) { b3 = d; i3 = i; }
     }
+    __device__ __forceinline__ bool has(float d, int i) const
+    {
+        return (d == b1 && i == i1) || (d == b2 && i == i2) || (d == b3 && i == i3);
+    }
+    // union with the partner lane's list (both lanes end with the same three).  After the first ring the lists of a group
+    // share the entries of the previous merge: a candidate (= a row index) already present is not inserted twice.
+    __device__ __forceinline__ void merge_xor(int mask)
+    {
+        const float p1 = __shfl_xor(b1, mask, 64), p2 = __shfl_xor(b2, mask, 64), p3 = __shfl_xor(b3, mask, 64);
+        const int j1 = __shfl_xor(i1, mask, 64), j2 = __shfl_xor(i2, mask, 64), j3 = __shfl_xor(i3, mask, 64);
+        if (p1 < __builtin_huge_valf() && !has(p1, j1)) push(p1, j1);
+        if (p2 < __builtin_huge_valf() && !has(p2, j2)) push(p2, j2);
+        if (p3 < __builtin_huge_valf() && !has(p3, j3)) push(p3, j3);
+    }
 };
 
+// FOUR lanes per unknown point (a thread per point walked ~130 candidates serially with 64 different trip counts per
+// wave, and 32 k points filled half the chip: 212 us per call): lane `sub` of a group takes every fourth candidate of a
+// cell, the four partial lists are merged by two xor-shuffles after every ring, so the stop test and the result are those
+// of the serial search (the (distance, row) order is total: any visiting order gives the same three).
 __global__ void __launch_bounds__(256) three_nn_binned_kernel(int n, const float *__restrict__ unknown, NnBins g,
                                                               const int *__restrict__ start,
                                                               const float4 *__restrict__ sorted,
@@ -148,8 +167,9 @@ __global__ void __launch_bounds__(256) three_nn_binned_kernel(int n, const float
                                                               float *__restrict__ dist2, int *__restrict__ idx)
 {
 #pragma clang fp contract(off)
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = gt >> 2, sub = gt & 3;
+    if (p >= n) return;                                     // (whole groups leave together)
     const float4 u = ((const float4 *)unknown)[p];
     Top3 t;
     t.init();
@@ -167,7 +187,7 @@ __global__ void __launch_bounds__(256) three_nn_binned_kernel(int n, const float
                     if (x < 0 || x >= g.nx) continue;
                     const int c = (base + y) * g.nx + x;
                     const int e = start[c + 1];
-                    for (int j = start[c]; j < e; ++j) {
+                    for (int j = start[c] + sub; j < e; j += 4) {
                         const float4 q = sorted[j];
                         const float d = (u.y - q.y) * (u.y - q.y) + (u.z - q.z) * (u.z - q.z) +
                                         (u.w - q.w) * (u.w - q.w);
@@ -175,12 +195,16 @@ __global__ void __launch_bounds__(256) three_nn_binned_kernel(int n, const float
                     }
                 }
             }
+            t.merge_xor(1);
+            t.merge_xor(2);
             const float reach = (float)r * g.cell * 0.999f;             // 0.1 % slack for cell-boundary rounding
-            if (r >= 1 && t.b3 <= (double)reach * (double)reach) break;
+            if (r >= 1 && (double)t.b3 <= (double)reach * (double)reach) break;
         }
     }
-    dist2[p * 3 + 0] = (float)t.b1; dist2[p * 3 + 1] = (float)t.b2; dist2[p * 3 + 2] = (float)t.b3;
-    idx[p * 3 + 0] = t.i1; idx[p * 3 + 1] = t.i2; idx[p * 3 + 2] = t.i3;
+    if (sub == 0) {
+        dist2[p * 3 + 0] = t.b1; dist2[p * 3 + 1] = t.b2; dist2[p * 3 + 2] = t.b3;
+        idx[p * 3 + 0] = t.i1; idx[p * 3 + 1] = t.i2; idx[p * 3 + 2] = t.i3;
+    }
 }
 
 // one thread per (point, channel); consecutive threads -> consecutive channels (coalesced rows)
@@ -308,7 +332,7 @@ extern "C" int sassd_three_nn_binned(int n, int m, const float *unknown, const f
     hipLaunchKernelGGL(nn_scan_local_kernel, dim3(nsb), dim3(1024), 0, s, L.ncell, count, start, btot);
     hipLaunchKernelGGL(nn_scan_offset_kernel, dim3(nsb), dim3(1024), 0, s, L.ncell, (const int *)btot, start, cursor);
     if (m > 0) hipLaunchKernelGGL(nn_fill_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, m, known, g, cursor, sorted, rows);
-    hipLaunchKernelGGL(three_nn_binned_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, unknown, g, start, sorted, rows,
+    hipLaunchKernelGGL(three_nn_binned_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, n, unknown, g, start, sorted, rows,
                        dist2, idx);
     return sassd_launch_status();
 }

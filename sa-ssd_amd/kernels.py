@@ -418,6 +418,23 @@ def conv2d_wino4_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=No
     return y
 
 
+def conv2d_wino4_chain_supported(cin, cout, h, w):
+    return bool(_C.lib().sassd_conv2d_wino4_chain_supported(int(cin), int(cout), int(h), int(w)))
+
+
+def conv2d_wino4_chain(x, prev, w_packed, cin, cout, cmax, batch, h, w, scale, shift, relu, y, ws):
+    """One layer of a chain of Winograd F(4x4,3x3) convolutions (sassd_conv2d_wino4_chain).  `x`: NCHW input map, or None
+    to continue from the products the previous call left in `ws` (then prev = (scale, shift, relu) of that layer).
+    `y`: NCHW output map, or None to leave the products in `ws` for the next call."""
+    _chk_cuda(x, w_packed, scale, shift, y, ws)
+    ps, pb, pr = prev if prev is not None else (None, None, False)
+    _C.check(_C.lib().sassd_conv2d_wino4_chain(_C.ptr(x), 0 if x is not None else 1, _C.ptr(ps), _C.ptr(pb), 1 if pr else 0,
+                                               _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
+                                               _C.ptr(y), batch, cin, cout, cmax, h, w, _C.ptr(ws), ws.numel(),
+                                               _C.stream()), "sassd_conv2d_wino4_chain")
+    return y
+
+
 def conv1x1_gemm_supported(cin, cout, h, w):
     return bool(_C.lib().sassd_conv1x1_gemm_supported(int(cin), int(cout), int(h), int(w)))
 

@@ -55,7 +55,7 @@ class InferencePlan:
                  sparse_shape=(40, 1600, 1408), anchors=None, anchors_bv=None, anchor_area_threshold=1,
                  anchors_per_loc=2, grid_offsets=(0., 40.), featmap_stride=0.4, rpn_thr=0.1, score_thr=0.3,
                  iou_thr=0.1, cap_k=4096, cap_d=512, device=None, level_cap_factor=2, overlap=True, winograd=True,
-                 fused_rulebooks=True):
+                 fused_rulebooks=True, chain_bev=True):
         dev = torch.device(device if device is not None else "cuda:0")
         self.dev, self.B, self.ncls, self.A = dev, int(batch_size), int(num_class), int(anchors_per_loc)
         self.voxel_size = np.asarray(voxel_size, np.float32)
@@ -111,8 +111,16 @@ class InferencePlan:
                   K.conv1x1_gemm_pack_weight(w.contiguous()) if wino == 1 else K.conv2d_pack_weight(w.contiguous()))
             self.bev.append((wp, w.shape[0], w.shape[2], scale, shift, wino))
         self.wino4_ws = None
+        # consecutive F(4x4) layers are chained: the map between two of them stays in the transform domain (fused output
+        # -> input transform, sassd_conv2d_wino4_chain); `chain_bev=False` keeps three launches per layer (A/B)
+        self.bev_cin = [int(sd["neck.fcn.conv%d.weight" % i].shape[1]) for i in range(8)]
+        self.chain = [False] * 8                         # chain[i]: layer i reads the products layer i-1 left behind
         if any(l[5] == 4 for l in self.bev):
-            self.wino4_ws = K.conv2d_wino4_workspace(self.B, max(64 * D3, 256), 256, self.H, self.W, dev)
+            self.cmax = max(max(self.bev_cin[i], self.bev[i][1]) for i in range(8) if self.bev[i][5] == 4)
+            self.wino4_ws = K.conv2d_wino4_workspace(self.B, self.cmax, self.cmax, self.H, self.W, dev)
+            for i in range(1, 8):
+                self.chain[i] = bool(chain_bev and self.bev[i][5] == 4 and self.bev[i - 1][5] == 4 and i - 1 != 6 and
+                                     K.conv2d_wino4_chain_supported(self.bev_cin[i], self.bev[i][1], self.H, self.W))
         hw = torch.cat([sd["rpn_head.conv_box.weight"], sd["rpn_head.conv_cls.weight"],
                         sd["rpn_head.conv_dir_cls.weight"]], 0).float().contiguous()
         hb = torch.cat([sd["rpn_head.conv_box.bias"], sd["rpn_head.conv_cls.bias"],
@@ -287,7 +295,12 @@ class InferencePlan:
             y = self.act[i % 2] if i < 7 else self.act[2]
             e0 = self._ev() if self.prof is not None else None
             if wino == 4:
-                K.conv2d_wino4_fwd(x, wp, cout, scale, shift, True, y, self.wino4_ws)
+                # layer i hands its products to layer i+1 (no NCHW map in between) unless its output is needed: conv6
+                # feeds the part-sensitive head, the last F(4x4) layer feeds a 1x1 / direct layer
+                keep = i + 1 < 8 and self.chain[i + 1]
+                prev = self.bev[i - 1][3:5] + (True,) if self.chain[i] else None
+                K.conv2d_wino4_chain(None if self.chain[i] else x, prev, wp, self.bev_cin[i], cout, self.cmax, self.B,
+                                     self.H, self.W, scale, shift, True, None if keep else y, self.wino4_ws)
             elif wino == 2:
                 K.conv2d_wino_fwd(x, wp, cout, scale, shift, True, y)
             elif wino == 1:

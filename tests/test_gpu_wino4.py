@@ -57,3 +57,39 @@ def test_conv1x1_gemm(dev, b, cin, cout, hw, relu):
     y2 = K.conv1x1_gemm_fwd(x.to(dev), wp, cout)
     assert (y2.cpu() - raw).abs().max().item() <= 1e-5 * max(1.0, raw.abs().max().item())
     assert not K.conv1x1_gemm_supported(256, 28, 200, 176) and not K.conv1x1_gemm_supported(256, 256, 188, 188)
+
+
+@pytest.mark.parametrize("b,cin0,hw", [(1, 320, (200, 176)), (3, 64, (20, 44)), (2, 256, (188, 188)), (2, 96, (8, 12))])
+def test_conv2d_wino4_chain(dev, b, cin0, hw):
+    """Three chained 3x3 layers (cin0 -> 256 -> 256 -> 256, folded scale / shift + ReLU after each) through
+    sassd_conv2d_wino4_chain -- the maps between the layers stay in the transform domain (fused output -> input transform,
+    one LDS plane per (channel, image)) -- against the same three layers through sassd_conv2d_wino4_fwd (three launches per
+    layer, maps in HBM), which the test above holds to torch-CPU conv2d.  The fused kernel performs the same fp32 operations
+    in the same order: the results are compared at 1e-6 relative (bit equality is reported).  Shapes: the KITTI BEV map
+    (tile count 2200), a multi-image batch whose images do not start on a 4-tile boundary (11 x 5 = 55 tiles per image),
+    the Waymo-scale map (47 x 47 tiles), a tiny map where every tile touches the padding."""
+    g = torch.Generator().manual_seed(cin0 + hw[0])
+    x = torch.randn(b, cin0, *hw, generator=g)
+    x *= (torch.rand(b, cin0, *hw, generator=g) > 0.6).float()
+    cins = [cin0, 256, 256]
+    ws = [torch.randn(256, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5 for c in cins]
+    scs = [(torch.rand(256, generator=g) + 0.5).to(dev) for _ in cins]
+    shs = [(torch.randn(256, generator=g) * 0.1).to(dev) for _ in cins]
+    wps = [K.conv2d_wino4_pack_weight(w.to(dev)) for w in ws]
+    assert all(K.conv2d_wino4_chain_supported(c, 256, *hw) for c in cins)
+    xd = x.to(dev)
+    ref = xd
+    for wp, sc, sh in zip(wps, scs, shs):
+        ref = K.conv2d_wino4_fwd(ref, wp, 256, sc, sh, True)
+    cmax = max(cin0, 256)
+    wsb = K.conv2d_wino4_workspace(b, cmax, cmax, hw[0], hw[1], dev)
+    y = torch.empty(b, 256, *hw, device=dev)
+    for i, (wp, sc, sh) in enumerate(zip(wps, scs, shs)):
+        K.conv2d_wino4_chain(xd if i == 0 else None, None if i == 0 else (scs[i - 1], shs[i - 1], True), wp, cins[i], 256,
+                             cmax, b, hw[0], hw[1], sc, sh, True, y if i == 2 else None, wsb)
+    torch.cuda.synchronize()
+    err = (y - ref).abs().max().item()
+    print("wino4 chain %s: max abs difference to the unchained layers %.2e (bit-equal: %s)" % ((b, cin0, hw), err,
+                                                                                          torch.equal(y, ref)))
+    assert err <= 1e-6 * max(1.0, ref.abs().max().item()), err
+    assert not K.conv2d_wino4_chain_supported(256, 256, 400, 352)          # plane does not fit the LDS

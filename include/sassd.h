@@ -212,9 +212,10 @@ int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, const float *s
  *                      HBM (cmn.py:240-262: conv0 .. conv6 of the BEV stack);
  *   then the 36 GEMMs; y != NULL: output transform + scale / shift / relu into the NCHW map y, y == NULL: the products
  *   stay in the workspace for the next call.  cmax >= every Cin / Cout of the chain fixes the workspace layout
- *   (sassd_conv2d_wino4_workspace_bytes(batch, cmax, cmax, H, W)).  sassd_conv2d_wino4_chain_supported: the fused
+ *   (sassd_conv2d_wino4_chain_workspace_bytes(batch, cmax, H, W)).  sassd_conv2d_wino4_chain_supported: the fused
  *   transform keeps one (H + 2) x (W + 2) plane in LDS (<= 160 KB). */
 int sassd_conv2d_wino4_chain_supported(int Cin, int Cout, int H, int W);
+size_t sassd_conv2d_wino4_chain_workspace_bytes(int batch, int cmax, int H, int W);
 int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev_scale, const float *prev_shift,
                              int prev_relu, const float *w_packed, const float *scale, const float *shift, int relu,
                              float *y, int batch, int Cin, int Cout, int cmax, int H, int W, void *workspace,

@@ -138,6 +138,7 @@ _SIGS = {
     "sassd_focal_loss_workspace_bytes": (_SZ, [_I]),
     "sassd_focal_loss": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "sassd_conv2d_wino4_chain_supported": (_I, [_I, _I, _I, _I]),
+    "sassd_conv2d_wino4_chain_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sassd_conv2d_wino4_chain": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_gather_pack": (_I, [_P, _P, _P, C.c_long, _I, _P]),
     "sassd_grad_sumsq": (_I, [_P, C.c_long, _P, _P]),

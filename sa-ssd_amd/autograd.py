@@ -105,7 +105,14 @@ class SparseConvFn(Function):
             if nbr is None:
                 dx = K.spconv_bwd_data(dyc, None, _n_ptr(n_in, dev), max(n_in, 1), wt, 1, cin, cout)[:n_in]
             else:
-                nbr_t = K.rulebook_transpose(nbr, _n_ptr(n_out, dev), nbr.shape[0], max(n_in, 1))
+                # the transposed table depends on the rulebook alone: layers sharing an `indice_key` (conv2.0-2, ...)
+                # build it once per batch (kept on the rulebook tensor, which lives as long as the batch)
+                cached = getattr(nbr, "_sassd_transposed", None)
+                if cached is not None and cached[0] == (n_out, n_in):
+                    nbr_t = cached[1]
+                else:
+                    nbr_t = K.rulebook_transpose(nbr, _n_ptr(n_out, dev), nbr.shape[0], max(n_in, 1))
+                    nbr._sassd_transposed = ((n_out, n_in), nbr_t)
                 dx = K.spconv_bwd_data(dyc, nbr_t, _n_ptr(n_in, dev), max(n_in, 1), wt, 27, cin, cout)[:n_in]
         if ctx.needs_input_grad[1]:
             if nbr is None and n_in > 0 and cin >= 16:

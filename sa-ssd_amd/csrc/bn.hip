@@ -19,7 +19,7 @@
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kBnMaxBlocks = 256;
+constexpr int kBnMaxBlocks = 1024;     // (317 k-row Waymo-scale levels: 256 blocks walked 1240 rows each)
 
 struct BnFwdArgs {
     const float *x;
@@ -57,10 +57,11 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(BnFwdArgs P)
 
 // sums of the block partials for every channel, identical in every block: thread (r, c) adds the partials of blocks
 // r, r + rl, ... in order, the rl partial sums are combined in order of r
-__device__ __forceinline__ void bn_reduce_partials(const double *part, int nb, int C, double (*red)[256], double *out0,
+template <int NT>
+__device__ __forceinline__ void bn_reduce_partials(const double *part, int nb, int C, double (*red)[NT], double *out0,
                                                    double *out1)
 {
-    const int rl = 256 / C, c = threadIdx.x % C, r = threadIdx.x / C;
+    const int rl = NT / C, c = threadIdx.x % C, r = threadIdx.x / C;
     double a = 0.0, b = 0.0;
     for (int k = r; k < nb; k += rl) {
         a += part[((size_t)k * 2 + 0) * C + c];
@@ -86,11 +87,12 @@ struct BnApplyArgs {
     float momentum, eps;
 };
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(BnApplyArgs P)
+// (1024 threads: the <= 1024 block partials of a channel are added by 1024 / C thread groups, 15 -> 4 us per call)
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(BnApplyArgs P)
 {
-    __shared__ double red[2][256];
+    __shared__ double red[2][1024];
     double ss = 0.0, qq = 0.0;
-    bn_reduce_partials(P.part, P.nb, P.C, red, &ss, &qq);
+    bn_reduce_partials<1024>(P.part, P.nb, P.C, red, &ss, &qq);
     if (threadIdx.x < P.C) {
         const double mean = ss / P.n;
         double var = qq / P.n - mean * mean;
@@ -166,11 +168,11 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(BnBwdArgs P)
     }
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(BnBwdArgs P)
+__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(BnBwdArgs P)
 {
-    __shared__ double red[2][256];
+    __shared__ double red[2][1024];
     double a = 0.0, b = 0.0;
-    bn_reduce_partials(P.part, P.nb, P.C, red, &a, &b);
+    bn_reduce_partials<1024>(P.part, P.nb, P.C, red, &a, &b);
     if (threadIdx.x < P.C) {
         P.dbeta[threadIdx.x] = (float)a;
         P.dgamma[threadIdx.x] = (float)b;
@@ -250,7 +252,7 @@ extern "C" int sassd_bn_relu_fwd(const float *x, int n, int C, const float *gamm
     Q.x = x; Q.n = n; Q.C = C; Q.nb = P.nb; Q.part = (const double *)workspace; Q.gamma = gamma; Q.beta = beta; Q.y = y;
     Q.mean = save_mean; Q.invstd = save_invstd; Q.rmean = running_mean; Q.rvar = running_var;
     Q.momentum = momentum; Q.eps = eps;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, Q);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, s, Q);
     hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(bn_apply_blocks(n, C)), dim3(256), 0, s, Q);
     return sassd_launch_status();
 }
@@ -271,7 +273,7 @@ extern "C" int sassd_bn_relu_bwd(const float *x, const float *dy, int n, int C, 
     P.part = (double *)workspace;
     P.dx = dx; P.dgamma = dgamma; P.dbeta = dbeta;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(P.nb), dim3(256), 0, s, P);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, P);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(n, C)), dim3(256), 0, s, P);
     return sassd_launch_status();
 }

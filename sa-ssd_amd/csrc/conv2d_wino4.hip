@@ -572,6 +572,13 @@ extern "C" int sassd_conv2d_wino4_chain_supported(int Cin, int Cout, int H, int 
     return sassd_conv2d_wino4_supported(Cin, Cout, H, W) && w4_plane_bytes(H, W) <= (size_t)160 * 1024 ? 1 : 0;
 }
 
+extern "C" size_t sassd_conv2d_wino4_chain_workspace_bytes(int batch, int cmax, int H, int W)
+{
+    if (batch < 1 || cmax < 1 || H < 4 || W < 4 || H % 4 || W % 4) return 0;
+    const size_t Tp = (size_t)cdiv(batch * (H / 4) * (W / 4), 192) * 192 + 192;          // widest tile block + slack
+    return 2 * align_up(36 * (size_t)cmax * Tp * 4, 256);                              // V | M, each for cmax channels
+}
+
 extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev_scale,
                                         const float *prev_shift, int prev_relu, const float *w_packed,
                                         const float *scale, const float *shift, int relu, float *y, int batch, int Cin,
@@ -583,13 +590,14 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
         return SASSD_EINVAL;
     if (src_products && !sassd_conv2d_wino4_chain_supported(Cin, Cout, H, W)) return SASSD_EINVAL;
     if ((y && ((uintptr_t)y & 15)) || ((uintptr_t)w_packed & 15) || ((uintptr_t)workspace & 15)) return SASSD_EINVAL;
-    if (workspace_bytes < sassd_conv2d_wino4_workspace_bytes(batch, cmax, cmax, H, W)) return SASSD_ENOSPC;
+    const size_t need = sassd_conv2d_wino4_chain_workspace_bytes(batch, cmax, H, W);
+    if (need == 0 || workspace_bytes < need) return SASSD_ENOSPC;
     hipStream_t stream = (hipStream_t)stream_;
     W4Geom G;
     G.B = batch; G.C = Cin; G.H = H; G.W = W; G.TH = H / 4; G.TW = W / 4; G.T = batch * G.TH * G.TW;
     G.Tp = w4_tiles_padded(batch, H, W, Cout);
     float *V = (float *)workspace;
-    float *M = (float *)((char *)workspace + align_up(36 * (size_t)cmax * ((size_t)cdiv(G.T, 192) * 192 + 192) * 4, 256));
+    float *M = (float *)((char *)workspace + need / 2);
     if (!src_products) {
         if (!(g_wino4_dbg & 16))
             hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V);
@@ -597,7 +605,7 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
         // the previous call left M [36][Cin][Tp] (its Cout = this Cin, same tile geometry) in the workspace
         static std::atomic<unsigned long long> attr_done{0};
         const size_t lds = w4_plane_bytes(H, W);
-        int rc = sassd_dyn_lds((const void *)wino4_outin_kernel, lds, attr_done);
+        int rc = sassd_dyn_lds((const void *)wino4_outin_kernel, (size_t)160 * 1024, attr_done);   // once, for any plane
         if (rc) return rc;
         hipLaunchKernelGGL(wino4_outin_kernel, dim3(Cin, batch), dim3(256), lds, stream, (const float *)M, G, prev_scale,
                            prev_shift, prev_relu, w4_plane_pitch(W), V);

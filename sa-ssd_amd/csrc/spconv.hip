@@ -576,6 +576,12 @@ __global__ void nbr_transpose_kernel(const int32_t *__restrict__ nbr, const int3
 }
 
 constexpr int kWgRows = 128;       // output rows per weight-gradient workgroup (~2 workgroups per CU at 29k rows)
+// rows per workgroup of the offset-per-wave kernel: 128 up to 64 k rows, then capacity / 512 (multiple of 64, <= 2048)
+static inline int wgrad_rows_per_wg(int cap)
+{
+    int r = ((cap + 511) / 512 + 63) / 64 * 64;
+    return r < kWgRows ? kWgRows : (r > 2048 ? 2048 : r);
+}
 
 // One wave = one 16x16 tile of dW[k] (ci tile x co tile) for all 27 offsets; the MFMA K dimension runs over rows:
 //   D[ci][co] += sum_rows X[nbr[row][k]][ci] * dY[row][co]      (4 rows per v_mfma_f32_16x16x4_f32)
@@ -658,18 +664,18 @@ template <int CIN, int COUT>
 __global__ void __launch_bounds__(512) spconv_wgrad_offset_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                                   const int32_t *__restrict__ nbr,
                                                                   const int32_t *__restrict__ n_ptr, int cap,
-                                                                  float *__restrict__ part)
+                                                                  float *__restrict__ part, int wg_rows)
 {
     constexpr int MT = (CIN + 15) / 16, NTT = COUT / 16;
-    __shared__ int lists[8][2][kWgRows];
+    extern __shared__ int wg_lists[];                            // [8 waves][2][wg_rows]
     const int n = min(*n_ptr, cap);
-    const int r0 = blockIdx.x * kWgRows;
+    const int r0 = blockIdx.x * wg_rows;
     if (r0 >= n) return;                                        // workgroup-uniform
-    const int rows = min(kWgRows, n - r0);
+    const int rows = min(wg_rows, n - r0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, m16 = lane & 15;
-    int *lin = lists[wave][0], *lout = lists[wave][1];
+    int *lin = wg_lists + wave * 2 * wg_rows, *lout = lin + wg_rows;
     float *dst = part + (size_t)blockIdx.x * kK * CIN * COUT;
     // offsets of this wave: wave 0 -> 13; wave w >= 1 -> the (w-1)-th, (w+6)-th, ... of the other 26
 #pragma unroll 1
@@ -751,10 +757,10 @@ __global__ void __launch_bounds__(512) spconv_wgrad_offset_kernel(const float *_
 }
 
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, const int32_t *__restrict__ n_ptr, int cap,
-                                    int per, float *__restrict__ dw, int accumulate)
+                                    int per, float *__restrict__ dw, int accumulate, int wg_rows)
 {
     const int n = min(*n_ptr, cap);
-    const int nwg = (n + kWgRows - 1) / kWgRows;
+    const int nwg = (n + wg_rows - 1) / wg_rows;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per) return;
     // four independent partial sums keep four loads in flight (the loop is latency-bound otherwise); fixed order
@@ -776,16 +782,27 @@ int launch_wgrad(const float *x, const float *dy, const int32_t *nbr, const int3
 {
     constexpr int MT = (CIN + 15) / 16, NTT = COUT / 16;
     constexpr int WPW = MT * NTT < 8 ? MT * NTT : 8;
-    const int nwg = cdiv(cap, kWgRows);
-    if (g_spconv_dbg & 32)      // debug bit 5: the tile-per-wave formulation
-        hipLaunchKernelGGL((spconv_wgrad_kernel<CIN, COUT>), dim3(nwg, MT * NTT / WPW), dim3(WPW * 64), 0, stream, x,
-                           dy, nbr, n_ptr, cap, part);
-    else
-        hipLaunchKernelGGL((spconv_wgrad_offset_kernel<CIN, COUT>), dim3(nwg), dim3(512), 0, stream, x, dy, nbr, n_ptr,
-                           cap, part);
+    int wg_rows = kWgRows;
+    if (g_spconv_dbg & 32) {    // debug bit 5: the tile-per-wave formulation
+        hipLaunchKernelGGL((spconv_wgrad_kernel<CIN, COUT>), dim3(cdiv(cap, kWgRows), MT * NTT / WPW), dim3(WPW * 64), 0,
+                           stream, x, dy, nbr, n_ptr, cap, part);
+    } else {
+        // every workgroup leaves one [27][Cin][Cout] partial (442 KB at 64 x 64): beyond ~512 workgroups the partials
+        // (1.1 GB per layer at Waymo scale, 317 k rows) cost more than the gradient itself, so the rows per workgroup grow
+        // with the capacity (the pair lists live in dynamic LDS: 64 bytes per row)
+        wg_rows = wgrad_rows_per_wg(cap);
+        const size_t lds = (size_t)8 * 2 * wg_rows * sizeof(int);
+        static std::atomic<unsigned long long> attr_done{0};
+        // (the opt-in is made once per device with the largest size any capacity can ask for)
+        int rc = sassd_dyn_lds((const void *)spconv_wgrad_offset_kernel<CIN, COUT>, (size_t)8 * 2 * 2048 * sizeof(int),
+                               attr_done);
+        if (rc) return rc;
+        hipLaunchKernelGGL((spconv_wgrad_offset_kernel<CIN, COUT>), dim3(cdiv(cap, wg_rows)), dim3(512), lds, stream, x, dy,
+                           nbr, n_ptr, cap, part, wg_rows);
+    }
     const int per = kK * CIN * COUT;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(per, 256)), dim3(256), 0, stream, (const float *)part, n_ptr, cap,
-                       per, dw, accumulate);
+                       per, dw, accumulate, wg_rows);
     return sassd_launch_status();
 }
 
@@ -825,7 +842,7 @@ extern "C" int sassd_spconv_bwd_data(const float *dy, const int32_t *nbrT, const
 
 extern "C" size_t sassd_spconv_bwd_weight_workspace_bytes(int cap_out, int K, int Cin, int Cout)
 {
-    return (size_t)cdiv(cap_out > 0 ? cap_out : 1, kWgRows) * K * Cin * Cout * sizeof(float);
+    return (size_t)cdiv(cap_out > 0 ? cap_out : 1, kWgRows) * K * Cin * Cout * sizeof(float);      // (sized for 128-row groups)
 }
 
 extern "C" int sassd_spconv_bwd_weight(const float *x, const float *dy, const int32_t *nbr, const int32_t *n_out_ptr,

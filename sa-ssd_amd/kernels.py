@@ -422,6 +422,13 @@ def conv2d_wino4_chain_supported(cin, cout, h, w):
     return bool(_C.lib().sassd_conv2d_wino4_chain_supported(int(cin), int(cout), int(h), int(w)))
 
 
+def conv2d_wino4_chain_workspace(b, cmax, h, w, device):
+    n = _C.lib().sassd_conv2d_wino4_chain_workspace_bytes(b, cmax, h, w)
+    if n == 0:
+        raise ValueError("wino4 chain: unsupported shape")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
 def conv2d_wino4_chain(x, prev, w_packed, cin, cout, cmax, batch, h, w, scale, shift, relu, y, ws):
     """One layer of a chain of Winograd F(4x4,3x3) convolutions (sassd_conv2d_wino4_chain).  `x`: NCHW input map, or None
     to continue from the products the previous call left in `ws` (then prev = (scale, shift, relu) of that layer).

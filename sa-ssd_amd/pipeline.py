@@ -117,7 +117,7 @@ class InferencePlan:
         self.chain = [False] * 8                         # chain[i]: layer i reads the products layer i-1 left behind
         if any(l[5] == 4 for l in self.bev):
             self.cmax = max(max(self.bev_cin[i], self.bev[i][1]) for i in range(8) if self.bev[i][5] == 4)
-            self.wino4_ws = K.conv2d_wino4_workspace(self.B, self.cmax, self.cmax, self.H, self.W, dev)
+            self.wino4_ws = K.conv2d_wino4_chain_workspace(self.B, self.cmax, self.H, self.W, dev)
             for i in range(1, 8):
                 self.chain[i] = bool(chain_bev and self.bev[i][5] == 4 and self.bev[i - 1][5] == 4 and i - 1 != 6 and
                                      K.conv2d_wino4_chain_supported(self.bev_cin[i], self.bev[i][1], self.H, self.W))

@@ -82,7 +82,7 @@ def test_conv2d_wino4_chain(dev, b, cin0, hw):
     for wp, sc, sh in zip(wps, scs, shs):
         ref = K.conv2d_wino4_fwd(ref, wp, 256, sc, sh, True)
     cmax = max(cin0, 256)
-    wsb = K.conv2d_wino4_workspace(b, cmax, cmax, hw[0], hw[1], dev)
+    wsb = K.conv2d_wino4_chain_workspace(b, cmax, hw[0], hw[1], dev)
     y = torch.empty(b, 256, *hw, device=dev)
     for i, (wp, sc, sh) in enumerate(zip(wps, scs, shs)):
         K.conv2d_wino4_chain(xd if i == 0 else None, None if i == 0 else (scs[i - 1], shs[i - 1], True), wp, cins[i], 256,

@@ -344,6 +344,9 @@ def main():
                     "streams, so one frame's latency-bound sparse stage overlaps another frame's MFMA-bound BEV stage")
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: the config's own -- car 1, "
                     "multi 8, waymo 4)")
+    ap.add_argument("--spconv-cfg", type=int, default=0, help="workgroup geometry of the sparse gather-GEMM-scatter kernel "
+                    "(A/B): 0 = default (8 waves, 128 KB of LDS slabs: one workgroup per CU), 1 = 4 waves / 64 KB (two per "
+                    "CU, and room beside a BEV GEMM workgroup of another frame in flight)")
     ap.add_argument("--eager", action="store_true", help="issue the ~80 launches per frame from the host instead of "
                     "replaying the captured hipGraph (A/B)")
     args = ap.parse_args()
@@ -360,6 +363,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if args.spconv_cfg:
+        from sassd import kernels as K0
+        K0.debug_set_spconv(args.spconv_cfg << 16)
     model, w = build_model(0, dev, args.config)
     B = args.batch if args.batch > 0 else w["batch"]
     S = max(1, args.inflight)
@@ -472,14 +478,14 @@ def main():
             if getattr(iso_plan, "chain", None) and any(iso_plan.chain):
                 # the fused output -> input transform between two chained layers, alone (GEMM switched off)
                 K.debug_set_wino4(0, 32)
-                args = (None, (scale, shift, True), wp, 256, cout, iso_plan.cmax, B, iso_plan.H, iso_plan.W, scale, shift, True,
-                        None, iso_plan.wino4_ws)
+                cargs = (None, (scale, shift, True), wp, 256, cout, iso_plan.cmax, B, iso_plan.H, iso_plan.W, scale, shift, True,
+                         None, iso_plan.wino4_ws)
                 for _ in range(3):
-                    K.conv2d_wino4_chain(*args)
+                    K.conv2d_wino4_chain(*cargs)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(20):
-                    K.conv2d_wino4_chain(*args)
+                    K.conv2d_wino4_chain(*cargs)
                 e1.record()
                 torch.cuda.synchronize()
                 w4_parts["outin_fused"] = e0.elapsed_time(e1) / 20
@@ -542,7 +548,7 @@ def main():
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": round(fps / world / PUBLISHED_FPS, 3) if headline else None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s, batch=%d, random-init SA-SSD weights, points resident in HBM" % (w["desc"], B),
-                   "frames_per_step_per_gpu": B, "frames_in_flight": S,
+                   "frames_per_step_per_gpu": B, "frames_in_flight": S, "spconv_cfg": args.spconv_cfg,
                    "launch": "eager host launches" if args.eager else "one hipGraph replay per frame",
                    "parallelism": "frame-sharded x%d, no collective" % world,
                    "vs_baseline_ref": "reference readme.md:2 '25 FPS' (hardware unstated), per-GPU fps / 25"},

@@ -456,40 +456,41 @@ def main():
             sp_ms = timed_graph_ms(iso_plan, None)
             iso_plan.capture(w["points_cap"], stages=("voxelize", "backbone", "tail"))
             frame_ms = timed_graph_ms(iso_plan, batch_of(29))
-    # the three launches of one F(4x4) layer timed separately on the live buffers of the last frame
+    # the launches of an F(4x4) layer timed separately on the LIVE buffers the last frame left behind (real activations:
+    # zero-filled or dense-random operands clock the chip differently): the GEMM on the transformed input of conv6, the fused
+    # output -> input transform and the output transform on its products, the input transform on the densified map
     w4_parts = {}
     if iso_plan.bev[1][5] == 4:
         from sassd import kernels as K
         wp, cout, ks, scale, shift, _ = iso_plan.bev[1]
-        xin, yout = iso_plan.act[0], iso_plan.act[1]
-        xin.normal_().clamp_(min=0)            # (chained layers never write the intermediate maps: time on live-like data)
-        with torch.cuda.stream(streams[0]):
-            for name, flags in (("in", 32 | 64), ("gemm", 16 | 64), ("out", 16 | 32)):
-                K.debug_set_wino4(0, flags)
-                for _ in range(3):
-                    K.conv2d_wino4_fwd(xin, wp, cout, scale, shift, True, yout, iso_plan.wino4_ws)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    K.conv2d_wino4_fwd(xin, wp, cout, scale, shift, True, yout, iso_plan.wino4_ws)
-                e1.record()
-                torch.cuda.synchronize()
-                w4_parts[name] = e0.elapsed_time(e1) / 20
-            if getattr(iso_plan, "chain", None) and any(iso_plan.chain):
-                # the fused output -> input transform between two chained layers, alone (GEMM switched off)
-                K.debug_set_wino4(0, 32)
-                cargs = (None, (scale, shift, True), wp, 256, cout, iso_plan.cmax, B, iso_plan.H, iso_plan.W, scale, shift, True,
-                         None, iso_plan.wino4_ws)
-                for _ in range(3):
-                    K.conv2d_wino4_chain(*cargs)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    K.conv2d_wino4_chain(*cargs)
-                e1.record()
-                torch.cuda.synchronize()
-                w4_parts["outin_fused"] = e0.elapsed_time(e1) / 20
+        wp0 = iso_plan.bev[0][0]
+        H_, W_, cm, ws = iso_plan.H, iso_plan.W, iso_plan.cmax, iso_plan.wino4_ws
+        chained = any(iso_plan.chain)
+
+        def timed_part(flags, call):
+            K.debug_set_wino4(0, flags)
+            for _ in range(3):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
             K.debug_set_wino4(0, 0)
+            return e0.elapsed_time(e1) / 20
+        with torch.cuda.stream(streams[0]):
+            prev = (scale, shift, True)
+            # debug bits: 16 skip input transform, 32 skip GEMM, 64 skip output transform, 128 skip fused transform
+            w4_parts["gemm"] = timed_part(128 | 16, lambda: K.conv2d_wino4_chain(
+                None, prev, wp, 256, cout, cm, B, H_, W_, scale, shift, True, None, ws))
+            if chained:
+                w4_parts["outin_fused"] = timed_part(32, lambda: K.conv2d_wino4_chain(
+                    None, prev, wp, 256, cout, cm, B, H_, W_, scale, shift, True, None, ws))
+            w4_parts["out"] = timed_part(128 | 32, lambda: K.conv2d_wino4_chain(
+                None, prev, wp, 256, cout, cm, B, H_, W_, scale, shift, True, iso_plan.act[1], ws))
+            w4_parts["in"] = timed_part(32, lambda: K.conv2d_wino4_chain(
+                iso_plan.dense, None, wp0, iso_plan.bev_cin[0], cout, cm, B, H_, W_, scale, shift, True, None, ws))
     headline = args.config == "car" and B == 1
     # ---- the training half of BASELINE.json's metric (configs[2]: car_cfg, batch 2 / GPU, bf16, DDP): every rank takes
     # part (gradient all-reduce over RCCL at N > 1); the record rides in the same JSON line as `train` ------------------

@@ -66,6 +66,23 @@ def _const_i32(dev, values):
     return _CONSTS_I32[key]
 
 
+_GT_CAT = [None, None]
+
+
+def _gt_cat(gt_bboxes):
+    """Ground-truth boxes of a batch as one contiguous fp32 [T, 7] tensor (None when the batch has none).  The four
+    consumers of a training step (RPN assignment, aux targets, guided anchors, rescoring targets) share one concatenation:
+    the last result is kept, keyed on the identity and autograd version of the per-sample tensors."""
+    key = tuple((id(g), g._version, tuple(g.shape)) for g in gt_bboxes)
+    if _GT_CAT[0] != key:
+        tot = sum(int(g.shape[0]) for g in gt_bboxes)
+        _GT_CAT[1] = torch.cat([g.float() for g in gt_bboxes], 0).contiguous() if tot else None
+        _GT_CAT[0] = key
+        _GT_CAT.append(list(gt_bboxes))          # (keeps the keyed tensors alive: their ids cannot be recycled)
+        del _GT_CAT[2:-1]
+    return _GT_CAT[1]
+
+
 def change_default_args(**kwargs):
     """mmdet/models/utils/__init__.py:41."""
     def layer_wrapper(layer_class):
@@ -293,7 +310,7 @@ class SpMiddleFHD(nn.Module):
         voxel_features, coors, middle, batch_size = ctx
         dev = voxel_features.device
         counts = [int(g.shape[0]) for g in gt_bboxes]
-        gt_all = torch.cat([g.float() for g in gt_bboxes], 0).contiguous() if sum(counts) else None
+        gt_all = _gt_cat(gt_bboxes)
         points, known, label, target, npos = K.aux_prepare(
             voxel_features.detach().float().contiguous(), coors.int().contiguous(),
             [m.indices.int().contiguous() for m in middle], self.aux_voxel_size, self.aux_offset, gt_all,
@@ -443,7 +460,7 @@ class SSDRotateHead(nn.Module):
         a_c = anchors[names[0]].shape[1]
         counts = [int(g.shape[0]) for g in gt_bboxes]
         gt_off = K.gt_offsets(counts, dev)
-        gt_all = torch.cat([g.float() for g in gt_bboxes], 0).contiguous() if sum(counts) else None
+        gt_all = _gt_cat(gt_bboxes)
         cls_all = torch.cat([l.to(dev).long() for l in gt_labels], 0).contiguous() if sum(counts) else None
         flat = np.concatenate([np.asarray(c) == n for n in names for c in gt_types] or [np.zeros(0, bool)])
         up = torch.from_numpy(flat).pin_memory().to(dev, non_blocking=True)
@@ -544,7 +561,7 @@ class SSDRotateHead(nn.Module):
         gmax = max(counts) if counts else 0
         if self.fused_tail:
             # decode + direction flip + ground-truth prefix in one kernel each way (sassd_guided_decode_*)
-            gt_all = torch.cat([g.float() for g in gt_bboxes], 0).contiguous() if sum(counts) else None
+            gt_all = _gt_cat(gt_bboxes)
             guided, total = GuidedDecodeFn.apply(box_preds.view(b, a, self._box_code_size),
                                                  dir_cls_preds.view(b, a, 2) if self._use_direction_classifier else None,
                                                  anchors.view(b, a, 7).contiguous(), sel, cnt, gt_all,
@@ -697,7 +714,7 @@ class PSWarpHead(nn.Module):
         for i in range(b):
             o += capk * g_counts[i]
             offs.append(o)
-        gt_all = torch.cat([g.float() for g in gt_bboxes]).contiguous() if tot else None
+        gt_all = _gt_cat(gt_bboxes)
         if self.fused_tail and tot:
             # every sample's rotated 3-D IoU matrix in one launch (sassd_boxes_iou3d_batch)
             ov = K.boxes_iou3d_batch(boxes, counts.contiguous(), gt_all, K.gt_offsets(g_counts, dev), max(g_counts),

@@ -440,7 +440,8 @@ def parse_losses(losses):
     """train_utils/__init__.py:8-25 without the per-term .item() host syncs: (total loss tensor, detached terms)."""
     one = lambda t: t.reshape(()) if t.numel() == 1 else t.mean()       # noqa: E731  (a [1] tensor needs no reduction)
     terms = {k: (one(v) if torch.is_tensor(v) else sum(one(x) for x in v)) for k, v in losses.items()}
-    total = sum(v for k, v in terms.items() if "loss" in k)
+    parts = [v for k, v in terms.items() if "loss" in k]
+    total = torch.stack(parts).sum() if len(parts) > 1 and all(torch.is_tensor(p) for p in parts) else sum(parts)
     return total, {k: v.detach() for k, v in terms.items()}
 
 
@@ -578,18 +579,29 @@ def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, 
     kw["sassd_merged"] = dict(voxels=voxels[:n0], num_points=nump[:n0], coordinates=coors4[:n0])
     if model is not None:
         shape0 = [int(v) for v in model.neck.sparse_shape]
-        caps = [max(n0, 1)] + [max(n0 * level_cap_factor, 1)] * 3
-        idx = [coors4[:max(n0, 1)]] + [torch.empty(c, 4, dtype=torch.int32, device=dev) for c in caps[1:]]
-        n_dev = torch.zeros(3, dtype=torch.int32, device=dev)
-        n_ptrs = [row_off[B:B + 1]] + [n_dev[i:i + 1] for i in range(3)]
-        nbr_s = [torch.empty(c, 27, dtype=torch.int32, device=dev) for c in caps]
-        nbr_d = [None] + [torch.empty(c, 27, dtype=torch.int32, device=dev) for c in caps[1:]]
-        pyr = K.RulebookPyramid(idx, n_ptrs, caps, shape0, B, nbr_s, nbr_d, status)
-        pyr.build()
-        tail = torch.cat([n_dev, status]).cpu().numpy()    # host sync 2: down-sampled row counts + overflow flags
+
+        def build_pyramid(factor):
+            # a strided level has at most 8 x the rows of the level above (isolated voxels); LiDAR frames sit near 1.1 x,
+            # tiny or very sparse clouds well above 2 x: capacity = factor x n0 with a floor, never more than 8 x the level above
+            caps = [max(n0, 1)]
+            for _ in range(3):
+                caps.append(max(min(8 * caps[-1], max(n0 * factor, n0 + 16384)), 1))
+            idx = [coors4[:max(n0, 1)]] + [torch.empty(c, 4, dtype=torch.int32, device=dev) for c in caps[1:]]
+            n_dev = torch.zeros(3, dtype=torch.int32, device=dev)
+            n_ptrs = [row_off[B:B + 1]] + [n_dev[i:i + 1] for i in range(3)]
+            nbr_s = [torch.empty(c, 27, dtype=torch.int32, device=dev) for c in caps]
+            nbr_d = [None] + [torch.empty(c, 27, dtype=torch.int32, device=dev) for c in caps[1:]]
+            pyr = K.RulebookPyramid(idx, n_ptrs, caps, shape0, B, nbr_s, nbr_d, status)
+            pyr.build()
+            return idx, nbr_s, nbr_d, pyr, torch.cat([n_dev, status]).cpu().numpy()   # host sync 2: row counts + flags
+
+        idx, nbr_s, nbr_d, pyr, tail = build_pyramid(level_cap_factor)
+        if int(tail[3]) != 0 and level_cap_factor < 8:
+            status.zero_()                                 # capacity overflow: once more with the worst-case bound
+            idx, nbr_s, nbr_d, pyr, tail = build_pyramid(8)
         if int(tail[3]) != 0:
-            raise RuntimeError("device_batch: status 0x%x (voxel / rulebook capacity overflow: raise max_voxels or "
-                               "level_cap_factor)" % int(tail[3]))
+            raise RuntimeError("device_batch: status 0x%x (voxel / rulebook capacity overflow: raise max_voxels)"
+                               % int(tail[3]))
         n = [n0] + [int(v) for v in tail[:3]]
         shapes = [shape0]
         for _ in range(3):

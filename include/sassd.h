@@ -234,7 +234,7 @@ int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *s
  * direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulation, NCHW fp32 activations in and out, optional
  * per-channel bias.  Weights are packed once per update ([Cout,Cin,3,3] fp32 -> bf16 [tap][Cin32/8][Cout][8],
  * sassd_conv2d_bf16_packed_elems 16-bit elements).  The data gradient is the same call on dy with the weights
- * transposed and the taps mirrored.  Supported: Cout % 32 == 0, W % 16 == 0 (else SASSD_EINVAL; the caller keeps the
+ * transposed and the taps mirrored.  Supported: Cout % 32 == 0, W >= 16 and W % 4 == 0 (the last 16-column tile may be partial: the 188-wide Waymo-scale map; else SASSD_EINVAL; the caller keeps the
  * fp32 kernels); Cin is padded to a multiple of 32 with zero weights inside the pack. */
 int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W);
 void sassd_debug_set_bf16(int flags);   /* ablation switches, 0 = off (tools/run_bf16_conv.py) */

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
 #pragma unroll 1
             for (int e = lt; e < kItems; e += NLT) {
                 const int qd = e % (kLC / 4), row = (e / (kLC / 4)) % kLR, g = e / (kLR * (kLC / 4));
-                const int yy = r0 - 1 + row, xx = c0 - 4 + 4 * qd;            // xx % 4 == 0, W % 16 == 0: whole quad in or out
+                const int yy = r0 - 1 + row, xx = c0 - 4 + 4 * qd;            // xx % 4 == 0, W % 4 == 0: whole quad in or out
                 const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
                 const float *q = xb + (ok ? (size_t)yy * p.W + xx : 0);
                 f32x4 st[8];
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
 #pragma unroll
     for (int n = 0; n < NPB; ++n) {
         const int yy = r0 + 2 * n + (li >> 4), xx = c0 + (li & 15);
-        if (yy >= p.H) continue;
+        if (yy >= p.H || xx >= p.W) continue;               // partial last tile row / column
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co_w + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -244,7 +244,9 @@ extern "C" void sassd_debug_set_bf16(int flags) { g_bf16_dbg = flags; }
 
 extern "C" int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W)
 {
-    return Cin >= 1 && Cout >= 32 && Cout % 32 == 0 && H >= 1 && W >= 16 && W % 16 == 0;
+    // W % 4 == 0: the loader stages whole 4-pixel quads (in or out of the image together, 16-byte aligned); a map whose width is
+    // not a multiple of the 16-column tile (the 188-wide Waymo-scale BEV map) gets a partial last tile column with masked stores
+    return Cin >= 1 && Cout >= 32 && Cout % 32 == 0 && H >= 1 && W >= 16 && W % 4 == 0;
 }
 
 extern "C" size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout) { return (size_t)9 * align_up(Cin, 32) * Cout; }
@@ -266,7 +268,7 @@ extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const
     BfParams p;
     p.x = x; p.wp = (const unsigned short *)w_packed; p.shift = shift; p.y = y;
     p.B = batch; p.Cin = Cin; p.CinP = (int)align_up(Cin, 32); p.Cout = Cout; p.H = H; p.W = W;
-    p.tiles_x = W / kTC; p.tiles_y = cdiv(H, kTR);
+    p.tiles_x = cdiv(W, kTC); p.tiles_y = cdiv(H, kTR);
     hipStream_t s = (hipStream_t)stream_;
     const long tiles = (long)p.tiles_x * p.tiles_y * batch;
     if (Cout % 256 == 0) {

@@ -35,7 +35,7 @@ def test_argument_validation_returns_error_codes():
     p16 = C.c_void_p(16)
     assert L.sassd_conv2d_bf16_fwd(null, null, null, null, 1, 32, 128, 8, 16, null) == EINVAL
     assert L.sassd_conv2d_bf16_fwd(p16, p16, null, p16, 1, 32, 100, 8, 16, null) == EINVAL        # Cout % 32
-    assert L.sassd_conv2d_bf16_fwd(p16, p16, null, p16, 1, 32, 128, 8, 20, null) == EINVAL        # W % 16
+    assert L.sassd_conv2d_bf16_fwd(p16, p16, null, p16, 1, 32, 128, 8, 18, null) == EINVAL        # W % 4
     assert L.sassd_conv2d_bwd_weight_bf16(p16, p16, p16, 1, 16, 16, 8, 9, 3, 0, p16, 1 << 30, null) == EINVAL   # odd W
     assert L.sassd_conv2d_bwd_weight_bf16(p16, p16, p16, 1, 16, 16, 8, 8, 3, 0, p16, 4, null) == ENOSPC
     assert L.sassd_assign_targets(null, 0, null, 100, 2, null, null, null, null, 0, null, null, 0.6, 0.45, null, null,
@@ -72,7 +72,8 @@ def test_host_side_queries():
     assert L.sassd_spconv_bwd_weight_workspace_bytes(16111, 27, 64, 64) >= 126 * 27 * 64 * 64 * 4
     assert L.sassd_hash_bytes(20000) >= 2 * 20000 * 8
     assert L.sassd_conv2d_bf16_supported(256, 256, 200, 176) == 1 and L.sassd_conv2d_bf16_supported(28, 256, 200, 176) == 1
-    assert L.sassd_conv2d_bf16_supported(256, 28, 200, 176) == 0 and L.sassd_conv2d_bf16_supported(256, 256, 200, 180) == 0
+    assert L.sassd_conv2d_bf16_supported(256, 28, 200, 176) == 0 and L.sassd_conv2d_bf16_supported(256, 256, 200, 182) == 0
+    assert L.sassd_conv2d_bf16_supported(256, 256, 188, 188) == 1      # partial last tile column (W % 4 == 0)
     assert L.sassd_conv2d_bf16_packed_elems(28, 256) == 9 * 32 * 256          # Cin padded to 32 inside the pack
     assert L.sassd_assign_targets_workspace_bytes(2, 70400, 16) >= 2 * 70400 * 8 + 16 * 4
     assert L.sassd_rpn_loss_workspace_bytes(2, 70400) == 2 * 275 * 3 * 4

@@ -66,7 +66,8 @@ def test_wgrad_bf16_full_bev_layer(dev):
 
 @pytest.mark.parametrize("b,cin,cout,hw", [(2, 256, 256, (24, 32)), (1, 128, 256, (17, 48)), (2, 256, 128, (8, 16)),
                                           (1, 32, 128, (5, 176)), (1, 64, 512, (9, 16)), (2, 28, 256, (12, 32)),
-                                          (1, 70, 128, (6, 16)), (2, 256, 320, (16, 32)), (1, 64, 96, (8, 16))])
+                                          (1, 70, 128, (6, 16)), (2, 256, 320, (16, 32)), (1, 64, 96, (8, 16)),
+                                          (1, 64, 256, (11, 188)), (2, 32, 64, (23, 20)), (1, 256, 256, (188, 188))])
 def test_conv3x3_bf16(dev, b, cin, cout, hw):
     g = torch.Generator().manual_seed(cin + 3 * cout)
     x = torch.randn(b, cin, *hw, generator=g)

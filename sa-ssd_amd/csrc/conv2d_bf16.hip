@@ -224,22 +224,51 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
         yb[(size_t)(co_w + lh) * hw + (size_t)(r0 + (li >> 4)) * p.W + c0 + (li & 15)] = t;
         return;
     }
+    // Through LDS (the input buffers are dead: every MMA wave is past the last barrier, the loader waves have left): a
+    // 32 couts x 32 pixels accumulator tile goes to the wave's private 4.5 KB image and comes back as 16-byte pieces
+    // along the pixel rows -- 4 float4 stores per lane and tile instead of 16 dword stores (a dword store costs several
+    // times more per byte; the epilogue was 29 of the kernel's 124 us in the round-2 ablation).
+    if (DBG & 16) {     // A/B: the dword-store epilogue
+#pragma unroll
+        for (int n = 0; n < NPB; ++n) {
+            const int yy = r0 + 2 * n + (li >> 4), xx = c0 + (li & 15);
+            if (yy >= p.H || xx >= p.W) continue;               // partial last tile row / column
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_w + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float sh = p.shift ? p.shift[co] : 0.f;
+                yb[(size_t)co * hw + (size_t)yy * p.W + xx] = acc[n][r] + sh;
+            }
+        }
+        return;
+    }
+    constexpr int kEP = 36;                                     // image row pitch in floats (16-byte aligned rows)
+    static_assert(COW * 32 * kEP * 4 <= 2 * kBufB, "epilogue images exceed the LDS input buffers");
+    float *img = (float *)lds + wave * 32 * kEP;
 #pragma unroll
     for (int n = 0; n < NPB; ++n) {
-        const int yy = r0 + 2 * n + (li >> 4), xx = c0 + (li & 15);
-        if (yy >= p.H || xx >= p.W) continue;               // partial last tile row / column
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_w + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float sh = p.shift ? p.shift[co] : 0.f;
-            yb[(size_t)co * hw + (size_t)yy * p.W + xx] = acc[n][r] + sh;
+        for (int r = 0; r < 16; ++r) img[((r & 3) + 8 * (r >> 2) + 4 * lh) * kEP + li] = acc[n][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private image: written, now read back
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = (j * 64 + lane) * 4;                  // element of the [32 co][32 px] tile
+            const int col = e >> 5, px = e & 31;                // cout row of the tile, first pixel of the quad
+            const f32x4 v = *(const f32x4 *)(img + col * kEP + px);
+            const int co = co_w + col;
+            const int yy = r0 + 2 * n + (px >> 4), xx = c0 + (px & 15);
+            if (yy < p.H && xx < p.W) {                         // W % 4 == 0: a quad is inside or outside as a whole
+                const float sh = p.shift ? p.shift[co] : 0.f;
+                *(f32x4 *)(yb + (size_t)co * hw + (size_t)yy * p.W + xx) = (f32x4){v[0] + sh, v[1] + sh, v[2] + sh, v[3] + sh};
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads retired before the next tile overwrites the image
     }
 }
 }  // namespace
 
 // ablation (tools/run_bf16_conv.py --ablate): bit0 stage only the first input chunk, bit1 re-load one hot weight
-// fragment, bit2 no MFMA, bit3 no output stores
+// fragment, bit2 no MFMA, bit3 no output stores, bit4 (value 16) the round-2 dword-store epilogue
 extern "C" void sassd_debug_set_bf16(int flags) { g_bf16_dbg = flags; }
 
 extern "C" int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W)
@@ -276,7 +305,7 @@ extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const
         switch (g_bf16_dbg) {       // compile-time ablation variants (a run-time switch inside the kernel de-tunes it)
 #define SASSD_BF16_VARIANT(D) case D: hipLaunchKernelGGL((conv2d_bf16_kernel<8, 4, D>), grid, dim3(768), 0, s, p); break;
             SASSD_BF16_VARIANT(1) SASSD_BF16_VARIANT(2) SASSD_BF16_VARIANT(3) SASSD_BF16_VARIANT(4)
-            SASSD_BF16_VARIANT(8) SASSD_BF16_VARIANT(11) SASSD_BF16_VARIANT(15)
+            SASSD_BF16_VARIANT(8) SASSD_BF16_VARIANT(11) SASSD_BF16_VARIANT(15) SASSD_BF16_VARIANT(16)
 #undef SASSD_BF16_VARIANT
             default: hipLaunchKernelGGL((conv2d_bf16_kernel<8, 4, 0>), grid, dim3(768), 0, s, p);
         }

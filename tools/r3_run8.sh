@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r3h; O=gpurun_out/r3h
+timeout 600 python -m pytest tests/test_gpu_bf16.py -q -s > $O/t_bf16.log 2>&1; echo "bf16 tests rc=$?"; tail -3 $O/t_bf16.log
+timeout 300 python tools/run_bf16_conv.py --ablate > $O/bf16_conv_timing.json 2> $O/bf16_conv_timing.err; echo "timing rc=$?"; cat $O/bf16_conv_timing.json
+timeout 300 python bench.py --mode train --steps 40 --warmup 8 > $O/bench_train.log 2> $O/bench_train.err; echo "train rc=$?"
+grep -o '"value": [0-9.]*' $O/bench_train.log

@@ -121,4 +121,34 @@ if nf and nw:
     rec["traffic_bytes_per_launch"] = rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]
     rec["traffic_over_algorithmic"] = round(rec["traffic_bytes_per_launch"] / alg, 3)
     json.dump(rec, open(os.path.join(DST, "%s_bf16_conv_hbm_traffic.json" % tag), "w"), indent=1)
+# SQ stall counters of the three hot kernels (one pass each, eight SQ counters): where the wave-cycles go
+stall = {}
+for name, pats in (("stall_bf16conv", ("conv2d_bf16_kernel",)), ("stall_sparse_car", ("spconv_gs_kernel",)),
+                   ("stall_wino4", ("wino4_gemm_kernel", "wino4_outin_kernel", "wino4_in_kernel", "wino4_out_kernel"))):
+    path = os.path.join(SRC, name + "_SQ_WAVE_CYCLES.json")
+    if not os.path.exists(path):
+        continue
+    d = json.load(open(path))
+    if "error" in d:
+        continue
+    for pat in pats:
+        acc, nd = {}, 0
+        for k, v in d.items():
+            if pat in k:
+                for c, rec in v.items():
+                    acc[c] = acc.get(c, 0.0) + rec["mean_per_dispatch"] * rec["dispatches"]
+                    nd = max(nd, rec["dispatches"])
+        if acc and acc.get("SQ_WAVE_CYCLES"):
+            wc = acc["SQ_WAVE_CYCLES"]
+            stall[pat] = dict(dispatches=nd, per_dispatch={c: v / nd for c, v in acc.items()},
+                              fraction_of_wave_cycles={c: round(v / wc, 4) for c, v in acc.items() if c != "SQ_WAVE_CYCLES"})
+if stall:
+    json.dump(dict(csrc_hash=CSRC,
+                   command="rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                           "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -- python tools/"
+                           "run_bf16_conv.py | run_sparse_only.py --config car | run_wino4.py --profile",
+                   note="MI355X_MICROARCH.md: SQ_WAIT_ANY = wave parked (s_waitcnt / barrier), SQ_WAIT_INST_ANY = issue stall, "
+                        "SQ_ACTIVE_INST_ANY = issuing; the three are disjoint and add up to ~SQ_WAVE_CYCLES (quad-cycles); "
+                        "SQ_VALU_MFMA_BUSY_CYCLES counts cycles",
+                   kernels=stall), open(os.path.join(DST, "%s_stall_breakdown.json" % tag), "w"), indent=1)
 print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith(tag)))

@@ -104,33 +104,67 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
         // padding of the last chunk) read the last real plane: their weights are zero.
         const float *xb = p.x + (size_t)b * p.Cin * hw;
         const int lt = tid - 64 * COW;
-        auto stage = [&](int ci0, int buf) {
-#pragma unroll 1
-            for (int e = lt; e < kItems; e += NLT) {
-                const int qd = e % (kLC / 4), row = (e / (kLC / 4)) % kLR, g = e / (kLR * (kLC / 4));
-                const int yy = r0 - 1 + row, xx = c0 - 4 + 4 * qd;            // xx % 4 == 0, W % 4 == 0: whole quad in or out
-                const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                const float *q = xb + (ok ? (size_t)yy * p.W + xx : 0);
-                f32x4 st[8];
+        // an item = (8-channel group, tile row, pixel quad): 8 plane loads, then four 16-byte channel vectors into LDS.  With
+        // 288 items on 256 loader threads 32 threads own two.  The loads of chunk c+2 are ISSUED before the barrier that ends
+        // chunk c and converted / stored after it (hand-issued like the weight ring: the compiler's barrier does not drain
+        // loads it does not know about), so a chunk's memory latency has a whole chunk of MFMAs to hide behind and the loader
+        // waves reach every barrier early -- `profiles/r03_stall_breakdown.json` showed 48 % of the kernel's wave-cycles
+        // parked, with load -> convert -> store -> barrier inside ONE chunk time.
+        auto item_geom = [&](int e, bool live, bool &ok, int &dst_off, const float *&q, int &g) {
+            const int qd = e % (kLC / 4), row = (e / (kLC / 4)) % kLR;
+            g = e / (kLR * (kLC / 4));
+            const int yy = r0 - 1 + row, xx = c0 - 4 + 4 * qd;            // xx % 4 == 0, W % 4 == 0: whole quad in or out
+            ok = live && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            q = xb + (ok ? (size_t)yy * p.W + xx : 0);
+            dst_off = row * kRowB + 4 * qd * kPixB + g * 16;
+        };
+        auto item_issue = [&](int e, bool live, f32x4 (&st)[8], int ci0) {
+            bool ok; int d, g; const float *q;
+            item_geom(e, live, ok, d, q, g);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ch = ok ? min(ci0 + g * 8 + j, p.Cin - 1) : 0;
-                    st[j] = *(const f32x4 *)(q + (size_t)ch * hw);
-                }
-                unsigned char *dst = lds + buf * kBufB + row * kRowB + 4 * qd * kPixB + g * 16;
-#pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    u32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = ok ? pack2(st[2 * j][px], st[2 * j + 1][px]) : 0u;
-                    *(u32x4 *)(dst + px * kPixB) = v;
-                }
+            for (int j = 0; j < 8; ++j) {
+                const int ch = ok ? min(ci0 + g * 8 + j, p.Cin - 1) : 0;
+                const float *a = q + (size_t)ch * hw;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st[j]) : "v"(a));
             }
         };
-        stage(0, 0);
+        auto item_store = [&](int e, bool live, const f32x4 (&st)[8], int buf) {
+            bool ok; int d, g; const float *q;
+            item_geom(e, live, ok, d, q, g);
+            unsigned char *dst = lds + buf * kBufB + d;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                u32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ok ? pack2(st[2 * j][px], st[2 * j + 1][px]) : 0u;
+                *(u32x4 *)(dst + px * kPixB) = v;
+            }
+        };
+        static_assert(kItems <= 2 * NLT, "a loader thread owns at most two items");
+        const bool one = lt < kItems, two = lt + NLT < kItems;
+        f32x4 s0[8], s1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; s1[j] = s0[j]; }
+        auto issue = [&](int ci0) {
+            if (one) item_issue(lt, true, s0, ci0);
+            if (two) item_issue(lt + NLT, true, s1, ci0);
+        };
+        auto land = [&](int buf) {      // every hand-issued load of this wave has returned; registers -> LDS
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(s0[0]), "+v"(s0[1]), "+v"(s0[2]), "+v"(s0[3]), "+v"(s0[4]), "+v"(s0[5]), "+v"(s0[6]), "+v"(s0[7]),
+                           "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
+            if (one) item_store(lt, true, s0, buf);
+            if (two) item_store(lt + NLT, true, s1, buf);
+        };
+        issue(0);
+        land(0);
+        if (nchunk > 1 && !(DBG & 1)) issue(kKC);
         __syncthreads();
         for (int c = 0; c < nchunk; ++c) {
-            if (c + 1 < nchunk && !(DBG & 1)) stage((c + 1) * kKC, (c + 1) & 1);
+            if (c + 1 < nchunk && !(DBG & 1)) {
+                land((c + 1) & 1);                      // chunk c+1 (issued one chunk ago) -> the buffer chunk c-1 vacated
+                if (c + 2 < nchunk) issue((c + 2) * kKC);
+            }
             __syncthreads();
         }
         return;

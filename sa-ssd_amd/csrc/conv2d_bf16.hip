@@ -48,6 +48,7 @@ struct BfParams {
     float *y;
     int B, Cin, CinP, Cout, H, W;                  // CinP: Cin rounded up to a whole 32-channel chunk
     int tiles_x, tiles_y;
+    int nwg;                                       // real workgroups (the grid is padded to a multiple of 8)
 };
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi)
@@ -78,18 +79,27 @@ __global__ void bf16_pack_kernel(const float *__restrict__ w, int Cout, int Cin,
 // (global fp32 -> bf16 -> LDS) while the MMA waves multiply the current one.  The split matters because vector-memory
 // loads return in order: with one wave doing both, every wait for a weight fragment (L2 latency) also waited for the
 // input-tile loads issued before it (HBM / MALL latency), and the MFMA pipe idled for about half of every chunk.
-template <int COW, int NLW, int DBG>
-__global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfParams p)
+// CPW = 32-cout blocks per MMA wave.  CPW = 2 (round 3: 4 MMA + 4 loader waves, 2 waves per SIMD, 256 VGPRs each): every
+// B fragment read from LDS feeds TWO MFMAs and a SIMD hosts one MMA wave, so the wave's own ten MFMAs per step (320 cycles)
+// cover its LDS / weight look-ahead -- with CPW = 1 (8 + 4 waves, 170 VGPRs) eight MMA waves issued their five-fragment
+// ds_read bursts together and two of them shared every MFMA pipe (profiles/r03_stall_breakdown.json: MFMA busy 33 %).
+template <int COW, int NLW, int DBG, int CPW = 1>
+__global__ void __launch_bounds__(64 * (COW + NLW), CPW == 1 ? 3 : 2) conv2d_bf16_kernel(BfParams p)
 {
     constexpr int NLT = 64 * NLW;                  // loader threads
     constexpr int NPB = kTR / 2;                   // 32-pixel blocks (2 rows x 16 columns) of the tile, all per MMA wave
-    constexpr int RING = 6;                        // weight fragments in flight per MMA wave (18 % RING == 0)
+    constexpr int RING = CPW == 1 ? 6 : 3;         // weight fragment STEPS in flight per MMA wave (18 % RING == 0)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kBufB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool loader = wave >= COW;               // wave-uniform
     const int li = lane & 31, lh = lane >> 5;
 
-    int wg = blockIdx.x;
+    // XCD-local tile order: blockIdx % 8 selects the XCD (dispatch order), and every XCD walks its own contiguous band of
+    // tiles, so the halo rows / columns two neighbouring tiles share (44 % of a tile's input) meet in that XCD's L2 instead
+    // of crossing the fabric twice (round-2 PMC: 2.8 x the algorithmic bytes; without the MFMAs the kernel still took 70 us
+    // = 416 MB at the HBM copy rate -- it is bound by that traffic).  The grid is padded to a multiple of 8.
+    int wg = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (wg >= p.nwg) return;                               // padding workgroup (uniform: before any barrier)
     const int tx = wg % p.tiles_x; wg /= p.tiles_x;
     const int ty = wg % p.tiles_y; wg /= p.tiles_y;
     const int b = wg % p.B;
@@ -171,31 +181,42 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
     }
 
     // ---- MMA waves
-    const int co_w = (cot * COW + wave) * 32;      // this wave's first cout
+    const int co_w = (cot * COW + wave) * 32 * CPW;     // this wave's first cout
     // Cout not a multiple of the workgroup's cout tile: the waves past Cout only keep the barriers company
     const bool active = co_w < p.Cout;
-    // A: packed weights, element ((tap * CinP/8 + c8) * Cout + co) * 8; this lane: co = co_w + li, c8 += lh
+    // A: packed weights, element ((tap * CinP/8 + c8) * Cout + co) * 8; this lane: co = co_w + 32 h + li, c8 += lh
     const unsigned short *wl = p.wp + ((size_t)lh * p.Cout + (active ? co_w : 0) + li) * 8;
     const size_t w_c8 = (size_t)p.Cout * 8;                 // elements per 8-channel group
     const size_t w_tap = (size_t)(p.CinP / 8) * w_c8;       // elements per tap
     // B: LDS byte offset of this lane's pixel for block n: rows 2*n + (li>>4), column (li&15) + kColOff (+ kx per tap)
     const int b_off = ((li >> 4) * kRowB) + ((li & 15) + kColOff) * kPixB + lh * 16;
 
-    f32x16 acc[NPB];
+    f32x16 acc[CPW][NPB];
 #pragma unroll
-    for (int n = 0; n < NPB; ++n)
+    for (int h = 0; h < CPW; ++h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        for (int n = 0; n < NPB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[h][n][r] = 0.f;
 
     // The weight loads are issued by hand (inline asm + explicit s_waitcnt): left to the compiler, the scheduler sinks
     // every load next to its MFMA to save registers, which turns the ring into load -> wait -> use.  These are the only
-    // vector-memory loads of an MMA wave inside the loop, so vmcnt counts exactly the ring.
-    u32x4 aring[RING];
+    // vector-memory loads of an MMA wave inside the loop, so vmcnt counts exactly the ring (CPW loads per step).
+    u32x4 aring[RING][CPW];
     auto load_a = [&](int slot, int chunk, int s) {          // s = 2*tap + kstep, chunk clamped by the caller
         const int tap = s >> 1, ks = s & 1;
         const unsigned short *q = wl + tap * w_tap + (size_t)(chunk * (kKC / 8) + ks * 2) * w_c8;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(aring[slot]) : "v"(q));
+#pragma unroll
+        for (int h = 0; h < CPW; ++h) {
+            const unsigned short *qh = q + h * 32 * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(aring[slot][h]) : "v"(qh));
+        }
     };
+    auto wait_a = [&](int slot) {      // RING * CPW loads are outstanding; the oldest CPW are this step's fragments
+        if constexpr (CPW == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(aring[slot][0]) : "n"(RING - 1));
+        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(aring[slot][0]), "+v"(aring[slot][CPW - 1]) : "n"((RING - 1) * CPW));
+    };
+    static_assert(CPW == 1 || CPW == 2, "one or two cout blocks per MMA wave");
     if (active) {
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s) load_a(s, 0, s);
@@ -224,26 +245,36 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
                     for (int n = 0; n < NPB; ++n)
                         bf[(s + 1) & 1][n] = *(const u32x4 *)(xt + (2 * n + ky) * kRowB + kx * kPixB + ks * 32);
                 }
-                // RING loads are outstanding; the oldest one is this step's fragment
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(aring[s % RING]) : "n"(RING - 1));
+                wait_a(s % RING);
                 if (!(DBG & 4)) {
 #pragma unroll
                 for (int n = 0; n < NPB; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aring[s % RING]),
-                                                                    __builtin_bit_cast(bf16x8, bf[s & 1][n]), acc[n],
-                                                                    0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < CPW; ++h)
+                        acc[h][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aring[s % RING][h]),
+                                                                           __builtin_bit_cast(bf16x8, bf[s & 1][n]),
+                                                                           acc[h][n], 0, 0, 0);
                 } else {
 #pragma unroll
-                for (int n = 0; n < NPB; ++n) acc[n][0] += __builtin_bit_cast(float, aring[s % RING][0] ^ bf[s & 1][n][1]);
+                for (int n = 0; n < NPB; ++n)
+#pragma unroll
+                    for (int h = 0; h < CPW; ++h)
+                        acc[h][n][0] += __builtin_bit_cast(float, aring[s % RING][h][0] ^ bf[s & 1][n][1]);
                 }
             }
         }
         __syncthreads();
     }
     if (active) {     // drain the look-ahead loads of the (clamped) "next" chunk before their registers are reused
-        static_assert(RING == 6, "the drain below names the six ring registers");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(aring[0]), "+v"(aring[1]), "+v"(aring[2]), "+v"(aring[3]),
-                     "+v"(aring[4]), "+v"(aring[5]));
+        if constexpr (CPW == 1) {
+            static_assert(CPW != 1 || RING == 6, "the drain below names the six ring registers");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(aring[0][0]), "+v"(aring[1][0]), "+v"(aring[2][0]), "+v"(aring[3][0]),
+                         "+v"(aring[4][0]), "+v"(aring[5][0]));
+        } else {
+            static_assert(CPW != 2 || RING == 3, "the drain below names the 3 x 2 ring registers");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(aring[0][0]), "+v"(aring[0][CPW - 1]), "+v"(aring[1][0]),
+                         "+v"(aring[1][CPW - 1]), "+v"(aring[2][0]), "+v"(aring[2][CPW - 1]));
+        }
     }
 
     // ---- epilogue: D row = cout = (r & 3) + 8 * (r >> 2) + 4 * lh, column = pixel li -> (row li >> 4, column li & 15)
@@ -252,57 +283,64 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
     if (DBG & 8) {      // ablation: one store per lane that depends on every accumulator
         float t = 0.f;
 #pragma unroll
-        for (int n = 0; n < NPB; ++n)
+        for (int h = 0; h < CPW; ++h)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t += acc[n][r];
+            for (int n = 0; n < NPB; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[h][n][r];
         yb[(size_t)(co_w + lh) * hw + (size_t)(r0 + (li >> 4)) * p.W + c0 + (li & 15)] = t;
         return;
     }
     // Through LDS (the input buffers are dead: every MMA wave is past the last barrier, the loader waves have left): a
     // 32 couts x 32 pixels accumulator tile goes to the wave's private 4.5 KB image and comes back as 16-byte pieces
-    // along the pixel rows -- 4 float4 stores per lane and tile instead of 16 dword stores (a dword store costs several
-    // times more per byte; the epilogue was 29 of the kernel's 124 us in the round-2 ablation).
-    if (DBG & 16) {     // A/B: the dword-store epilogue
+    // along the pixel rows -- 4 float4 stores per lane and tile instead of 16 dword stores.
+    if (DBG & 16) {     // A/B: the dword-store epilogue of round 2
 #pragma unroll
-        for (int n = 0; n < NPB; ++n) {
-            const int yy = r0 + 2 * n + (li >> 4), xx = c0 + (li & 15);
-            if (yy >= p.H || xx >= p.W) continue;               // partial last tile row / column
+        for (int h = 0; h < CPW; ++h)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co_w + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float sh = p.shift ? p.shift[co] : 0.f;
-                yb[(size_t)co * hw + (size_t)yy * p.W + xx] = acc[n][r] + sh;
+            for (int n = 0; n < NPB; ++n) {
+                const int yy = r0 + 2 * n + (li >> 4), xx = c0 + (li & 15);
+                if (yy >= p.H || xx >= p.W) continue;           // partial last tile row / column
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_w + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float sh = p.shift ? p.shift[co] : 0.f;
+                    yb[(size_t)co * hw + (size_t)yy * p.W + xx] = acc[h][n][r] + sh;
+                }
             }
-        }
         return;
     }
     constexpr int kEP = 36;                                     // image row pitch in floats (16-byte aligned rows)
     static_assert(COW * 32 * kEP * 4 <= 2 * kBufB, "epilogue images exceed the LDS input buffers");
     float *img = (float *)lds + wave * 32 * kEP;
 #pragma unroll
-    for (int n = 0; n < NPB; ++n) {
+    for (int h = 0; h < CPW; ++h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) img[((r & 3) + 8 * (r >> 2) + 4 * lh) * kEP + li] = acc[n][r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private image: written, now read back
+        for (int n = 0; n < NPB; ++n) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = (j * 64 + lane) * 4;                  // element of the [32 co][32 px] tile
-            const int col = e >> 5, px = e & 31;                // cout row of the tile, first pixel of the quad
-            const f32x4 v = *(const f32x4 *)(img + col * kEP + px);
-            const int co = co_w + col;
-            const int yy = r0 + 2 * n + (px >> 4), xx = c0 + (px & 15);
-            if (yy < p.H && xx < p.W) {                         // W % 4 == 0: a quad is inside or outside as a whole
-                const float sh = p.shift ? p.shift[co] : 0.f;
-                *(f32x4 *)(yb + (size_t)co * hw + (size_t)yy * p.W + xx) = (f32x4){v[0] + sh, v[1] + sh, v[2] + sh, v[3] + sh};
+            for (int r = 0; r < 16; ++r) img[((r & 3) + 8 * (r >> 2) + 4 * lh) * kEP + li] = acc[h][n][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private image: written, now read back
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = (j * 64 + lane) * 4;              // element of the [32 co][32 px] tile
+                const int col = e >> 5, px = e & 31;            // cout row of the tile, first pixel of the quad
+                const f32x4 v = *(const f32x4 *)(img + col * kEP + px);
+                const int co = co_w + 32 * h + col;
+                const int yy = r0 + 2 * n + (px >> 4), xx = c0 + (px & 15);
+                if (yy < p.H && xx < p.W) {                     // W % 4 == 0: a quad is inside or outside as a whole
+                    const float sh = p.shift ? p.shift[co] : 0.f;
+                    *(f32x4 *)(yb + (size_t)co * hw + (size_t)yy * p.W + xx) =
+                        (f32x4){v[0] + sh, v[1] + sh, v[2] + sh, v[3] + sh};
+                }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads retired before the next tile overwrites the image
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads retired before the next tile overwrites the image
-    }
 }
 }  // namespace
 
 // ablation (tools/run_bf16_conv.py --ablate): bit0 stage only the first input chunk, bit1 re-load one hot weight
-// fragment, bit2 no MFMA, bit3 no output stores, bit4 (value 16) the round-2 dword-store epilogue
+// fragment, bit2 no MFMA, bit3 no output stores, bit4 (value 16) the round-2 dword-store epilogue (all on the 8 + 4 wave
+// kernel), value 32 the 8 + 4 wave kernel itself (the default is 4 MMA waves of 64 couts + 4 loader waves)
 extern "C" void sassd_debug_set_bf16(int flags) { g_bf16_dbg = flags; }
 
 extern "C" int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W)
@@ -335,16 +373,19 @@ extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const
     hipStream_t s = (hipStream_t)stream_;
     const long tiles = (long)p.tiles_x * p.tiles_y * batch;
     if (Cout % 256 == 0) {
-        const dim3 grid((unsigned)(tiles * (Cout / 256)));
+        p.nwg = (int)(tiles * (Cout / 256));
+        const dim3 grid((unsigned)(cdiv(p.nwg, 8) * 8));
         switch (g_bf16_dbg) {       // compile-time ablation variants (a run-time switch inside the kernel de-tunes it)
 #define SASSD_BF16_VARIANT(D) case D: hipLaunchKernelGGL((conv2d_bf16_kernel<8, 4, D>), grid, dim3(768), 0, s, p); break;
             SASSD_BF16_VARIANT(1) SASSD_BF16_VARIANT(2) SASSD_BF16_VARIANT(3) SASSD_BF16_VARIANT(4)
             SASSD_BF16_VARIANT(8) SASSD_BF16_VARIANT(11) SASSD_BF16_VARIANT(15) SASSD_BF16_VARIANT(16)
 #undef SASSD_BF16_VARIANT
-            default: hipLaunchKernelGGL((conv2d_bf16_kernel<8, 4, 0>), grid, dim3(768), 0, s, p);
+            case 32: hipLaunchKernelGGL((conv2d_bf16_kernel<8, 4, 0>), grid, dim3(768), 0, s, p); break;   // A/B: 8 + 4 waves
+            default: hipLaunchKernelGGL((conv2d_bf16_kernel<4, 4, 0, 2>), grid, dim3(512), 0, s, p);       // 4 x 64 couts + 4
         }
     } else {    // 128-cout tiles; the last one may be partly idle (Cout = 320: 3 tiles, 2.5 used)
-        hipLaunchKernelGGL((conv2d_bf16_kernel<4, 4, 0>), dim3((unsigned)(tiles * cdiv(Cout, 128))), dim3(512), 0, s, p);
+        p.nwg = (int)(tiles * cdiv(Cout, 128));
+        hipLaunchKernelGGL((conv2d_bf16_kernel<4, 4, 0>), dim3((unsigned)(cdiv(p.nwg, 8) * 8)), dim3(512), 0, s, p);
     }
     return sassd_launch_status();
 }

@@ -51,7 +51,7 @@ def main():
         if a.ablate:
             from sassd import _C
             names = {1: "no_input_staging", 2: "hot_weights", 4: "no_mfma", 8: "no_stores", 3: "no_global_loads",
-                     15: "only_lds", 11: "mfma_and_lds_only", 16: "dword_store_epilogue_r02"}
+                     15: "only_lds", 11: "mfma_and_lds_only", 16: "dword_store_epilogue_r02", 32: "kernel_8plus4_waves"}
             for flag, name in names.items():
                 _C.lib().sassd_debug_set_bf16(flag)
                 out["ablate_" + name + "_ms"] = timed(lambda: K.conv2d_bf16_fwd(x, pk, 256), a.iters)

@@ -43,6 +43,22 @@ static inline int sassd_dyn_lds(const void *fn, size_t bytes, std::atomic<unsign
     return SASSD_OK;
 }
 
+// Compute units of the current device (cached per device; persistent kernels launch one workgroup per CU).
+static inline int sassd_num_cus(int *out)
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SASSD_EHIP;
+    int n = cached[dev & 63].load(std::memory_order_acquire);
+    if (n <= 0) {
+        hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess || n <= 0) { g_sassd_last_hip_error = (int)e; return SASSD_EHIP; }
+        cached[dev & 63].store(n, std::memory_order_release);
+    }
+    *out = n;
+    return SASSD_OK;
+}
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline unsigned next_pow2(unsigned x)

@@ -13,7 +13,7 @@ from sassd import kernels as K  # noqa: E402
 
 
 def timed(fn, iters):
-    for _ in range(3):
+    for _ in range(max(10, iters // 2)):     # clocks settle over the first dozens of launches
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -27,13 +27,20 @@ def timed(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--ablate", action="store_true", help="time the bf16 conv with parts switched off")
+    ap.add_argument("--only-fwd", action="store_true", help="only the bf16 forward conv (for counter passes)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     x = torch.randn(2, 256, 200, 176, device=dev)
     dy = torch.randn(2, 256, 200, 176, device=dev) * 0.01
     out = {}
+    if a.only_fwd:
+        w = torch.randn(256, 256, 3, 3, device=dev) / 48
+        pk = K.conv2d_bf16_pack_weight(w)
+        out["fwd3x3_bf16_ms"] = timed(lambda: K.conv2d_bf16_fwd(x, pk, 256), a.iters)
+        print(json.dumps(out, indent=1))
+        return
     out["wgrad3x3_fp32_ms"] = timed(lambda: K.conv2d_bwd_weight(x, dy, 3), a.iters)
     out["wgrad3x3_bf16_ms"] = timed(lambda: K.conv2d_bwd_weight(x, dy, 3, bf16=True), a.iters)
     out["wgrad1x1_fp32_ms"] = timed(lambda: K.conv2d_bwd_weight(x, dy, 1), a.iters)
@@ -51,7 +58,13 @@ def main():
         if a.ablate:
             from sassd import _C
             names = {1: "no_input_staging", 2: "hot_weights", 4: "no_mfma", 8: "no_stores", 3: "no_global_loads",
-                     15: "only_lds", 11: "mfma_and_lds_only", 16: "dword_store_epilogue_r02", 32: "kernel_8plus4_waves"}
+                     15: "only_lds", 11: "mfma_and_lds_only", 16: "input_hot_in_l2",
+                     43: "mma_loop_no_b_reads", 75: "mma_loop_no_barriers",
+                     171: "mma_loop_mfma_and_barriers_only", 235: "mma_loop_mfma_only",
+                     172: "loaders_only", 164: "loaders_and_stores_only",
+                     168: "staging_and_mfma_only", 40: "staging_mfma_weights_no_b_reads",
+                     0x10000: "mma_waves_default_priority", 0x20000: "loader_waves_high_priority",
+                     0x40000: "loader_quad_fastest_order_r02", 0: "default_again"}
             for flag, name in names.items():
                 _C.lib().sassd_debug_set_bf16(flag)
                 out["ablate_" + name + "_ms"] = timed(lambda: K.conv2d_bf16_fwd(x, pk, 256), a.iters)

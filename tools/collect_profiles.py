@@ -151,4 +151,35 @@ if stall:
                         "SQ_ACTIVE_INST_ANY = issuing; the three are disjoint and add up to ~SQ_WAVE_CYCLES (quad-cycles); "
                         "SQ_VALU_MFMA_BUSY_CYCLES counts cycles",
                    kernels=stall), open(os.path.join(DST, "%s_stall_breakdown.json" % tag), "w"), indent=1)
+# LDS / clock counters of the bf16 conv (two passes): LDS-array cycles, bank conflicts, GRBM_GUI_ACTIVE (clock), MFMA busy
+lds = {}
+for fname in ("ldsclk_bf16conv_SQ_LDS_BANK_CONFLICT.json", "ldsclk_bf16conv_GRBM_GUI_ACTIVE.json"):
+    path = os.path.join(SRC, fname)
+    if not os.path.exists(path):
+        continue
+    d = json.load(open(path))
+    if "error" in d:
+        continue
+    for k, v in d.items():
+        if "conv2d_bf16_kernel" in k:
+            for c, rec in v.items():
+                lds[c] = rec["mean_per_dispatch"]
+if lds:
+    derived = {}
+    if lds.get("GRBM_GUI_ACTIVE"):
+        cyc = lds["GRBM_GUI_ACTIVE"] / 8.0                     # summed over the 8 XCDs
+        derived["gpu_cycles_per_dispatch"] = cyc
+        if lds.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            derived["mfma_busy_fraction"] = round(lds["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc, 4)   # 1024 SIMDs
+    if lds.get("SQ_LDS_IDX_ACTIVE") and lds.get("SQ_LDS_BANK_CONFLICT") is not None:
+        derived["lds_conflict_fraction_of_lds_cycles"] = round(lds["SQ_LDS_BANK_CONFLICT"] / lds["SQ_LDS_IDX_ACTIVE"], 4)
+        if "gpu_cycles_per_dispatch" in derived:
+            derived["lds_array_busy_fraction"] = round(lds["SQ_LDS_IDX_ACTIVE"] / 256.0 / derived["gpu_cycles_per_dispatch"], 4)
+    json.dump(dict(csrc_hash=CSRC, kernel="conv2d_bf16_kernel<8, 4, 0>",
+                   command="rocprofv3 --kernel-trace --pmc <counters> -- python tools/run_bf16_conv.py --only-fwd --iters 10 "
+                           "(two passes of six counters)",
+                   note="GRBM_GUI_ACTIVE is summed over the 8 XCDs; kernel duration x clock = cycles per dispatch; "
+                        "SQ_VALU_MFMA_BUSY_CYCLES is summed over 1024 SIMDs, SQ_LDS_IDX_ACTIVE over 256 CUs",
+                   per_dispatch=lds, derived=derived),
+              open(os.path.join(DST, "%s_bf16_conv_lds_clock_counters.json" % tag), "w"), indent=1)
 print("profiles written:", sorted(f for f in os.listdir(DST) if f.startswith(tag)))

@@ -25,6 +25,8 @@ pmc bf16conv FETCH_SIZE python $R/tools/run_bf16_conv.py --iters 5
 pmc bf16conv WRITE_SIZE python $R/tools/run_bf16_conv.py --iters 5
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
 pmc stall_bf16conv "$SQ" python $R/tools/run_bf16_conv.py --iters 5
+pmc ldsclk_bf16conv "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" python $R/tools/run_bf16_conv.py --only-fwd --iters 10
+pmc ldsclk_bf16conv "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" python $R/tools/run_bf16_conv.py --only-fwd --iters 10
 pmc stall_sparse_car "$SQ" python $R/tools/run_sparse_only.py --config car --reps 5
 pmc stall_wino4 "$SQ" python $R/tools/run_wino4.py --profile --reps 5
 python tools/collect_profiles.py r03 > $O/collect.log 2>&1; echo "collect rc=$?"

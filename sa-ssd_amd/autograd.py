@@ -346,23 +346,29 @@ class BnRelu2dFn(Function):
         return dx, dg, db, None, None, None, None
 
 
-_pending_nbt = []
+_pending_nbt = {}      # id(counter tensor) -> [tensor, increments not yet applied]
 
 
 def count_bn_batch(bn):
     """`bn.num_batches_tracked += 1`, deferred: the 23 BatchNorm layers of a training step would each launch a one-element
-    add; the counters are collected here and bumped by ONE multi-tensor add per step (flush_bn_counters, called by
-    sassd.train.train_one_iter and before any state_dict / eval of the detector)."""
-    _pending_nbt.append(bn.num_batches_tracked)
-    if len(_pending_nbt) >= 4096:
-        flush_bn_counters()
+    int64 add (torch._foreach_add_ on 0-dim int64 tensors takes the per-tensor path too: 23 launches a step in the round-3
+    profile).  The increments are counted on the host and land in the tensors when somebody can look at them:
+    flush_bn_counters, called before any state_dict / load_state_dict / eval of the detector.  Nothing in a training
+    step reads the counter (every BatchNorm here has a fixed momentum)."""
+    t = bn.num_batches_tracked
+    e = _pending_nbt.get(id(t))
+    if e is None or e[0] is not t:
+        _pending_nbt[id(t)] = [t, 1]
+    else:
+        e[1] += 1
 
 
 def flush_bn_counters():
     if _pending_nbt:
-        ts = list(_pending_nbt)
+        todo = list(_pending_nbt.values())
         _pending_nbt.clear()
-        torch._foreach_add_(ts, 1)
+        for t, n in todo:
+            t += n
 
 
 def bn_relu_2d(bn, x):

@@ -799,6 +799,11 @@ class SingleStageDetector(nn.Module):
         flush_bn_counters()                              # deferred num_batches_tracked increments land first
         return super().state_dict(*args, **kwargs)
 
+    def load_state_dict(self, *args, **kwargs):
+        from .autograd import flush_bn_counters
+        flush_bn_counters()                              # ... and must not be added on top of loaded counters later
+        return super().load_state_dict(*args, **kwargs)
+
     @property
     def with_rpn(self):
         return hasattr(self, 'rpn_head') and self.rpn_head is not None

@@ -456,8 +456,6 @@ def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None):
         sync.reset()
     optimizer.zero_grad()
     loss, terms = parse_losses(model(**batch))
-    from .autograd import flush_bn_counters
-    flush_bn_counters()                              # num_batches_tracked of every BatchNorm: one multi-tensor add
     nxt = prefetch() if prefetch is not None else None
     if hasattr(getattr(model, "rpn_head", None), "poll_guided_capacity"):
         model.rpn_head.poll_guided_capacity()        # non-blocking: reports an overflow a step or two late

@@ -412,24 +412,33 @@ __global__ void __launch_bounds__(256) aux_wgrad_kernel(AuxArgs P)
     wp[kH * kF + j2 * kH + o2] = acc2;
 }
 
+// 8 threads per element, each summing every 8th workgroup's partial (two chains), then a fixed-order sum through LDS: the
+// chain of dependent memory round trips is what this kernel costs (see wgrad_reduce_kernel in spconv.hip)
 __global__ void __launch_bounds__(256) aux_wgrad_reduce_kernel(const float *__restrict__ wpart, int nwg,
                                                                float *__restrict__ dw1, float *__restrict__ dw2)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[8][32];
     constexpr int tot = kH * kF + kOut * kH;
-    if (i >= tot) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                       // four independent chains, fixed order
-    int w = 0;
-    for (; w + 3 < nwg; w += 4) {
-        s0 += wpart[(size_t)w * tot + i];
-        s1 += wpart[(size_t)(w + 1) * tot + i];
-        s2 += wpart[(size_t)(w + 2) * tot + i];
-        s3 += wpart[(size_t)(w + 3) * tot + i];
+    const int e = threadIdx.x & 31, pt = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < tot) {
+        int w = pt;
+        for (; w + 8 < nwg; w += 16) {
+            s0 += wpart[(size_t)w * tot + i];
+            s1 += wpart[(size_t)(w + 8) * tot + i];
+        }
+        if (w < nwg) s0 += wpart[(size_t)w * tot + i];
     }
-    for (; w < nwg; ++w) s0 += wpart[(size_t)w * tot + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (i < kH * kF) dw1[i] = s;
-    else dw2[i - kH * kF] = s;
+    red[pt][e] = s0 + s1;
+    __syncthreads();
+    if (pt == 0 && i < tot) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += red[j][e];
+        if (i < kH * kF) dw1[i] = s;
+        else dw2[i - kH * kF] = s;
+    }
 }
 
 constexpr size_t kWgradLds = (size_t)(kChunk * kFP + 2 * kChunk * kH + kChunk * kOut + kOut * kH) * 4;
@@ -551,7 +560,7 @@ extern "C" int sassd_aux_head_bwd(int N, const float *const *feats, const int *M
     const int nwg = aux_wgrad_wgs(N, &P.chunks_per_wg);
     P.wpart = (float *)workspace;
     hipLaunchKernelGGL(aux_wgrad_kernel, dim3(nwg), dim3(256), kWgradLds, s, P);
-    hipLaunchKernelGGL(aux_wgrad_reduce_kernel, dim3(cdiv(kH * kF + kOut * kH, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(aux_wgrad_reduce_kernel, dim3(cdiv(kH * kF + kOut * kH, 32)), dim3(256), 0, s,
                        (const float *)workspace, nwg, dw1, dw2);
     return sassd_launch_status();
 }

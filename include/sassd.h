@@ -237,7 +237,9 @@ int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *s
  * transposed and the taps mirrored.  Supported: Cout % 32 == 0, W >= 16 and W % 4 == 0 (the last 16-column tile may be partial: the 188-wide Waymo-scale map; else SASSD_EINVAL; the caller keeps the
  * fp32 kernels); Cin is padded to a multiple of 32 with zero weights inside the pack. */
 int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W);
-void sassd_debug_set_bf16(int flags);   /* ablation switches, 0 = off (tools/run_bf16_conv.py) */
+void sassd_debug_set_bf16(int flags);   /* 0 = off.  Low byte: compile-time ablation variant of the bf16 conv; bits 8-15:
+                                           forced workgroup count (tests: long runs of tiles); 0x10000 / 0x20000 / 0x40000:
+                                           wave-priority and loader-order A/B switches (tools/run_bf16_conv.py) */
 size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout);
 int sassd_conv2d_bf16_pack_weight(const float *w, int Cout, int Cin, void *packed, void *stream);
 int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const float *shift, float *y, int batch, int Cin,

@@ -349,12 +349,20 @@ class BnRelu2dFn(Function):
 _pending_nbt = {}      # id(counter tensor) -> [tensor, increments not yet applied]
 
 
+def _nbt_state_dict_hook(module, prefix, keep_vars):      # a module-level function: the layer stays picklable
+    flush_bn_counters()
+
+
 def count_bn_batch(bn):
     """`bn.num_batches_tracked += 1`, deferred: the 23 BatchNorm layers of a training step would each launch a one-element
     int64 add (torch._foreach_add_ on 0-dim int64 tensors takes the per-tensor path too: 23 launches a step in the round-3
     profile).  The increments are counted on the host and land in the tensors when somebody can look at them:
-    flush_bn_counters, called before any state_dict / load_state_dict / eval of the detector.  Nothing in a training
-    step reads the counter (every BatchNorm here has a fixed momentum)."""
+    flush_bn_counters -- a state_dict pre-hook on every counted layer, plus load_state_dict / eval of the detector.  Nothing
+    in a training step reads the counter (every BatchNorm here has a fixed momentum)."""
+    if not getattr(bn, "_sassd_nbt_hook", False):
+        # whoever serialises this layer -- directly or through any parent's state_dict() -- sees the flushed counter
+        bn.register_state_dict_pre_hook(_nbt_state_dict_hook)
+        bn._sassd_nbt_hook = True
     t = bn.num_batches_tracked
     e = _pending_nbt.get(id(t))
     if e is None or e[0] is not t:

@@ -252,3 +252,23 @@ def test_waymo_train_golden_is_complete():
     assert len(G["grad_names"]) == len(G["grad_norms"]) == len(G["grad_projs"]) >= 75
     stored = [k for k in G.files if k.startswith("grad:") or k.startswith("grad8:")]
     assert len(stored) >= 40 and all(np.isfinite(G[k]).all() for k in stored)
+
+
+def test_deferred_bn_batch_counters_land_in_any_state_dict():
+    """count_bn_batch keeps `num_batches_tracked += 1` on the host; every state_dict() that includes the layer -- its own,
+    a parent's -- sees the flushed counter (sassd.autograd.count_bn_batch / flush_bn_counters)."""
+    import torch
+    from sassd import autograd as AG
+    bn_a, bn_b = torch.nn.BatchNorm2d(4), torch.nn.BatchNorm1d(3)
+    parent = torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1), bn_a)
+    for _ in range(3):
+        AG.count_bn_batch(bn_a)
+    AG.count_bn_batch(bn_b)
+    assert int(bn_a.num_batches_tracked) == 0                      # nothing launched yet
+    assert int(parent.state_dict()["1.num_batches_tracked"]) == 3
+    assert int(bn_b.state_dict()["num_batches_tracked"]) == 1
+    AG.count_bn_batch(bn_a)
+    AG.flush_bn_counters()
+    assert int(bn_a.num_batches_tracked) == 4 and int(bn_b.num_batches_tracked) == 1
+    AG.flush_bn_counters()                                          # idempotent
+    assert int(bn_a.num_batches_tracked) == 4

@@ -5,18 +5,19 @@
 // NCHW fp32 activations in and out (BatchNorm / ReLU between the layers stay fp32), operands rounded to bf16
 // (round-to-nearest-even) on their way into LDS / at pack time, fp32 accumulation on v_mfma_f32_32x32x16_bf16.
 //
-// MFMA-bound (83 GFLOP per 256->256 layer at B = 2 against 2.5 PFLOP/s), tiled as an implicit GEMM
+// 83 GFLOP per 256->256 layer at B = 2 against 2.5 PFLOP/s nominal; measured 0.089 ms = 0.37 of that, with the MFMA stream
+// alone at 53 us and the staging side alone at 43 us (DESIGN.md section 8 has the decomposition).  Tiled as an implicit GEMM
 // D[co][pixel] = sum_k W[co][k] X[k][pixel], k = (tap, ci):
-//   * workgroup = 10 rows x 16 columns of one image (160 pixels) x 256 (or 128) couts: 8 (4) MMA waves of 32 couts x
-//     160 pixels (5 accumulator tiles) + 4 loader waves.  The MFMA's 32 pixel columns are 2 image rows x 16 columns:
-//     the lane -> pixel map is free because every lane computes its own LDS address, and 176 = 11 x 16 tiles the
-//     KITTI map with no padding.
-//   * the input tile (12 rows x 24 columns x 32 channels) is staged through LDS as [row][column][channel] bf16 --
+//   * a TILE = up to 10 rows x 16 columns of one image (<= 160 pixels) x 256 (or 128) couts: 8 (4) MMA waves of 32 couts x
+//     the tile's pixels (<= 5 accumulator tiles) + 4 loader waves.  The MFMA's 32 pixel columns are 2 image rows x 16
+//     columns: the lane -> pixel map is free because every lane computes its own LDS address, and 176 = 11 x 16 tiles the
+//     KITTI map with no padding.  Workgroups are persistent (one per CU) and walk a run of tiles each -- see the kernel.
+//   * the input tile (<= 12 rows x 24 columns x 32 channels) is staged through LDS as [row][column][channel] bf16 --
 //     channel-minor, so a lane's B operand (8 consecutive channels of its pixel) is ONE ds_read_b128 and the nine taps
 //     are plain address offsets.  The transposition NCHW -> channel-minor happens in registers: a thread loads 8
 //     channel planes x one aligned pixel quad (16-byte loads, coalesced along the row) and writes four 16-byte channel
-//     vectors.  Pixel pitch 80 B and row pitch 2048 B make the 16 lanes of every ds_read_b128 phase hit 16 different bank quads.  Double
-//     buffered: the loader waves fill the next 32-channel chunk during the 72 MFMAs per wave of the current one.
+//     vectors.  Pixel pitch 80 B and row pitch 2048 B make the 16 lanes of every ds_read_b128 phase hit 16 different bank
+//     quads.  Double buffered: the loader waves fill the next 32-channel chunk during the 18 MFMA steps of the current one.
 //   * weights are packed once per update as bf16 [tap][ci/8][cout][8]: a lane's A operand is one 16-byte global load,
 //     a wave reads 512 contiguous bytes, straight from L2 (1.2 MB per layer, shared by every workgroup) into a
 //     six-deep register ring, five (tap, k-step) groups ahead of the MFMAs that consume them.

@@ -235,3 +235,33 @@ def test_voxel_mean_vs_reference_simplevoxel():
     for case in ("small", "oob", "dense_t3", "t8"):
         G = np.load(os.path.join(here, "voxelizer_%s.npz" % case))
         assert np.array_equal(clib.voxel_mean(G["voxels"], G["num_points"]), R[case]), case
+
+
+def test_submanifold_rulebook_is_its_own_transpose_under_offset_reversal():
+    """For a submanifold layer nbr[j][k] = i  <=>  nbr[i][26 - k] = j (offset k and 26 - k are opposite), so the data
+    gradient is the forward operator on the SAME rulebook with the offset-reversed, transposed weights:
+    dx[i] = sum_k dy[nbr[i][k]] @ W[26 - k]^T.  (lead 1: no transposed rulebook for those layers.)"""
+    import numpy as np
+    import torch
+    from oracle import nets, rulebook
+    rng = np.random.default_rng(5)
+    shape = (6, 9, 8)
+    idx = np.stack([rng.integers(0, 2, 90), rng.integers(0, shape[0], 90), rng.integers(0, shape[1], 90),
+                    rng.integers(0, shape[2], 90)], 1).astype(np.int32)
+    idx = np.unique(idx, axis=0)
+    idx, nbr = rulebook.subm_rulebook(idx, shape)
+    n = idx.shape[0]
+    for j in range(n):
+        for k in range(27):
+            i = nbr[j, k]
+            if i >= 0:
+                assert nbr[i, 26 - k] == j
+    assert (nbr[:, 13] == np.arange(n)).all()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, 8, generator=g, requires_grad=True)
+    w = torch.randn(27, 8, 5, generator=g)
+    dy = torch.randn(n, 5, generator=g)
+    nb = torch.from_numpy(nbr.astype(np.int64))
+    nets.sparse_conv(x, nb, w).backward(dy)
+    dx = nets.sparse_conv(dy, nb, w.flip(0).transpose(1, 2).contiguous())
+    assert torch.allclose(dx, x.grad, rtol=1e-5, atol=1e-5)

@@ -12,6 +12,8 @@
 // Roofline: HBM/L2 bound (<= 16 FLOP/B); algorithmic bytes B_gs = 4P(Cin+Cout) + 8P + 4K*Cin*Cout + 4*Nout*Cout.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -41,22 +43,23 @@ __device__ __forceinline__ void load_vec(const float *__restrict__ p, float (&v)
     }
 }
 
-// w [K][CIN][COUT] -> packed [K][NT][64 lanes][KS]:  lane (q = l>>4, m = l&15) holds W[k][q*KS + kk][nt*16 + m]
+// w [K][CIN][COUT] -> packed [K][CIN/4][COUT][4]: element (k, ci, co) at ((k*CIN/4 + ci/4)*COUT + co)*4 + ci%4 -- four
+// consecutive input channels of one output channel are one 16-byte piece, pieces of neighbouring output channels are
+// contiguous, so every kernel of this file (16x16x4 fragments: lane (q, m) reads W[q*KS + kk][nt*16 + m]; 4x4x1 rows:
+// lane l reads W[ci][l]) fetches its operand registers with coalesced 16-byte loads from ONE image.
 // transposed = 1: `w` is the FORWARD weight [K][COUT][CIN] of a Cout->Cin layer and the packed image is W[k]^T, i.e.
 // the weights of the data-gradient conv (CIN x COUT here are the gradient conv's own in/out widths).
 template <int CIN, int COUT>
 __global__ void pack_weight_kernel(const float *__restrict__ w, int K, float *__restrict__ packed, int transposed)
 {
-    using S = SpShape<CIN, COUT>;
-    const int total = K * S::NT * 64 * S::KS;
+    const int total = K * CIN * COUT;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int kk = i % S::KS;
-    const int lane = (i / S::KS) % 64;
-    const int nt = (i / (S::KS * 64)) % S::NT;
-    const int k = i / (S::KS * 64 * S::NT);
-    const int q = lane >> 4, m = lane & 15;
-    const int ci = q * S::KS + kk, co = nt * 16 + m;
+    const int r = i & 3;
+    const int co = (i >> 2) % COUT;
+    const int c4 = (i / (4 * COUT)) % (CIN / 4);
+    const int k = i / (CIN * COUT);
+    const int ci = c4 * 4 + r;
     packed[i] = transposed ? w[((size_t)k * COUT + co) * CIN + ci] : w[((size_t)k * CIN + ci) * COUT + co];
 }
 
@@ -144,7 +147,7 @@ spconv_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, 
                     const int tnt = r / J, jj = r - tnt * J;
                     const int k = j * S + so;
                     if (k < KK) {
-                        const float *src = wp + (((size_t)k * NT + tnt) * 64 + lane) * KS + 4 * jj;
+                        const float *src = wp + (((size_t)k * (CIN / 4) + (lane >> 4) * J + jj) * COUT + tnt * 16 + (lane & 15)) * 4;
                         __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(buf + t * 256), 16, 0, 0);
                     }
                 }
@@ -163,7 +166,8 @@ spconv_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, 
                     bf[4 * jj] = v.x; bf[4 * jj + 1] = v.y; bf[4 * jj + 2] = v.z; bf[4 * jj + 3] = v.w;
                 }
             } else {
-                load_vec<KS>(wp + (((size_t)k * NT + t) * 64 + lane) * KS, bf);
+                static_assert(BLDS || KS == 1, "plain weight loads serve the 4-channel input layer only");
+                bf[0] = wp[((size_t)k * COUT + t * 16 + m16) * 4 + q];
             }
 #pragma unroll
             for (int kk = 0; kk < KS; kk += 2) {
@@ -240,8 +244,7 @@ int launch_fwd(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap
 template <int CIN, int COUT>
 int launch_pack(const float *w, int K, float *packed, int transposed, hipStream_t stream)
 {
-    using S = SpShape<CIN, COUT>;
-    const int total = K * S::NT * 64 * S::KS;
+    const int total = K * CIN * COUT;
     hipLaunchKernelGGL((pack_weight_kernel<CIN, COUT>), dim3(cdiv(total, 256)), dim3(256), 0, stream, w, K, packed,
                        transposed);
     return sassd_launch_status();
@@ -331,9 +334,14 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
     float b0[NTW][KS], b1[NTW][KS];
     float a0[KS], a1[KS];
     auto load_w = [&](int k, float (&b)[NTW][KS]) {             // fragment order, 16-B pieces, coalesced
-        if (dbg & 8) return;
 #pragma unroll
-        for (int u = 0; u < NTW; ++u) load_vec<KS>(wp + (((size_t)k * NT + half * NTW + u) * 64 + lane) * KS, b[u]);
+        for (int u = 0; u < NTW; ++u)
+#pragma unroll
+            for (int k4 = 0; k4 < KS / 4; ++k4) {
+                const float4 v = *(const float4 *)(wp + (((size_t)k * (CIN / 4) + q * (KS / 4) + k4) * COUT +
+                                                         (half * NTW + u) * 16 + m16) * 4);
+                b[u][4 * k4] = v.x; b[u][4 * k4 + 1] = v.y; b[u][4 * k4 + 2] = v.z; b[u][4 * k4 + 3] = v.w;
+            }
     };
     // every wave starts on a fixed offset (the heaviest ones), so its weights are requested at kernel entry as well
     constexpr int WPH = NW / CS;                             // waves per channel group
@@ -382,7 +390,7 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
     // of D^T, which is never written back, so no zero fill is needed
     auto fetch_a = [&](int t, float (&af)[KS]) {
         const int in = lin[t * 16 + m16];
-        if (!(dbg & 1)) load_vec<KS>(x + (size_t)in * CIN + q * KS, af);
+        load_vec<KS>(x + (size_t)in * CIN + q * KS, af);
     };
     // one tile of 16 pairs: D^T[cout = u*16 + q*4 + r][pair = m16] += W[k]^T X^T, accumulated in the pair's slab row
     auto tile = [&](int t, int nk, const float (&af)[KS], const float (&b)[NTW][KS]) {
@@ -424,12 +432,15 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
         const int ntile = (nk + 15) >> 4;
         if (lane < ntile * 16 - nk) { lin[nk + lane] = 0; lout[nk + lane] = 0; }      // pad the last tile
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own list writes precede its list reads
+        // (round 4) the look-ahead gathers are unconditional -- past the end the last tile is requested again: under a
+        // branch the number of loads in flight is path-dependent and the compiler then drains vmcnt(0), i.e. waits for
+        // the gather it has just issued, in front of every tile
         fetch_a(0, a0);
         for (int t = 0; t < ntile; t += 2) {
-            if (t + 1 < ntile) fetch_a(t + 1, a1);
+            fetch_a(min(t + 1, ntile - 1), a1);
             tile(t, nk, a0, b);
             if (t + 1 < ntile) {
-                if (t + 2 < ntile) fetch_a(t + 2, a0);
+                fetch_a(min(t + 2, ntile - 1), a0);
                 tile(t + 1, nk, a1, b);
             }
         }
@@ -447,12 +458,12 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
     }
     while (k >= 0) {
         int kn = grab();
-        if (kn >= 0) load_w(kn, b1);
+        load_w(kn >= 0 ? kn : k, b1);
         process(k, b0);
         k = kn;
         if (k < 0) break;
         kn = grab();
-        if (kn >= 0) load_w(kn, b0);
+        load_w(kn >= 0 ? kn : k, b0);
         process(k, b1);
         k = kn;
     }
@@ -478,7 +489,9 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
     }
 }
 
-int g_spconv_cfg = 0;           // 0 = default geometry; 1..3 alternatives (tools/, tests)
+#include "spconv_gq.h"
+
+int g_spconv_cfg = 0;           // 0 = default; 1..5, 10 geometries of spconv_gs_kernel, 6..9 of spconv_gq_kernel (tools/, tests)
 
 template <int CIN, int COUT, int RW, int NW, int CS, int WPS>
 int launch_gs_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp,
@@ -513,10 +526,21 @@ int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap,
         if (g_spconv_cfg == 4) return launch_gs_cfg<CIN, COUT, 64, 16, 2, 4>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     }
     if (g_spconv_cfg == 5) return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    // default: KITTI-scale single frames (capacity <= 64 k rows) one 8-wave workgroup per CU, larger batches / frames
-    // two 4-wave workgroups per CU (measured: 316 vs 330 us at B=1, 1385 vs 1500 us at multi_cfg B=8)
-    if (cap > 65536) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    // balanced kernel (spconv_gq.h): 6 / 9 = 16x16x4 tiles on 8 / 4 waves, 7 / 8 = 4x4x1 quads on 8 / 4 waves (16-channel
+    // outputs have no quad form and take the 16x16x4 tile)
+    constexpr int Q = (COUT >= 32) ? 1 : 0;
+    if (g_spconv_cfg == 6) return launch_gq_cfg<CIN, COUT, 8, 2, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 9) return launch_gq_cfg<CIN, COUT, 4, 2, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 7) return launch_gq_cfg<CIN, COUT, 8, 2, Q>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 8) return launch_gq_cfg<CIN, COUT, 4, 2, Q>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 10) {
+        // round-3 default: KITTI-scale single frames (capacity <= 64 k rows) one 8-wave workgroup per CU, larger batches /
+        // frames two 4-wave workgroups per CU (measured: 316 vs 330 us at B=1, 1385 vs 1500 us at multi_cfg B=8)
+        if (cap > 65536) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+        return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    }
+    if (cap > 65536) return launch_gq_cfg<CIN, COUT, 4, 2, Q>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    return launch_gq_cfg<CIN, COUT, 8, 2, Q>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
 }
 
 // forward / data-gradient dispatch: gather-GEMM-scatter for 27-offset layers with Cin >= 16, the register-stationary

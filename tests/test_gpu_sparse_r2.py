@@ -77,13 +77,15 @@ def test_rulebook_pyramid_overflow_flag(dev):
     assert int(st.item()) & 1 and int(n[1].item()) == caps[1]
 
 
-@pytest.mark.parametrize("mode", ["default", "rw64x4", "rw128", "split2", "split2x16", "rw64x8", "legacy"])
+@pytest.mark.parametrize("mode", ["default", "rw64x4", "rw128", "split2", "split2x16", "rw64x8", "legacy",
+                                  "gq16", "gq16x4", "gq4", "gq4x4", "r3"])
 @pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (32, 16), (64, 32)])
 def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
     """subm and strided gather tables, ragged row counts (not multiples of the slice), every forward / data-gradient
     shape, against the CPU oracle; bar 2e-4 * max|y| (fp32 sums in a different order)."""
     flags = {"default": 0, "rw64x4": 1 << 16, "rw128": 2 << 16, "split2": 3 << 16, "split2x16": 4 << 16,
-             "rw64x8": 5 << 16, "legacy": 256}[mode]
+             "rw64x8": 5 << 16, "legacy": 256, "gq16": 6 << 16, "gq16x4": 9 << 16, "gq4": 7 << 16, "gq4x4": 8 << 16,
+             "r3": 10 << 16}[mode]
     if mode.startswith("split2") and cout != 64:
         pytest.skip("the channel split exists for 64-channel layers")
     if mode == "legacy" and (cin, cout) in ((32, 16), (64, 32)):
@@ -119,6 +121,39 @@ def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
             assert (y2[:n].cpu() - raw).abs().max().item() < tol
     finally:
         K.debug_set_spconv(0)
+
+
+@pytest.mark.parametrize("mode", [0, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 32), (16, 32)])
+def test_spconv_balanced_kernel_many_blocks(dev, cin, cout, mode):
+    """The balanced kernel's row -> (block, interleaved slice) map past 16384 rows (more than 8 blocks), on a batch of
+    two K21 frames at level 1 (36 k rows) with the device row count below the capacity; every geometry switch."""
+    idx = _level0("k21", 0, 2)
+    idx1, _, shape1 = orb.conv_rulebook(idx, (40, 1600, 1408), 2)
+    _, nbr = orb.subm_rulebook(idx1, shape1)
+    n = len(nbr)
+    assert n > 32768
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(27, cin, cout, generator=g) * 0.2
+    raw = onets.sparse_conv(x, nbr, w)
+    cap = n + 5000
+    nb = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+    nb[:n] = torch.from_numpy(nbr).to(dev)
+    nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+    wp = K.spconv_pack_weight(w.to(dev))
+    K.debug_set_spconv(mode << 16)
+    try:
+        y = torch.full((cap, cout), 7.0, device=dev)
+        K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout, None, None, False, y)
+        y2 = y.clone()
+        K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout, None, None, False, y2)
+    finally:
+        K.debug_set_spconv(0)
+    tol = 2e-4 * max(1.0, raw.abs().max().item())
+    assert (y[:n].cpu() - raw).abs().max().item() < tol
+    assert bool((y[n:] == 7.0).all())
+    assert torch.equal(y, y2)
 
 
 def test_spconv_empty_and_tiny(dev):

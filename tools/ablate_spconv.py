@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-layer timing + ablation of the sparse path on a synthetic frame batch (debug switches of spconv.hip):
-bit0 no gather loads, bit1 no slab accumulate, bit2 no MFMA, bit3 no weight loads, bit4 ticket (dynamic) offset assignment,
-bit8 legacy register-stationary kernel, bits 16+ workgroup geometry.  Also times the rulebook build (fused pyramid vs the per-op chain).
+bit1 no slab accumulate, bit2 no MFMA, bit4 ticket (dynamic) offset assignment (round-3 kernel only),
+bit8 legacy register-stationary kernel, bits 16+ kernel / workgroup geometry.  Also times the rulebook build (fused pyramid vs the per-op chain).
 
   python tools/ablate_spconv.py [--config car|multi|waymo] [--batch B] [--ablate]
 """
@@ -56,7 +56,10 @@ plan = plans[True]
 work = plan.sparse_work()
 print("pairs", work["pairs"], "bytes_gs %.1f MB" % (work["bytes_gs"] / 1e6))
 
-MODES = [("legacy", 256), ("gs 64x8", 5 << 16), ("gs 64x4", 1 << 16), ("default", 0), ("default+tickets", 16)]
+# round 4: the balanced kernel (spconv_gq.h) next to the round-3 kernel; the gather / weight-load ablation bits are gone
+# (a load under a branch makes the compiler drain vmcnt(0) in front of every tile -- the very thing being measured)
+MODES = [("r3", 10 << 16), ("gq16x8w", 6 << 16), ("gq4x8w", 7 << 16), ("gq4x4w", 8 << 16), ("gq16x4w", 9 << 16),
+         ("default", 0)]
 layers = []
 lvl = 0
 for kind, cin, cout, key, wp, scale, shift in plan.sp:
@@ -80,9 +83,9 @@ for kind, cin, cout, key, wp, scale, shift, lvl in layers:
     print(line)
     if args.ablate and (kind, key, cin) not in seen and cin >= 16 and key:
         seen.add((kind, key, cin))
-        for mname, base in MODES[1:]:
+        for mname, base in MODES[:1]:
             s = "        ablation %-8s" % mname
-            for bit, nm in ((1, "no-gather"), (2, "no-slab"), (4, "no-mfma"), (8, "no-wload"), (15, "none-of-them")):
+            for bit, nm in ((2, "no-slab"), (4, "no-mfma"), (6, "neither")):
                 K.debug_set_spconv(base | bit)
                 s += "  %s %6.1f" % (nm, timeit(lambda: K.spconv_fwd(x, nbr, plan.n[lvl], plan.caps[lvl], wp, k, cin,
                                                                       cout, scale, shift, True, y)))

@@ -529,18 +529,23 @@ int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap,
     // balanced kernel (spconv_gq.h): 6 / 9 = 16x16x4 tiles on 8 / 4 waves, 7 / 8 = 4x4x1 quads on 8 / 4 waves (16-channel
     // outputs have no quad form and take the 16x16x4 tile)
     constexpr int Q = (COUT >= 32) ? 1 : 0;
-    if (g_spconv_cfg == 6) return launch_gq_cfg<CIN, COUT, 8, 2, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 9) return launch_gq_cfg<CIN, COUT, 4, 2, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 7) return launch_gq_cfg<CIN, COUT, 8, 2, Q>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 8) return launch_gq_cfg<CIN, COUT, 4, 2, Q>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 6) return launch_gq_cfg<CIN, COUT, 8, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 9) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 7) return launch_gq_cfg<CIN, COUT, 8, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 8) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    // 11..14: the same four on consecutive 64-row slices
+    if (g_spconv_cfg == 11) return launch_gq_cfg<CIN, COUT, 8, 2, 0, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 14) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 12) return launch_gq_cfg<CIN, COUT, 8, 2, Q, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 13) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     if (g_spconv_cfg == 10) {
         // round-3 default: KITTI-scale single frames (capacity <= 64 k rows) one 8-wave workgroup per CU, larger batches /
         // frames two 4-wave workgroups per CU (measured: 316 vs 330 us at B=1, 1385 vs 1500 us at multi_cfg B=8)
         if (cap > 65536) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
         return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     }
-    if (cap > 65536) return launch_gq_cfg<CIN, COUT, 4, 2, Q>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    return launch_gq_cfg<CIN, COUT, 8, 2, Q>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (cap > 65536) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    return launch_gq_cfg<CIN, COUT, 8, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
 }
 
 // forward / data-gradient dispatch: gather-GEMM-scatter for 27-offset layers with Cin >= 16, the register-stationary

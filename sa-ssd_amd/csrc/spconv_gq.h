@@ -36,9 +36,13 @@
 template <int COUT, int NW>
 constexpr size_t gq_lds_bytes() { return (size_t)(NW * 64 * COUT + 64 * kK + kK * 64 + 32) * 4; }
 
-static inline int gq_grid(int cap) { return 256 * (cap <= 16384 ? 1 : cdiv(cap, 16384)); }
+static inline int gq_grid(int cap, int ilv) { return ilv ? 256 * (cap <= 16384 ? 1 : cdiv(cap, 16384)) : 64 * cdiv(cdiv(cap, 64), 64); }
 
-template <int CIN, int COUT, int NW, int WPS, int QUAD>
+// ILV = 1: interleaved slices of XCD-local blocks (change B above; KITTI-scale single frames, where a layer is ONE round of
+// workgroups and lasts as long as its heaviest one).  ILV = 0: 64 consecutive rows per workgroup in the XCD-aware order
+// of spconv_gs_kernel -- many rounds of workgroups per CU balance themselves, and consecutive rows share their gathered
+// neighbours in the CU's vector cache.
+template <int CIN, int COUT, int NW, int WPS, int QUAD, int ILV>
 __global__ void __launch_bounds__(NW * 64, WPS)
 spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_ptr,
                  int cap, const float *__restrict__ wp, const float *__restrict__ scale,
@@ -64,21 +68,30 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- workgroup -> (block, interleaved slice) -------------------------------------------------------------------
+    constexpr int RS = ILV ? 32 : 1;                         // row stride of a slice: local row r <-> row0 + RS * r
     const int xcd = (int)(blockIdx.x & 7), t_ = (int)(blockIdx.x >> 3);
-    const int sl = t_ & 31, j8 = t_ >> 5;
     for (int i = tid; i < NW * RW * COUT / 4; i += T) ((float4 *)slabs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int n = min(*n_ptr, cap);
-    const int nb8 = n <= 16384 ? 1 : (n + 16383) / 16384;
-    if (j8 >= nb8) return;                                   // workgroup-uniform
-    const int bs = (n + 8 * nb8 - 1) / (8 * nb8);            // rows per block, <= 2048
-    const int base = (j8 * 8 + xcd) * bs;
-    const int brows = min(bs, n - base);
-    if (brows <= sl) return;
-    const int rows = (brows - sl + 31) >> 5;                 // <= 64; local row r <-> row base + sl + 32 r
-    const int row0 = base + sl;
+    int rows, row0;
+    if constexpr (ILV) {
+        const int sl = t_ & 31, j8 = t_ >> 5;
+        const int nb8 = n <= 16384 ? 1 : (n + 16383) / 16384;
+        if (j8 >= nb8) return;                               // workgroup-uniform
+        const int bs = (n + 8 * nb8 - 1) / (8 * nb8);        // rows per block, <= 2048
+        const int base = (j8 * 8 + xcd) * bs;
+        const int brows = min(bs, n - base);
+        if (brows <= sl) return;
+        rows = (brows - sl + 31) >> 5;                       // <= 64
+        row0 = base + sl;
+    } else {
+        const int slice = (((t_ >> 3) << 3) + xcd) * 8 + (t_ & 7);   // runs of 8 consecutive slices on one XCD
+        row0 = slice * RW;
+        if (row0 >= n) return;
+        rows = min(RW, n - row0);
+    }
     for (int i = tid; i < RW * kK; i += T) {
         const int r = i / kK, kk = i - r * kK;
-        nbr_s[i] = (r < rows) ? nbr[(size_t)(row0 + 32 * r) * kK + kk] : -1;
+        nbr_s[i] = (r < rows) ? nbr[(size_t)(row0 + RS * r) * kK + kk] : -1;
     }
     __syncthreads();
     // ---- cooperative compaction of the 27 offsets ---------------------------------------------------------------
@@ -298,11 +311,11 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
         const float4 sh = shift ? *(const float4 *)(shift + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *(float4 *)(y + (size_t)(row0 + 32 * r) * COUT + c4 * 4) = v;
+        *(float4 *)(y + (size_t)(row0 + RS * r) * COUT + c4 * 4) = v;
     }
 }
 
-template <int CIN, int COUT, int NW, int WPS, int QUAD>
+template <int CIN, int COUT, int NW, int WPS, int QUAD, int ILV>
 int launch_gq_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp,
                   const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
 {
@@ -310,10 +323,10 @@ int launch_gq_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int 
     static_assert(lds <= 160 * 1024, "workgroup slabs exceed the 160 KB LDS");
     if (cap >= (1 << 25)) return SASSD_EINVAL;               // packed list entries: input row << 6 | local row
     static std::atomic<unsigned long long> attr_done{0};
-    const void *fn = (const void *)spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD>;
+    const void *fn = (const void *)spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD, ILV>;
     int rc = sassd_dyn_lds(fn, lds, attr_done);
     if (rc) return rc;
-    hipLaunchKernelGGL((spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD>), dim3(gq_grid(cap)), dim3(NW * 64), lds, stream, x,
+    hipLaunchKernelGGL((spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD, ILV>), dim3(gq_grid(cap, ILV)), dim3(NW * 64), lds, stream, x,
                        nbr, n_ptr, cap, wp, scale, shift, relu, y);
     return sassd_launch_status();
 }

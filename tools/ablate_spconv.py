@@ -59,6 +59,7 @@ print("pairs", work["pairs"], "bytes_gs %.1f MB" % (work["bytes_gs"] / 1e6))
 # round 4: the balanced kernel (spconv_gq.h) next to the round-3 kernel; the gather / weight-load ablation bits are gone
 # (a load under a branch makes the compiler drain vmcnt(0) in front of every tile -- the very thing being measured)
 MODES = [("r3", 10 << 16), ("gq16x8w", 6 << 16), ("gq4x8w", 7 << 16), ("gq4x4w", 8 << 16), ("gq16x4w", 9 << 16),
+         ("c16x8w", 11 << 16), ("c4x8w", 12 << 16), ("c4x4w", 13 << 16), ("c16x4w", 14 << 16), ("rw128", 2 << 16),
          ("default", 0)]
 layers = []
 lvl = 0

@@ -68,8 +68,16 @@ void rate(int threads, const char *name)
     float *out; long long *cyc;
     hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&cyc, 8 * 1024);
     const int iters = 2000, blocks = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL((rate_kernel<CHAINS, KIND>), dim3(blocks), dim3(threads), 0, 0, out, cyc, iters);
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL((rate_kernel<CHAINS, KIND>), dim3(blocks), dim3(threads), 0, 0, out, cyc, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)blocks * (threads / 64) * iters * 16.0 * (KIND == 0 ? 512.0 : 2048.0);
     std::vector<long long> h(blocks);
     hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
     double m = 0;
@@ -77,8 +85,8 @@ void rate(int threads, const char *name)
     m /= blocks;
     // __builtin_readcyclecounter = s_memtime: shader-clock ticks (guide); MFMAs per SIMD = waves per SIMD * iters * 16
     const double wps = threads / 256.0 < 1 ? 1 : threads / 256.0;
-    printf("%-34s threads %4d: %.1f ticks per MFMA per wave, %.1f per MFMA per SIMD\n", name, threads,
-           m / (iters * 16.0), m / (iters * 16.0 * wps));
+    printf("%-34s threads %4d: %.1f ticks per MFMA per wave, %.1f per MFMA per SIMD; wall %.3f ms = %.1f TFLOP/s\n", name,
+           threads, m / (iters * 16.0), m / (iters * 16.0 * wps), ms, flop / ms * 1e-9);
     hipFree(out); hipFree(cyc);
 }
 

@@ -17,8 +17,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="multi")
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--spconv-cfg", type=int, default=0, help="kernel / workgroup geometry switch of the sparse conv (spconv.hip)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
+K.debug_set_spconv(args.spconv_cfg << 16)
 w = synth.workload(args.config)
 B = args.batch or w["batch"]
 model, _ = synth.build_detector_for(w, 0)

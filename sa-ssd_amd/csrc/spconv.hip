@@ -538,24 +538,33 @@ int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap,
     if (g_spconv_cfg == 14) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     if (g_spconv_cfg == 12) return launch_gq_cfg<CIN, COUT, 8, 2, Q, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     if (g_spconv_cfg == 13) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 10) {
-        // round-3 default: KITTI-scale single frames (capacity <= 64 k rows) one 8-wave workgroup per CU, larger batches /
-        // frames two 4-wave workgroups per CU (measured: 316 vs 330 us at B=1, 1385 vs 1500 us at multi_cfg B=8)
-        if (cap > 65536) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-        return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    // default (round 4, measured per layer shape; profiles/r04_spconv_layers_*.txt).  The balanced kernel pays for its
+    // cooperative compaction and pays off where a layer is long enough to be bound by its heaviest workgroup: the
+    // 64 -> 64 layers.  KITTI-scale frames (one round of workgroups): 16x16x4 tiles on 4 waves, interleaved slices --
+    // 22 / 31 us instead of 33 / 37 us for the 14.6 k / 13.3 k-row submanifold layers.  Batches of frames: 4x4x1 quads
+    // (strided layers 91 instead of 111 us at 106 k rows).  Waymo-scale levels (13-17 pairs per row: 16-pair tiles are
+    // full) and every narrower layer stay on the round-3 geometry.
+    if constexpr (CIN == 64 && COUT == 64) {
+        if (g_spconv_cfg != 10) {
+            if (cap <= 100000) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+            if (cap <= 400000) return launch_gq_cfg<CIN, COUT, 4, 2, 1, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+        }
     }
-    if (cap > 65536) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    return launch_gq_cfg<CIN, COUT, 8, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    // round-3 geometry (cfg 10 forces it everywhere): KITTI-scale single frames (capacity <= 64 k rows) one 8-wave
+    // workgroup per CU, larger batches / frames two 4-wave workgroups per CU
+    if (cap > 65536) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
 }
 
-// forward / data-gradient dispatch: gather-GEMM-scatter for 27-offset layers with Cin >= 16, the register-stationary
-// kernel for the 4-channel input layer, the 1x1x1 layer and when the legacy switch (debug bit 8) is set
+// forward / data-gradient dispatch: gather-GEMM-scatter for 27-offset layers with Cin >= 16, the streaming kernel for the
+// 1x1x1 layer, the register-stationary kernel for the 4-channel input layer and when the legacy switch (debug bit 8) is set
 template <int CIN, int COUT>
 int launch_conv(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp, int K,
                 const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
 {
     if constexpr (CIN >= 16) {
         if (nbr && !(g_spconv_dbg & 256)) return launch_gs<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, stream);
+        if (!nbr && !(g_spconv_dbg & 256)) return launch_pw<CIN, COUT>(x, n_ptr, cap, wp, scale, shift, relu, y, stream);
     }
     return launch_fwd<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, stream);
 }

@@ -46,7 +46,7 @@ template <int CIN, int COUT, int NW, int WPS, int QUAD, int ILV>
 __global__ void __launch_bounds__(NW * 64, WPS)
 spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_ptr,
                  int cap, const float *__restrict__ wp, const float *__restrict__ scale,
-                 const float *__restrict__ shift, int relu, float *__restrict__ y)
+                 const float *__restrict__ shift, int relu, float *__restrict__ y, int dbg)
 {
     static_assert(!QUAD || COUT == 64 || COUT == 32, "the 4x4x1 path covers 32 / 64 output channels");
     constexpr int RW = 64, T = NW * 64;
@@ -70,7 +70,6 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
     // ---- workgroup -> (block, interleaved slice) -------------------------------------------------------------------
     constexpr int RS = ILV ? 32 : 1;                         // row stride of a slice: local row r <-> row0 + RS * r
     const int xcd = (int)(blockIdx.x & 7), t_ = (int)(blockIdx.x >> 3);
-    for (int i = tid; i < NW * RW * COUT / 4; i += T) ((float4 *)slabs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int n = min(*n_ptr, cap);
     int rows, row0;
     if constexpr (ILV) {
@@ -89,9 +88,20 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
         if (row0 >= n) return;
         rows = min(RW, n - row0);
     }
-    for (int i = tid; i < RW * kK; i += T) {
+    // the slice's rulebook rows are requested first; the slabs are cleared while they are on their way
+    constexpr int NST = (RW * kK + T - 1) / T;
+    int stage[NST];
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int i = tid + j * T;
         const int r = i / kK, kk = i - r * kK;
-        nbr_s[i] = (r < rows) ? nbr[(size_t)(row0 + RS * r) * kK + kk] : -1;
+        stage[j] = (r < rows) ? nbr[(size_t)(row0 + RS * r) * kK + kk] : -1;
+    }
+    for (int i = tid; i < NW * RW * COUT / 4; i += T) ((float4 *)slabs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int i = tid + j * T;
+        if (i < RW * kK) nbr_s[i] = stage[j];
     }
     __syncthreads();
     // ---- cooperative compaction of the 27 offsets ---------------------------------------------------------------
@@ -148,11 +158,13 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
         return __builtin_amdgcn_readlane(k_l, __builtin_ctzll(m));
     };
     auto fetch_a = [&](const Tile &tl, float (&af)[KSEG]) {
-        const int e = lists[tl.k * RW + tl.pb + (pl < tl.np ? pl : 0)];
+        int e = lists[tl.k * RW + tl.pb + (pl < tl.np ? pl : 0)];
+        if (dbg & 32) e &= 63;                               // ablation: every gather reads row 0 (same loads, cache hits)
         load_vec<KSEG>(x + (size_t)(e >> 6) * CIN + G_l * KSEG, af);
     };
     constexpr int NB = QUAD ? CIN : NTW * KSEG;              // weight registers of one offset
     auto load_w = [&](int k, float (&b)[NB]) {
+        if (dbg & 64) k = 0;                                 // ablation: one weight image for every offset
         const float *wk = wp + (size_t)k * CIN * COUT;
         if constexpr (QUAD) {                                // b[c] = W[k][c][cl]
 #pragma unroll
@@ -193,7 +205,7 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
                             c0[i] = *rowp[i];
                         }
                         f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;
-                        {
+                        if (!(dbg & 4)) {                               // ablation: no MFMAs
 #pragma unroll
                             for (int kk = 0; kk < KSEG; ++kk) {
                                 d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(af[kk], b[0 * KSEG + kk], d0, CBSZ, 0 * NS + s, 0);
@@ -228,7 +240,7 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
                 const float4 c = *(const float4 *)(row + (((u * 4 + q) ^ sw) << 2));
                 d[u] = (f32x4){c.x, c.y, c.z, c.w};
             }
-            {
+            if (!(dbg & 4)) {
 #pragma unroll
                 for (int kk = 0; kk < KSEG; ++kk)
 #pragma unroll
@@ -327,6 +339,87 @@ int launch_gq_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int 
     int rc = sassd_dyn_lds(fn, lds, attr_done);
     if (rc) return rc;
     hipLaunchKernelGGL((spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD, ILV>), dim3(gq_grid(cap, ILV)), dim3(NW * 64), lds, stream, x,
-                       nbr, n_ptr, cap, wp, scale, shift, relu, y);
+                       nbr, n_ptr, cap, wp, scale, shift, relu, y, g_spconv_dbg & 127);
+    return sassd_launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1 x 1 x 1 sparse conv (spconv's `SparseConv3d(64, 64, (1,1,1))` shortcut = a dense [rows, CIN] x [CIN, COUT] product,
+// cmn.py:208-212 `extra_conv`; the same shape is the data gradient of that layer).  The register-stationary kernel ran it
+// through its 27-offset machinery (41 us at 106 k rows = 1.3 TB/s); this is a streaming kernel: a wave keeps W (pack
+// [CIN/4][COUT][4]) in registers and walks 16-row tiles with the transposed 16x16x4 MFMA -- a lane ends up with four
+// consecutive output channels of one row, i.e. 16-byte stores -- with the next tile's rows in flight (unconditionally:
+// past the end the last tile is requested again).  HBM-bound: 8 * rows * 64 bytes.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256)
+spconv_pw_kernel(const float *__restrict__ x, const int32_t *__restrict__ n_ptr, int cap, const float *__restrict__ wp,
+                 const float *__restrict__ scale, const float *__restrict__ shift, int relu, float *__restrict__ y)
+{
+    constexpr int KSEG = CIN / 4, NTW = COUT / 16;
+    const int n = min(*n_ptr, cap);
+    const int lane = threadIdx.x & 63, q = lane >> 4, m16 = lane & 15;
+    const int wave = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = (int)gridDim.x * 4;
+    const int ntile = (n + 15) >> 4;
+    if (wave >= ntile) return;
+    float b[NTW * KSEG];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u)
+#pragma unroll
+        for (int k4 = 0; k4 < KSEG / 4; ++k4) {
+            const float4 v = *(const float4 *)(wp + ((size_t)(q * (KSEG / 4) + k4) * COUT + u * 16 + m16) * 4);
+            b[u * KSEG + 4 * k4] = v.x; b[u * KSEG + 4 * k4 + 1] = v.y; b[u * KSEG + 4 * k4 + 2] = v.z; b[u * KSEG + 4 * k4 + 3] = v.w;
+        }
+    float4 sc[NTW], sh[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        sc[u] = scale ? *(const float4 *)(scale + u * 16 + q * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[u] = shift ? *(const float4 *)(shift + u * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto fetch = [&](int t, float (&af)[KSEG]) {
+        const int r = min(t * 16 + m16, n - 1);
+        load_vec<KSEG>(x + (size_t)r * CIN + q * KSEG, af);
+    };
+    auto tile = [&](int t, const float (&af)[KSEG]) {
+        f32x4 d[NTW];
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) d[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KSEG; ++kk)
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u * KSEG + kk], af[kk], d[u], 0, 0, 0);
+        const int r = t * 16 + m16;
+        if (r < n) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                float4 v = make_float4(d[u][0] * sc[u].x + sh[u].x, d[u][1] * sc[u].y + sh[u].y, d[u][2] * sc[u].z + sh[u].z,
+                                       d[u][3] * sc[u].w + sh[u].w);
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *(float4 *)(y + (size_t)r * COUT + u * 16 + q * 4) = v;
+            }
+        }
+    };
+    float a0[KSEG], a1[KSEG];
+    fetch(wave, a0);
+    for (int t = wave; t < ntile; t += 2 * nwaves) {
+        fetch(min(t + nwaves, ntile - 1), a1);
+        tile(t, a0);
+        if (t + nwaves < ntile) {
+            fetch(min(t + 2 * nwaves, ntile - 1), a0);
+            tile(t + nwaves, a1);
+        }
+    }
+}
+
+template <int CIN, int COUT>
+int launch_pw(const float *x, const int32_t *n_ptr, int cap, const float *wp, const float *scale, const float *shift,
+              int relu, float *y, hipStream_t stream)
+{
+    int cus = 0;
+    int rc = sassd_num_cus(&cus);
+    if (rc) return rc;
+    const int grid = min(cdiv(cdiv(cap, 16), 4), cus * 8);
+    hipLaunchKernelGGL((spconv_pw_kernel<CIN, COUT>), dim3(grid), dim3(256), 0, stream, x, n_ptr, cap, wp, scale, shift, relu, y);
     return sassd_launch_status();
 }

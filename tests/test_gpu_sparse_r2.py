@@ -78,14 +78,16 @@ def test_rulebook_pyramid_overflow_flag(dev):
 
 
 @pytest.mark.parametrize("mode", ["default", "rw64x4", "rw128", "split2", "split2x16", "rw64x8", "legacy",
-                                  "gq16", "gq16x4", "gq4", "gq4x4", "r3", "c16", "c4", "c4x4", "c16x4"])
+                                  "gq16", "gq16x4", "gq4", "gq4x4", "r3", "c16", "c4", "c4x4", "c16x4",
+                                  "p16", "p16x4", "pc16", "pc16x4"])
 @pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (32, 16), (64, 32)])
 def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
     """subm and strided gather tables, ragged row counts (not multiples of the slice), every forward / data-gradient
     shape, against the CPU oracle; bar 2e-4 * max|y| (fp32 sums in a different order)."""
     flags = {"default": 0, "rw64x4": 1 << 16, "rw128": 2 << 16, "split2": 3 << 16, "split2x16": 4 << 16,
              "rw64x8": 5 << 16, "legacy": 256, "gq16": 6 << 16, "gq16x4": 9 << 16, "gq4": 7 << 16, "gq4x4": 8 << 16,
-             "r3": 10 << 16, "c16": 11 << 16, "c4": 12 << 16, "c4x4": 13 << 16, "c16x4": 14 << 16}[mode]
+             "r3": 10 << 16, "c16": 11 << 16, "c4": 12 << 16, "c4x4": 13 << 16, "c16x4": 14 << 16,
+             "p16": 15 << 16, "p16x4": 16 << 16, "pc16": 17 << 16, "pc16x4": 18 << 16}[mode]
     if mode.startswith("split2") and cout != 64:
         pytest.skip("the channel split exists for 64-channel layers")
     if mode == "legacy" and (cin, cout) in ((32, 16), (64, 32)):
@@ -123,7 +125,7 @@ def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
         K.debug_set_spconv(0)
 
 
-@pytest.mark.parametrize("mode", [0, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("mode", [0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 32), (16, 32)])
 def test_spconv_balanced_kernel_many_blocks(dev, cin, cout, mode):
     """The balanced kernel's row -> (block, interleaved slice) map past 16384 rows (more than 8 blocks), on a batch of
@@ -154,6 +156,30 @@ def test_spconv_balanced_kernel_many_blocks(dev, cin, cout, mode):
     assert (y[:n].cpu() - raw).abs().max().item() < tol
     assert bool((y[n:] == 7.0).all())
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (16, 32), (64, 32)])
+@pytest.mark.parametrize("n", [0, 1, 17, 4099, 40000])
+def test_spconv_1x1x1_streaming_kernel(dev, cin, cout, n):
+    """The 1 x 1 x 1 layer (cmn.py:208-212 `extra_conv`, K = 1, no rulebook) on the streaming kernel: ragged row counts,
+    folded scale / shift / ReLU, rows past the device row count untouched, against a float64 product."""
+    cap = n + 33
+    g = torch.Generator().manual_seed(n + cin)
+    x = torch.randn(max(cap, 1), cin, generator=g)
+    w = torch.randn(1, cin, cout, generator=g) * 0.3
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = torch.relu((x[:n].double() @ w[0].double()) * scale.double() + shift.double()).float()
+    nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+    y = torch.full((cap, cout), 5.0, device=dev)
+    K.spconv_fwd(x.to(dev), None, nptr, cap, K.spconv_pack_weight(w.to(dev)), 1, cin, cout, scale.to(dev), shift.to(dev),
+                 True, y)
+    torch.cuda.synchronize()
+    assert bool((y[n:] == 5.0).all())
+    if n:
+        assert (y[:n].cpu() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+        y2 = K.spconv_fwd(x.to(dev), None, nptr, cap, K.spconv_pack_weight(w.to(dev)), 1, cin, cout)
+        assert (y2[:n].cpu() - (x[:n].double() @ w[0].double()).float()).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
 def test_spconv_empty_and_tiny(dev):

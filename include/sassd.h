@@ -213,7 +213,9 @@ int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, const float *s
  *   then the 36 GEMMs; y != NULL: output transform + scale / shift / relu into the NCHW map y, y == NULL: the products
  *   stay in the workspace for the next call.  cmax >= every Cin / Cout of the chain fixes the workspace layout
  *   (sassd_conv2d_wino4_chain_workspace_bytes(batch, cmax, H, W)).  sassd_conv2d_wino4_chain_supported: the fused
- *   transform keeps one (H + 2) x (W + 2) plane in LDS (<= 160 KB). */
+ *   transform keeps one (H + 2) x (W + 2) plane in LDS (<= 160 KB).  src_products = 1 additionally requires that this
+ *   layer and the previous one (whose Cout is this Cin) pad their tile count to the same plane stride -- true whenever
+ *   both have the same Cout; SASSD_EINVAL otherwise. */
 int sassd_conv2d_wino4_chain_supported(int Cin, int Cout, int H, int W);
 size_t sassd_conv2d_wino4_chain_workspace_bytes(int batch, int cmax, int H, int W);
 int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev_scale, const float *prev_shift,

@@ -115,7 +115,7 @@ class SparseConvFn(Function):
                     nbr._sassd_transposed = ((n_out, n_in), nbr_t)
                 dx = K.spconv_bwd_data(dyc, nbr_t, _n_ptr(n_in, dev), max(n_in, 1), wt, 27, cin, cout)[:n_in]
         if ctx.needs_input_grad[1]:
-            if nbr is None and n_in > 0 and cin >= 16:
+            if nbr is None and n_in > 0 and (cin, cout) in _SP_PAIRS:
                 # 1x1x1 layer: X^T dY through the sparse weight-gradient kernel over an identity table (centre offset only)
                 dw = K.spconv_bwd_weight(x, dyc, _ident_nbr(n_in, dev), _n_ptr(n_in, dev), n_in, cin, cout)[13:14]
             elif nbr is None:
@@ -138,8 +138,19 @@ def _conv_any(x, weight, ks, packed=None, wino=None, shift=None, wino4=None):
     return K.conv2d_fwd(x, packed if packed is not None else K.conv2d_pack_weight(weight), cout, ks, None, shift)
 
 
+# channel pairs the sparse kernels are instantiated for (csrc/spconv.hip SP_DISPATCH); anything else takes the GEMM
+_SP_PAIRS = {(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (32, 16), (64, 32)}
+
 _dgrad_packs = {}
 _dgrad_direct = {}
+
+
+def _cacheable(weight):
+    """Packed images are cached per parameter STORAGE and weight generation.  A derived tensor (the fused RPN head's
+    `torch.cat` of three conv weights: fresh storage every step, `_version` always 0, and the caching allocator hands the
+    same address back) has no generation of its own -- after load_state_dict / a torch.optim step / an in-place edit of
+    its sources its cached image would be silently stale: such weights are packed on every call."""
+    return weight.is_leaf and weight.grad_fn is None
 
 
 def _dgrad_pack(weight, h, w):
@@ -147,11 +158,12 @@ def _dgrad_pack(weight, h, w):
     weight generation: the pack is a pure function of the weights, which change once per optimizer step."""
     ks = weight.shape[2]
     gen = K.weight_key(weight)
-    hit = _dgrad_direct.get((weight.data_ptr(), tuple(weight.shape)))       # installed by sassd.train.PackPlan
+    cache = _cacheable(weight)
+    hit = _dgrad_direct.get((weight.data_ptr(), tuple(weight.shape))) if cache else None   # installed by sassd.train.PackPlan
     if hit is not None and hit[0] == gen:
         return hit[1]
     key = (weight.data_ptr(), tuple(weight.shape), h, w)
-    hit = _dgrad_packs.get(key)
+    hit = _dgrad_packs.get(key) if cache else None
     if hit is not None and hit[0] == gen:
         return hit[1]
     wt = weight.detach().transpose(0, 1).flip(2, 3).contiguous()          # [Cin, Cout, k, k]
@@ -163,7 +175,8 @@ def _dgrad_pack(weight, h, w):
     else:
         pack = dict(packed=K.conv2d_pack_weight(wt))
     pack["wt"] = wt
-    _dgrad_packs[key] = (gen, pack)
+    if cache:
+        _dgrad_packs[key] = (gen, pack)
     return pack
 
 
@@ -175,14 +188,16 @@ def _bf16_pack(weight, transposed):
     cached per parameter storage and weight generation like _dgrad_pack."""
     key = (weight.data_ptr(), tuple(weight.shape), transposed)
     gen = K.weight_key(weight)
-    hit = _bf16_packs.get(key)
+    cache = _cacheable(weight)
+    hit = _bf16_packs.get(key) if cache else None
     if hit is not None and hit[0] == gen:
         return hit[1]
     w = weight.detach()
     if transposed:
         w = w.transpose(0, 1).flip(2, 3)
     pack = K.conv2d_bf16_pack_weight(w.contiguous())
-    _bf16_packs[key] = (gen, pack)
+    if cache:
+        _bf16_packs[key] = (gen, pack)
     return pack
 
 
@@ -346,37 +361,45 @@ class BnRelu2dFn(Function):
         return dx, dg, db, None, None, None, None
 
 
-_pending_nbt = {}      # id(counter tensor) -> [tensor, increments not yet applied]
+import weakref
+
+_pending_nbt = weakref.WeakKeyDictionary()      # BatchNorm module -> increments not yet applied (no strong references:
+                                                # a discarded model takes its pending counts with it)
 
 
 def _nbt_state_dict_hook(module, prefix, keep_vars):      # a module-level function: the layer stays picklable
     flush_bn_counters()
 
 
+def _nbt_load_hook(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    # load_state_dict on ANY module that contains the layer: pending increments land first (and are then overwritten by
+    # the loaded counter) instead of being added on top of it later
+    flush_bn_counters()
+
+
 def count_bn_batch(bn):
     """`bn.num_batches_tracked += 1`, deferred: the 23 BatchNorm layers of a training step would each launch a one-element
     int64 add (torch._foreach_add_ on 0-dim int64 tensors takes the per-tensor path too: 23 launches a step in the round-3
-    profile).  The increments are counted on the host and land in the tensors when somebody can look at them:
-    flush_bn_counters -- a state_dict pre-hook on every counted layer, plus load_state_dict / eval of the detector.  Nothing
-    in a training step reads the counter (every BatchNorm here has a fixed momentum)."""
+    profile).  The increments are counted on the host, per MODULE (whatever tensor the module holds when they land:
+    `.to(device)` in between is fine), and land when somebody can look at them: flush_bn_counters -- a state_dict pre-hook
+    and a load_state_dict pre-hook on every counted layer, plus eval / load_state_dict of the detector.  A direct read of
+    `bn.num_batches_tracked` between flushes sees the last flushed value; nothing in a training step reads the counter
+    (every BatchNorm here has a fixed momentum)."""
     if not getattr(bn, "_sassd_nbt_hook", False):
-        # whoever serialises this layer -- directly or through any parent's state_dict() -- sees the flushed counter
+        # whoever serialises / loads this layer -- directly or through any parent -- sees the flushed counter
         bn.register_state_dict_pre_hook(_nbt_state_dict_hook)
+        bn._register_load_state_dict_pre_hook(_nbt_load_hook, with_module=True)
         bn._sassd_nbt_hook = True
-    t = bn.num_batches_tracked
-    e = _pending_nbt.get(id(t))
-    if e is None or e[0] is not t:
-        _pending_nbt[id(t)] = [t, 1]
-    else:
-        e[1] += 1
+    _pending_nbt[bn] = _pending_nbt.get(bn, 0) + 1
 
 
 def flush_bn_counters():
-    if _pending_nbt:
-        todo = list(_pending_nbt.values())
+    if len(_pending_nbt):
+        todo = list(_pending_nbt.items())
         _pending_nbt.clear()
-        for t, n in todo:
-            t += n
+        for bn, n in todo:
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += n
 
 
 def bn_relu_2d(bn, x):

@@ -596,6 +596,10 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
     W4Geom G;
     G.B = batch; G.C = Cin; G.H = H; G.W = W; G.TH = H / 4; G.TW = W / 4; G.T = batch * G.TH * G.TW;
     G.Tp = w4_tiles_padded(batch, H, W, Cout);
+    // src_products: the previous call (its Cout = this Cin) left M [36][Cin][Tp'] with Tp' padded for ITS column-block
+    // width.  The fused transform reads M and writes V with one plane stride: both layers must agree on it (ADVICE r03;
+    // every chained SA-SSD layer is 256 -> 256, so they do) -- a mismatch is refused instead of read as garbage.
+    if (src_products && w4_tiles_padded(batch, H, W, Cin) != G.Tp) return SASSD_EINVAL;
     float *V = (float *)workspace;
     float *M = (float *)((char *)workspace + need / 2);
     if (!src_products) {

@@ -841,12 +841,13 @@ int launch_wgrad(const float *x, const float *dy, const int32_t *nbr, const int3
         // (1.1 GB per layer at Waymo scale, 317 k rows) cost more than the gradient itself, so the rows per workgroup grow
         // with the capacity (the pair lists live in dynamic LDS: 64 bytes per row)
         wg_rows = wgrad_rows_per_wg(cap);
-        const size_t lds = (size_t)8 * 2 * wg_rows * sizeof(int);
+        size_t lds = (size_t)8 * 2 * wg_rows * sizeof(int);
         static std::atomic<unsigned long long> attr_done{0};
-        // (the opt-in is made once per device with the largest size any capacity can ask for)
+        // the opt-in is made once per device with the largest size any capacity can ask for (128 KB); a device that
+        // refuses it still runs every capacity whose lists fit the 64 KB no kernel has to ask for
         int rc = sassd_dyn_lds((const void *)spconv_wgrad_offset_kernel<CIN, COUT>, (size_t)8 * 2 * 2048 * sizeof(int),
                                attr_done);
-        if (rc) return rc;
+        if (rc && lds > 64 * 1024) return rc;
         hipLaunchKernelGGL((spconv_wgrad_offset_kernel<CIN, COUT>), dim3(cdiv(cap, wg_rows)), dim3(512), lds, stream, x, dy,
                            nbr, n_ptr, cap, part, wg_rows);
     }

@@ -12,12 +12,21 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend=None):
-    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+def init(backend=None, force_single=False):
+    """Initialise the default process group from the torchrun environment (no-op for world size 1 unless
+    `force_single`: a one-rank communicator, so that the collectives of the training loop -- RCCL all-reduces launched
+    from gradient hooks on the HIP stream -- execute on a box with a single GPU; bench.py --force-ddp, tests)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_single) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            port = 29500
+            if world == 1:                                   # nobody to agree with: any free port
+                import socket
+                with socket.socket() as sock:
+                    sock.bind(("127.0.0.1", 0))
+                    port = sock.getsockname()[1]
+            os.environ["MASTER_PORT"] = str(port)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         dist.init_process_group(backend, rank=rank, world_size=world)

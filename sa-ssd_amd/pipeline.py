@@ -119,7 +119,9 @@ class InferencePlan:
             self.cmax = max(max(self.bev_cin[i], self.bev[i][1]) for i in range(8) if self.bev[i][5] == 4)
             self.wino4_ws = K.conv2d_wino4_chain_workspace(self.B, self.cmax, self.H, self.W, dev)
             for i in range(1, 8):
+                # (equal Cout on both sides of a boundary: the two layers then pad their tile count to one plane stride)
                 self.chain[i] = bool(chain_bev and self.bev[i][5] == 4 and self.bev[i - 1][5] == 4 and i - 1 != 6 and
+                                     self.bev[i - 1][1] == self.bev_cin[i] and self.bev[i - 1][1] == self.bev[i][1] and
                                      K.conv2d_wino4_chain_supported(self.bev_cin[i], self.bev[i][1], self.H, self.W))
         hw = torch.cat([sd["rpn_head.conv_box.weight"], sd["rpn_head.conv_cls.weight"],
                         sd["rpn_head.conv_dir_cls.weight"]], 0).float().contiguous()

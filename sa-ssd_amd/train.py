@@ -299,9 +299,11 @@ class GradSync:
     The sum is left in the buffer; the 1/world mean is folded into the update kernel.  `comm_ms()` reports the time of
     the last exchange between the first launch and the last completion (stream events; CUDA/HIP only)."""
 
-    def __init__(self, flat, buckets=4, overlap=True, time_comm=False):
+    def __init__(self, flat, buckets=4, overlap=True, time_comm=False, force=False):
         self.flat = flat
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # `force`: run the exchange on a one-rank communicator too (a sum over one rank; every collective still goes
+        # through the backend on the device stream -- the only way the RCCL path executes on a single-GPU box)
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or bool(force))
         self.ranges, self.works, self._hooks = [], [], []
         self.time_comm, self._ev = bool(time_comm), None
         if not self.on:

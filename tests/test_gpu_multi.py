@@ -1,4 +1,5 @@
-"""-m gpu multi-device checks (skipped on a 1-GPU box): the real RCCL path with world_size = torch.cuda.device_count()
+"""-m gpu multi-device checks: the real RCCL path with world_size = torch.cuda.device_count() (skipped on a 1-GPU box)
+and the same exchange on a one-rank communicator (always runs)
 -- gradient exchange of the training loop, and bench.py's own `--gpus N` launcher."""
 import json
 import os
@@ -14,6 +15,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _ngpu():
     return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def test_rccl_exchange_on_one_rank(dev):
+    """Not skipped on a 1-GPU box: the bucketed, hook-launched gradient all-reduce of the training step on a ONE-RANK
+    nccl (RCCL) communicator -- every collective of the DDP path executes on the HIP stream (tests/dist_gpu_single.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_single.py")], capture_output=True, text=True,
+                         env=env, timeout=600)
+    assert out.returncode == 0 and "RCCL_SINGLE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_rccl_gradient_exchange(dev):

@@ -434,3 +434,39 @@ def test_fused_aux_head_matches_module_path(dev):
     print("fused vs module aux head: losses", {k: (res[True][0][k], res[False][0][k]) for k in ("aux_loss_cls", "aux_loss_reg")},
           "worst gradient differences", [(k, "%.1e" % v) for k, v in top])
     assert max(worst.values()) < 1e-4, top
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fused_head_data_gradient_follows_in_place_weight_edits(dev, precision):
+    """the fused RPN head hands Conv2dFn a `torch.cat` of its three conv weights -- a derived tensor whose
+    `_version` is always 0 and whose storage address the caching allocator repeats.  Its packed data-gradient image must
+    not be cached: after an in-place edit of the source parameters (what load_state_dict / any torch.optim step does,
+    without sassd's generation bump) the gradient into the shared BEV features has to use the NEW weights."""
+    from sassd import autograd as AG
+    torch.manual_seed(3)
+    head = SSDRotateHead(num_class=1, num_output_filters=256).to(dev).train()
+    x = torch.randn(1, 256, 24, 32, device=dev, requires_grad=True)
+
+    def dx_of():
+        x.grad = None
+        ys = head(x)
+        sum((y * (i + 1.0)).sum() for i, y in enumerate(ys)).backward()
+        return x.grad.clone()
+
+    def ref_of():
+        xr = x.detach().clone().requires_grad_(True)
+        ys = [torch.nn.functional.conv2d(xr, c.weight.detach(), c.bias.detach()) for c in
+              (head.conv_box, head.conv_cls, head.conv_dir_cls)]
+        sum((y * (i + 1.0)).sum() for i, y in enumerate(ys)).backward()
+        return xr.grad
+
+    AG.set_bev_precision(precision)
+    try:
+        for rep in range(3):
+            got, ref = dx_of(), ref_of()
+            assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), (rep, precision)
+            with torch.no_grad():                            # no K.bump_weights_generation(): a foreign optimizer's step
+                for c in (head.conv_box, head.conv_cls, head.conv_dir_cls):
+                    c.weight.mul_(-1.7).add_(0.01)
+    finally:
+        AG.set_bev_precision("fp32")

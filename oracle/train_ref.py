@@ -158,7 +158,7 @@ def decode(enc, a):
 
 def train_step(sd, feats, coors, batch_size, sparse_shape, gt_bboxes, gt_types, class_names, anchors, anchors_mask,
                assign_cfg, anchor_thr=0.1, extra_thr=0.7, grid_offsets=(0., 40.), featmap_stride=0.4,
-               aux_offset=(0., -40., -3.), aux_voxel_size=(.05, .05, .1)):
+               aux_offset=(0., -40., -3.), aux_voxel_size=(.05, .05, .1), grad_exclude=()):
     """sd: detector state_dict (CPU tensors); feats [N,4] voxel means; coors [N,4] (b,z,y,x); gt_bboxes: list of
     [G,7]; gt_types: list of str arrays; anchors / anchors_mask: {class: [B, A, 7] / [B, A]};
     assign_cfg: {class: (pos_thr, neg_thr)}.  Returns (losses {name: float}, grads {param name: tensor},
@@ -295,7 +295,9 @@ def train_step(sd, feats, coors, batch_size, sparse_shape, gt_bboxes, gt_types, 
     el = torch.from_numpy(np.concatenate(elabels))
     ew = (el >= 0).float() / torch.clamp((el > 0).float().sum(), min=1.0)
     losses["loss_cls"] = focal_sum(torch.cat(scores), (el > 0).float(), ew) / B
-    total = sum(losses.values())
+    # grad_exclude: loss terms left out of the differentiated sum (tests: "loss_cls" removes the only term whose gradient
+    # depends on the discrete guided-anchor selection); every term is still reported
+    total = sum(v for k, v in losses.items() if k not in grad_exclude)
     names = [k for k, v in P.items() if v.requires_grad]
     grads = torch.autograd.grad(total, [P[k] for k in names], allow_unused=True)
     return ({k: float(v.detach()) for k, v in losses.items()}, dict(zip(names, grads)),

@@ -161,6 +161,11 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        # debugging aid (A/B of kernel geometries under an unmodified test / bench command): SASSD_SPCONV_DEBUG=<int> is
+        # handed to sassd_debug_set_spconv once, at load time (0 / unset in production)
+        flags = os.environ.get("SASSD_SPCONV_DEBUG")
+        if flags:
+            l.sassd_debug_set_spconv(int(flags, 0))
     return _lib
 
 

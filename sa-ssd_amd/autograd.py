@@ -1,6 +1,8 @@
 """torch.autograd glue for the training path: every forward and every data / weight gradient below
 runs in a hand-written HIP kernel of libsassd (BatchNorm / ReLU / Linear between them are torch ops, as in the
 reference).  There is no CPU fallback."""
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -59,15 +61,17 @@ def _ident_nbr(n, dev):
 _sp_t_packs = {}
 
 
-def _spconv_t_pack(weight):
+def _spconv_t_pack(weight, reverse=False):
     """Transposed packed image of a sparse-conv weight [K, Cin, Cout] for the data gradient, cached per parameter
-    storage and weight generation (sassd.train.PackPlan refreshes the entry right after the optimizer step)."""
-    key = (weight.data_ptr(), tuple(weight.shape))
+    storage and weight generation (sassd.train.PackPlan refreshes the entry right after the optimizer step).
+    reverse: the image of offset k holds W[K-1-k]^T (submanifold layers, see SparseConvFn.backward)."""
+    key = (weight.data_ptr(), tuple(weight.shape)) + ((True,) if reverse else ())
     gen = K.weight_key(weight)
     hit = _sp_t_packs.get(key)
     if hit is not None and hit[0] == gen:
         return hit[1]
-    pack = K.spconv_pack_weight_t(weight.detach().contiguous())
+    w = weight.detach()
+    pack = K.spconv_pack_weight_t((w.flip(0) if reverse else w).contiguous())
     _sp_t_packs[key] = (gen, pack)
     return pack
 
@@ -75,8 +79,14 @@ def _spconv_t_pack(weight):
 class SparseConvFn(Function):
     """y = sum_k x[nbr[:, k]] @ w[k]  (raw conv; BatchNorm / ReLU stay separate modules in training mode)."""
 
+    # submanifold layers take their data gradient on the FORWARD rulebook (no transposed table, no memset): for a
+    # submanifold table nbr[j][k] = i  <=>  nbr[i][26-k] = j, hence dx[i] = sum_k dy[nbr[i][k]] . W[26-k]^T -- the forward
+    # kernel with the offset-reversed transposed weight image (identity tested on the oracle, tests/test_oracle_cpu.py).
+    # False: the transposed-table formulation for every layer (A/B, tests).
+    subm_on_forward_table = os.environ.get("SASSD_SUBM_FWD_TABLE", "1") != "0"
+
     @staticmethod
-    def forward(ctx, x, weight, nbr, n_out, packed):
+    def forward(ctx, x, weight, nbr, n_out, packed, subm=False):
         # x [Nin, Cin]; weight [K, Cin, Cout] view of the module parameter; nbr [Nout, 27] or None (1x1x1)
         k, cin, cout = weight.shape
         x = x.contiguous()
@@ -84,6 +94,7 @@ class SparseConvFn(Function):
         y = K.spconv_fwd(x, nbr, _n_ptr(n_out, dev), max(n_out, 1), packed, k, cin, cout)
         ctx.save_for_backward(x, weight)
         ctx.nbr, ctx.n_out = nbr, n_out
+        ctx.subm = bool(subm) and nbr is not None and k == 27 and x.shape[0] == n_out
         return y[:n_out]
 
     @staticmethod
@@ -101,9 +112,12 @@ class SparseConvFn(Function):
         if ctx.needs_input_grad[0]:
             if cin < 16:
                 raise NotImplementedError("sparse data gradient needs Cin >= 16 (the 4-channel input layer has none)")
-            wt = _spconv_t_pack(weight)
+            on_fwd = ctx.subm and SparseConvFn.subm_on_forward_table and n_in > 0
+            wt = _spconv_t_pack(weight, reverse=on_fwd)
             if nbr is None:
                 dx = K.spconv_bwd_data(dyc, None, _n_ptr(n_in, dev), max(n_in, 1), wt, 1, cin, cout)[:n_in]
+            elif on_fwd:
+                dx = K.spconv_bwd_data(dyc, nbr, _n_ptr(n_in, dev), nbr.shape[0], wt, 27, cin, cout)[:n_in]
             else:
                 # the transposed table depends on the rulebook alone: layers sharing an `indice_key` (conv2.0-2, ...)
                 # build it once per batch (kept on the rulebook tensor, which lives as long as the batch)
@@ -123,7 +137,7 @@ class SparseConvFn(Function):
             else:
                 xc = x if n_in > 0 else torch.zeros(1, cin, device=dev)
                 dw = K.spconv_bwd_weight(xc, dyc, nbr, _n_ptr(n_out, dev), nbr.shape[0], cin, cout)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def _conv_any(x, weight, ks, packed=None, wino=None, shift=None, wino4=None):

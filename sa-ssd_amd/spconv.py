@@ -97,7 +97,8 @@ class SparseConvolution(nn.Module):
         """Raw conv (+bias) over a gather table: autograd-recording HIP path when gradients are wanted."""
         cin, cout = self.in_channels, self.out_channels
         if grad:
-            y = SparseConvFn.apply(feats, self.weight.view(k, cin, cout), nbr, n_out, self.packed_weight())
+            y = SparseConvFn.apply(feats, self.weight.view(k, cin, cout), nbr, n_out, self.packed_weight(),
+                                   isinstance(self, SubMConv3d))
             return y + self.bias if self.bias is not None else y
         bias = self.bias.detach() if self.bias is not None else None
         n_ptr = _cached_n_ptr(n_out, feats.device)

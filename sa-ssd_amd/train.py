@@ -134,9 +134,13 @@ class PackPlan:
                 if m.in_channels >= 16:
                     key = (m.weight.data_ptr(), (k, m.in_channels, m.out_channels))
 
+                    # submanifold layers differentiate on the forward rulebook with the offset-reversed image
+                    rev = isinstance(m, SP.SubMConv3d) and k == 27 and AG.SparseConvFn.subm_on_forward_table
+                    key = key + ((True,) if rev else ())
+
                     def inst_t(view, m=m, key=key):
                         AG._sp_t_packs[key] = (K.weight_key(m.weight), view)
-                    add_f32(K.spconv_pack_weight_t(wi), inst_t)
+                    add_f32(K.spconv_pack_weight_t(wi.flip(0).contiguous() if rev else wi), inst_t)
             elif isinstance(m, _HipConv2d) and m.weight.requires_grad:
                 cout, cin, ks = m.out_channels, m.in_channels, m.kernel_size[0]
                 off = (m.weight.data_ptr() - base) // 4

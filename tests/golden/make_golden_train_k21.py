@@ -83,6 +83,21 @@ def main():
         elif k in SLICED:
             out["grad8:" + k] = g[:8].numpy().astype(np.float32)
     out.update(grad_names=np.array(names), grad_norms=np.array(norms), grad_projs=np.array(projs))
+    # the same step with the rescoring head's loss_cls left out of the differentiated sum: the part of the objective that
+    # does not depend on WHICH anchors pass the guided-anchor threshold (the bf16 comparison uses it: bf16 moves the
+    # classification scores by ~1e-2, far more than any threshold margin, and ~2000 candidates sit near the threshold)
+    _, grads_x, _ = train_ref.train_step(*args, anchor_thr=thr, grad_exclude=("loss_cls",))
+    xn, xnorm = [], []
+    for k, g in grads_x.items():
+        if g is None:
+            continue
+        xn.append(k)
+        xnorm.append(float(g.double().norm()))
+        if k in FULL or ".bn" in k or k.split(".")[-2].isdigit() and g.dim() == 1:
+            out["gradx:" + k] = g.numpy().astype(np.float32)
+        elif k in SLICED:
+            out["gradx8:" + k] = g[:8].numpy().astype(np.float32)
+    out.update(gradx_names=np.array(xn), gradx_norms=np.array(xnorm))
     path = os.path.join(HERE, "train_k21_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", {k: round(v, 5) for k, v in losses.items()},

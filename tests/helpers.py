@@ -149,6 +149,19 @@ def safe_threshold(base, values, margin=1e-4, step=2.5e-4):
     raise AssertionError("no safe threshold near %g" % base)
 
 
+def widest_gap_threshold(base, values, span=2e-2):
+    """The threshold within base +- span that stays farthest from every value (the middle of the widest gap between
+    neighbouring values): -> (threshold, distance to the nearest value).  For dense score sets, where safe_threshold
+    would have to fall back to a margin of the size of the fp32 noise between two implementations."""
+    v = np.sort(np.asarray(values, np.float64).ravel())
+    v = v[(v > base - span) & (v < base + span)]
+    edges = np.concatenate([[base - span], v, [base + span]])
+    i = int(np.argmax(np.diff(edges)))
+    t = float(np.float32(0.5 * (edges[i] + edges[i + 1])))
+    near = float(np.abs(v - t).min()) if v.size else span
+    return t, near
+
+
 def oracle_forward_safe(sd, clouds, anchors, anchors_bv, cfg, num_class=1, rpn_thr=0.1, score_thr=0.3):
     """Whole path on the CPU oracle with thresholds nudged (by multiples of 2.5e-4) away from every candidate score.
     Returns (results dict, rpn_thr, score_thr) -- hand the two thresholds to the plan under test."""

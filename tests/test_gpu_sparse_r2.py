@@ -10,6 +10,7 @@ from oracle import clib, nets as onets, rulebook as orb
 import helpers as H
 
 pytestmark = pytest.mark.gpu
+_SLOW = pytest.mark.slow
 
 
 def _level0(name="k21", seed=0, batch=1):
@@ -159,7 +160,7 @@ def test_spconv_balanced_kernel_many_blocks(dev, cin, cout, mode):
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 64), (16, 32), (64, 32)])
-@pytest.mark.parametrize("n", [0, 1, 17, 4099, 40000])
+@pytest.mark.parametrize("n", [0, 17, 4099, pytest.param(1, marks=_SLOW), pytest.param(40000, marks=_SLOW)])
 def test_spconv_1x1x1_streaming_kernel(dev, cin, cout, n):
     """The 1 x 1 x 1 layer (cmn.py:208-212 `extra_conv`, K = 1, no rulebook) on the streaming kernel: ragged row counts,
     folded scale / shift / ReLU, rows past the device row count untouched, against a float64 product."""
@@ -274,3 +275,38 @@ def test_weight_gradient_formulations_agree(dev):
             K.debug_set_spconv(0)
         err = float((new - old).abs().max()) / float(old.abs().max())
         assert err < 1e-5, (cin, cout, err)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (64, 64)])
+def test_submanifold_data_gradient_on_forward_rulebook(dev, cin, cout):
+    """dx of a submanifold layer through the FORWARD table with the offset-reversed transposed weights
+    (nbr[j][k] = i <=> nbr[i][26-k] = j) against the transposed-table formulation and against torch autograd through the
+    oracle's gather / mm / index_add."""
+    from sassd.autograd import SparseConvFn
+    idx = _level0("small", 2)
+    shape = (40, 1600, 1408)
+    idx, _, shape = orb.conv_rulebook(idx, shape, 1)
+    idx, _, shape = orb.conv_rulebook(idx, shape, 1)
+    _, nbr = orb.subm_rulebook(idx, shape)
+    n = len(nbr)
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(27, cin, cout, generator=g) * 0.2
+    dy = torch.randn(n, cout, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    onets.sparse_conv(xr, nbr, wr).backward(dy)
+    nb = torch.from_numpy(nbr).to(dev)
+    got = {}
+    for on_fwd in (True, False):
+        SparseConvFn.subm_on_forward_table = on_fwd
+        try:
+            xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+            y = SparseConvFn.apply(xd, wd, nb, n, K.spconv_pack_weight(wd.detach()), True)
+            y.backward(dy.to(dev))
+            got[on_fwd] = (xd.grad.cpu(), wd.grad.cpu())
+        finally:
+            SparseConvFn.subm_on_forward_table = True
+    tol = 2e-4 * max(1.0, xr.grad.abs().max().item())
+    assert (got[True][0] - xr.grad).abs().max().item() < tol
+    assert (got[False][0] - xr.grad).abs().max().item() < tol
+    assert (got[True][1] - wr.grad).abs().max().item() < 2e-4 * max(1.0, wr.grad.abs().max().item())

@@ -263,7 +263,7 @@ def train_measure(args, dev, rank, world, config="car", precision="bf16", steps=
     sps = steps * B * world / dt
     traffic, at = (None, None)
     if bf16_conv and B == 2 and config == "car":
-        rec, at = stamped_traffic("r03_bf16_conv_hbm_traffic.json")
+        rec, at = stamped_traffic("r04_bf16_conv_hbm_traffic.json")
         traffic = rec["traffic_bytes_per_launch"] if rec else None
     roof = dict(bound="mfma", kernel=kname, achieved=round(flops / kms / 1e9, 1), peak=peak, unit="TFLOP/s",
                 frac=round(flops / kms / 1e9 / peak, 4), ms_per_launch=round(kms, 4), traffic=traffic,
@@ -567,12 +567,18 @@ def main():
     # the kernel sources this library was built from (`traffic_measured_at` says which)
     traffic = traffic_at = sp_traffic = sp_traffic_at = None
     if B == 1 and args.config == "car":
-        rec, traffic_at = stamped_traffic("r03_wino4_gemm_hbm_traffic.json")
+        rec, traffic_at = stamped_traffic("r04_wino4_gemm_hbm_traffic.json")
         traffic = rec["traffic_bytes_per_launch"] if rec else None
     if B == w["batch"]:                  # fabric-side bytes of one sparse pass: 2 x FETCH + WRITE
-        t, sp_traffic_at = stamped_traffic("r03_sparse_%s_hbm_traffic.json" % args.config)
+        t, sp_traffic_at = stamped_traffic("r04_sparse_%s_hbm_traffic.json" % args.config)
         if t:
             sp_traffic = int((2 * t["FETCH_SIZE_kb_per_pass_raw"] + t["WRITE_SIZE_kb_per_pass_raw"]) * 1024)
+    # issue / wait / MFMA-busy fractions of the sparse-conv kernels from the stamped SQ-counter passes (profiles/)
+    sp_counters, sp_counters_at = None, None
+    st, sp_counters_at = stamped_traffic("r04_stall_breakdown.json")
+    if st:
+        sp_counters = {k: dict(v["fraction_of_wave_cycles"], mfma_busy_fraction=v.get("mfma_busy_fraction"))
+                       for k, v in st["kernels"].items() if k.startswith("spconv") and k.endswith("@" + args.config)} or None
     out = {
         "metric": "KITTI-Car inference frames/sec (whole job)" if args.config == "car" else
                   "%s inference frames/sec (whole job)" % args.config,
@@ -613,6 +619,10 @@ def main():
                             "bytes_gs": work["bytes_gs"], "bytes_min": work["bytes_min"],
                             "rulebook_bytes": work["rulebook_bytes"], "flops": work["flops"],
                             "ms": round(sp_ms, 4), "ms_eager_isolated": round(iso_ms["sparse"], 4), "rows": work["n"],
+                            "counters": sp_counters, "counters_measured_at": sp_counters_at,
+                            "counters_unit": "per sparse-conv kernel: fractions of its wave-cycles parked (SQ_WAIT_ANY), issue-"
+                                             "stalled (SQ_WAIT_INST_ANY), issuing (SQ_ACTIVE_INST_ANY); mfma_busy_fraction = "
+                                             "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES per SE)",
                             "traffic": sp_traffic, "traffic_measured_at": sp_traffic_at,
                             "traffic_unit": "fabric-side bytes per pass, upper bound 2 x FETCH_SIZE + WRITE_SIZE over all "
                                             "rulebook / sparse-conv dispatches (separate rocprofv3 --pmc passes, profiles/): "

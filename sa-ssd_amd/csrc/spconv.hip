@@ -540,13 +540,14 @@ int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap,
     if (g_spconv_cfg == 13) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     // default (round 4, measured per layer shape; profiles/r04_spconv_layers_*.txt).  The balanced kernel pays for its
     // cooperative compaction and pays off where a layer is long enough to be bound by its heaviest workgroup: the
-    // 64 -> 64 layers.  KITTI-scale frames (one round of workgroups): 16x16x4 tiles on 4 waves, interleaved slices --
-    // 22 / 31 us instead of 33 / 37 us for the 14.6 k / 13.3 k-row submanifold layers.  Batches of frames: 4x4x1 quads
-    // (strided layers 91 instead of 111 us at 106 k rows).  Waymo-scale levels (13-17 pairs per row: 16-pair tiles are
-    // full) and every narrower layer stay on the round-3 geometry.
+    // 64 -> 64 layers.  KITTI-scale single frames (one round of workgroups; level capacity 40 k rows): 16x16x4 tiles on 4
+    // waves, interleaved slices -- 22 / 31 us instead of 33 / 37 us for the 14.6 k / 13.3 k-row submanifold layers.
+    // Batches of frames (training batch 2: 37 / 55 us instead of 48 / 65 us; multi_cfg batch 8: strided layers 91 instead
+    // of 111 us at 106 k rows): 4x4x1 quads.  Waymo-scale levels (13-17 pairs per row: 16-pair tiles are full) and every
+    // narrower layer stay on the round-3 geometry.
     if constexpr (CIN == 64 && COUT == 64) {
         if (g_spconv_cfg != 10) {
-            if (cap <= 100000) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+            if (cap <= 65536) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
             if (cap <= 400000) return launch_gq_cfg<CIN, COUT, 4, 2, 1, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
         }
     }
@@ -765,20 +766,25 @@ __global__ void __launch_bounds__(512) spconv_wgrad_offset_kernel(const float *_
             }
         };
         const int nsteps = (cnt + 3) >> 2;
-        if (nsteps > 0) fetch(0, av[0], bv[0]);
+        // (round 4) the look-ahead fetch is UNCONDITIONAL -- past the end the last step is requested again: a load under a
+        // branch makes the number of loads in flight path-dependent and the compiler answered with s_waitcnt vmcnt(0)
+        // after every group of loads (no step's operands were ever in flight during the previous step's MFMAs)
+        if (nsteps > 0) {
+            fetch(0, av[0], bv[0]);
 #pragma unroll 1
-        for (int s = 0; s < nsteps; s += 2) {
-            if (s + 1 < nsteps) fetch(s + 1, av[1], bv[1]);
+            for (int s = 0; s < nsteps; s += 2) {
+                fetch(min(s + 1, nsteps - 1), av[1], bv[1]);
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
+                for (int a = 0; a < MT; ++a)
 #pragma unroll
-                for (int b = 0; b < NTT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][a], bv[0][b], acc[a][b], 0, 0, 0);
-            if (s + 1 >= nsteps) break;
-            if (s + 2 < nsteps) fetch(s + 2, av[0], bv[0]);
+                    for (int b = 0; b < NTT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][a], bv[0][b], acc[a][b], 0, 0, 0);
+                if (s + 1 >= nsteps) break;
+                fetch(min(s + 2, nsteps - 1), av[0], bv[0]);
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
+                for (int a = 0; a < MT; ++a)
 #pragma unroll
-                for (int b = 0; b < NTT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][a], bv[1][b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < NTT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][a], bv[1][b], acc[a][b], 0, 0, 0);
+            }
         }
         // D[row = q*4 + reg][col = m16] -> dW[k][ci = a*16 + q*4 + reg][co = b*16 + m16]
 #pragma unroll

@@ -215,26 +215,29 @@ def test_training_step_vs_oracle(dev, cfgfile, names, HALF, precision):
             continue
         worst[name] = _rel(p.grad, rg)
         checked += 1
-    # (three classes: the box-head BIAS gradient sums 42 channels over 105 600 anchors with heavy cancellation, so its
-    # relative error is set by the last bits of the activations: 2.6e-3 and 3.7e-3 measured with two fp32 summation
-    # orders of the sparse convs -- 6e-3 for that one tensor, every other tensor < 2e-3)
-    tols = {"rpn_head.conv_box.bias": 6e-3} if len(names) > 1 else {}
-    per_tensor = 2e-3
+    # car_cfg: every tensor < 2e-3 (measured < 6e-4).
+    # Three classes: the box head's gradient sums 42 channels over 105 600 / 211 200 anchors with heavy cancellation, and
+    # the tensors at the sparse / dense seam (extra_conv, bn0, conv0) collect that rounding through eight train-mode BN
+    # layers: their relative error is set by the last bits of the sparse activations, i.e. by the ORDER in which a sparse
+    # conv sums its <= 27 offset contributions.  Measured on the half grid with three orders of round 4 (balanced kernel,
+    # round-3 geometry, register-stationary kernel) AND with the round-3 sources forced onto their own register-stationary
+    # kernel: whole-model gradient 4.9e-4 ... 5.1e-4, box head 2.0e-2 / 1.8e-2, seam tensors 2.5e-3 ... 2.7e-3 -- every
+    # one of them; only the round-3 default order, which happens to follow the oracle's ascending-offset sum, measured
+    # 4.0e-5 / 9e-4 / 7e-4 (and its bars of 2e-3 / 6e-3 were set on that).  The loss terms carry the strict bar above;
+    # the three-class gradient is held as a whole (2e-3 relative L2 over all parameters), 1e-2 per tensor, 4e-2 for the
+    # box head.
+    tols, per_tensor = {}, 2e-3
     g_got = torch.cat([p.grad.detach().double().cpu().reshape(-1) for n, p in model.named_parameters() if n in worst])
     g_ref = torch.cat([ref_g[n].double().reshape(-1) for n, p in model.named_parameters() if n in worst])
     whole = float((g_got - g_ref).norm() / g_ref.norm())
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
     print("training step vs oracle (%s, %d-wide grid, %s): whole-model gradient rel L2 %.2e; worst tensors %s"
           % (cfgfile, HALF["sparse_shape"][2], precision, whole, [(k, "%.1e" % v) for k, v in top]))
-    if len(names) > 1 and HALF is FULL:
-        # multi_cfg on its own full grid (211 200 anchors): the loss terms carry the strict bar above; the gradient is held
-        # as a whole (2e-3 relative L2 over all parameters; measured 9.1e-4) with 1e-2 per tensor -- the tensors at the
-        # sparse / dense seam (extra_conv, bn0) collect the rounding of 42 + 18 + 12 head channels through eight train-mode
-        # BN layers and measure 4-5e-3 here against < 1e-3 on the half grid and on car_cfg -- and 2e-2 for the box head
-        # (weight 1.1e-2, bias 1.0e-2 measured: sums of 42 channels over 211 200 anchors with heavy cancellation, the
-        # tensor that already needs 6e-3 on the half grid)
+    if len(names) > 1:
         assert whole < 2e-3, whole
-        per_tensor, tols = 1e-2, {"rpn_head.conv_box.bias": 2e-2, "rpn_head.conv_box.weight": 2e-2}
+        per_tensor, tols = 1e-2, {"rpn_head.conv_box.bias": 4e-2, "rpn_head.conv_box.weight": 4e-2}
+    else:
+        assert whole < 5e-4, whole
     bad = {k: v for k, v in worst.items() if not v < tols.get(k, per_tensor)}
     assert checked >= 60 and not bad, (checked, bad)
 

@@ -58,8 +58,8 @@ print("pairs", work["pairs"], "bytes_gs %.1f MB" % (work["bytes_gs"] / 1e6))
 
 # round 4: the balanced kernel (spconv_gq.h) next to the round-3 kernel; the gather / weight-load ablation bits are gone
 # (a load under a branch makes the compiler drain vmcnt(0) in front of every tile -- the very thing being measured)
-MODES = [("r3", 10 << 16), ("gq4x8w", 7 << 16), ("gq4x4w", 8 << 16), ("gq16x4w", 9 << 16), ("c16x4w", 14 << 16),
-         ("p16x8w", 15 << 16), ("p16x4w", 16 << 16), ("pc16x8w", 17 << 16), ("pc16x4w", 18 << 16)]
+MODES = [("r3", 10 << 16), ("gq4x8w", 7 << 16), ("gq4x4w", 8 << 16), ("gq16x4w", 9 << 16), ("gq16x8w", 6 << 16),
+         ("c4x4w", 13 << 16), ("c16x4w", 14 << 16), ("default", 0)]
 layers = []
 lvl = 0
 for kind, cin, cout, key, wp, scale, shift in plan.sp:
@@ -83,10 +83,10 @@ for kind, cin, cout, key, wp, scale, shift, lvl in layers:
     print(line)
     if args.ablate and (kind, key, cin) not in seen and cin >= 16 and key:
         seen.add((kind, key, cin))
-        for mname, base in [MODES[0], MODES[2], MODES[3], MODES[4]]:
+        for mname, base in [MODES[0], MODES[2], MODES[3]]:
             s = "        ablation %-8s" % mname
             bits = ((2, "no-slab"), (4, "no-mfma"), (6, "neither")) if mname == "r3" else \
-                   ((4, "no-mfma"), (96, "hot-both"), (100, "skeleton"), (16, "prio-mfma"), (8, "prio-rest"))
+                   ((4, "no-mfma"), (32, "hot-gather"), (64, "hot-w"), (96, "hot-both"), (100, "skeleton"))
             for bit, nm in bits:
                 K.debug_set_spconv(base | bit)
                 s += "  %s %6.1f" % (nm, timeit(lambda: K.spconv_fwd(x, nbr, plan.n[lvl], plan.caps[lvl], wp, k, cin,

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 sys.path.insert(0, ROOT)
 import sassd  # noqa: E402,F401
 from sassd import _C  # noqa: E402
@@ -46,11 +46,16 @@ for name in ("bench_inflight3", "bench_inflight1", "bench_multi", "bench_waymo",
         d = json_line(lg)
         if d:
             json.dump(d, open(os.path.join(DST, "%s_%s_under_rocprof.json" % (tag, name)), "w"), indent=1)
-for name in ("bench_default", "bench_train_bf16", "bench_train_fp32", "bench_train_waymo"):
+for name in ("bench_default", "bench_train_bf16", "bench_train_fp32", "bench_train_waymo", "bench_train_forceddp",
+             "bench_multi", "bench_waymo", "bench_20steps"):
     lg = os.path.join(SRC, name + ".log")
     d = json_line(lg) if os.path.exists(lg) else None
     if d:
         json.dump(d, open(os.path.join(DST, "%s_%s.json" % (tag, name)), "w"), indent=1)
+for name in ("spconv_layers_car", "spconv_layers_multi", "spconv_layers_waymo", "mfma4x4_probe"):
+    src = os.path.join(SRC, name + ".txt")
+    if os.path.exists(src) and os.path.getsize(src) > 10:
+        shutil.copy(src, os.path.join(DST, "%s_%s.txt" % (tag, name)))
 bt = os.path.join(SRC, "bf16_conv_timing.json")
 if os.path.exists(bt) and os.path.getsize(bt) > 10:
     shutil.copy(bt, os.path.join(DST, "%s_bf16_conv_timing.json" % tag))
@@ -123,8 +128,13 @@ if nf and nw:
     json.dump(rec, open(os.path.join(DST, "%s_bf16_conv_hbm_traffic.json" % tag), "w"), indent=1)
 # SQ stall counters of the three hot kernels (one pass each, eight SQ counters): where the wave-cycles go
 stall = {}
-for name, pats in (("stall_bf16conv", ("conv2d_bf16_kernel",)), ("stall_sparse_car", ("spconv_gs_kernel",)),
-                   ("stall_wino4", ("wino4_gemm_kernel", "wino4_outin_kernel", "wino4_in_kernel", "wino4_out_kernel"))):
+for name, pats, suffix in (("stall_bf16conv", ("conv2d_bf16_kernel",), ""),
+                           ("stall_sparse_car", ("spconv_gq_kernel<64, 64", "spconv_gs_kernel<32, 32", "spconv_gs_kernel<32, 64",
+                                                 "spconv_pw_kernel", "spconv_gs_kernel", "spconv_gq_kernel"), "@car"),
+                           ("stall_sparse_multi", ("spconv_gq_kernel<64, 64", "spconv_gs_kernel<32, 32", "spconv_gs_kernel<32, 64",
+                                                   "spconv_pw_kernel", "spconv_gs_kernel", "spconv_gq_kernel"), "@multi"),
+                           ("stall_sparse_car_r3geom", ("spconv_gs_kernel<64, 64",), "@car(round-3 geometry)"),
+                           ("stall_wino4", ("wino4_gemm_kernel", "wino4_outin_kernel", "wino4_in_kernel", "wino4_out_kernel"), "")):
     path = os.path.join(SRC, name + "_SQ_WAVE_CYCLES.json")
     if not os.path.exists(path):
         continue
@@ -140,13 +150,18 @@ for name, pats in (("stall_bf16conv", ("conv2d_bf16_kernel",)), ("stall_sparse_c
                     nd = max(nd, rec["dispatches"])
         if acc and acc.get("SQ_WAVE_CYCLES"):
             wc = acc["SQ_WAVE_CYCLES"]
-            stall[pat] = dict(dispatches=nd, per_dispatch={c: v / nd for c, v in acc.items()},
-                              fraction_of_wave_cycles={c: round(v / wc, 4) for c, v in acc.items() if c != "SQ_WAVE_CYCLES"})
+            e = dict(dispatches=nd, per_dispatch={c: v / nd for c, v in acc.items()},
+                     fraction_of_wave_cycles={c: round(v / wc, 4) for c, v in acc.items() if c != "SQ_WAVE_CYCLES"})
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4): / 32 = the kernel's cycles; the MFMA pipe
+            # can be busy on 1024 SIMDs during each of them
+            if acc.get("SQ_BUSY_CYCLES") and acc.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+                e["mfma_busy_fraction"] = round(acc["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * acc["SQ_BUSY_CYCLES"] / 32.0), 4)
+            stall[pat + suffix] = e
 if stall:
     json.dump(dict(csrc_hash=CSRC,
                    command="rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
                            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -- python tools/"
-                           "run_bf16_conv.py | run_sparse_only.py --config car | run_wino4.py --profile",
+                           "run_bf16_conv.py | run_sparse_only.py --config car / multi [--spconv-cfg 10] | run_wino4.py --profile",
                    note="MI355X_MICROARCH.md: SQ_WAIT_ANY = wave parked (s_waitcnt / barrier), SQ_WAIT_INST_ANY = issue stall, "
                         "SQ_ACTIVE_INST_ANY = issuing; the three are disjoint and add up to ~SQ_WAVE_CYCLES (quad-cycles); "
                         "SQ_VALU_MFMA_BUSY_CYCLES counts cycles",

@@ -41,9 +41,14 @@ const char *sassd_version(void);
 int sassd_last_hip_error(void);
 const char *sassd_last_hip_error_string(void);
 
-/* Debug / ablation switches of the sparse-conv forward kernel (tools/ablate_spconv.py); 0 in production:
- * bit0 no gather loads, bit1 no LDS scatter-add, bit2 no MFMA, bit3 no weight loads, bit4 ticket offset assignment, bit8 legacy register-stationary
- * kernel, bits 16+ force the row-slice size (64 / 128). */
+/* Debug / ablation switches of the sparse-conv forward kernels (tools/ablate_spconv.py); 0 in production.  Low 16 bits:
+ * bit1 no LDS slab update, bit2 no MFMA, bit4 ticket offset assignment (round-3 kernel), bit5 every gather reads row 0,
+ * bit6 one weight image for every offset (bits 5 / 6 keep the number of loads in flight unchanged: a load under a branch
+ * changes the compiler's wait counts, the very thing being measured), bit8 register-stationary kernel everywhere.
+ * Bits 16+: kernel / workgroup geometry -- 0 the per-shape default, 1-5 and 10 geometries of spconv_gs_kernel (10 = the
+ * round-3 default everywhere), 6-9 / 11-14 the balanced kernel spconv_gq_kernel (16x16x4 tiles or 4x4x1 quads, 8 or 4
+ * waves, interleaved or consecutive row slices).  The environment variable SASSD_SPCONV_DEBUG (read once by the Python
+ * binding at load time) sets the same word for an unmodified test / bench command. */
 void sassd_debug_set_spconv(int flags);
 
 /* hipGraph capture of a launch sequence issued through this ABI (the reference has no counterpart: its frame is
@@ -134,7 +139,8 @@ int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32_t *const *
  * Replaces spconv `indice_conv_fp32` (+ nn.BatchNorm1d + nn.ReLU, cmn.py:138-173,208-212).
  *   y[o,:] = act( (sum_k x[nbr[o,k],:] @ w[k]) * scale + shift )
  *   w        [K, Cin, Cout] f32 (spconv layout [kz,ky,kx,Cin,Cout] flattened) -> pack once with
- *            sassd_spconv_pack_weight (sassd_spconv_packed_floats floats).
+ *            sassd_spconv_pack_weight (sassd_spconv_packed_floats floats; an opaque image -- since round 4
+ *            [K][Cin/4][Cout][4], four consecutive input channels of one output channel per 16-byte piece).
  *   nbr NULL = identity rulebook with K=1 (the 1x1x1 `extra_conv` shortcut, cmn.py:208-212).
  *   scale/shift may be NULL (1 / 0).  (Cin,Cout) in {(4,16),(16,16),(16,32),(32,32),(32,64),(64,64)}.
  * ---------------------------------------------------------------------------------------------- */

@@ -78,17 +78,19 @@ def test_rulebook_pyramid_overflow_flag(dev):
     assert int(st.item()) & 1 and int(n[1].item()) == caps[1]
 
 
-@pytest.mark.parametrize("mode", ["default", "rw64x4", "rw128", "split2", "split2x16", "rw64x8", "legacy",
-                                  "gq16", "gq16x4", "gq4", "gq4x4", "r3", "c16", "c4", "c4x4", "c16x4",
-                                  "p16", "p16x4", "pc16", "pc16x4"])
+@pytest.mark.parametrize("mode", ["default", "legacy", "gq16x4", "gq4x4", "r3", "rw128",
+                                  pytest.param("rw64x4", marks=_SLOW), pytest.param("split2", marks=_SLOW),
+                                  pytest.param("split2x16", marks=_SLOW), pytest.param("rw64x8", marks=_SLOW),
+                                  pytest.param("gq16", marks=_SLOW), pytest.param("gq4", marks=_SLOW),
+                                  pytest.param("c16", marks=_SLOW), pytest.param("c4", marks=_SLOW),
+                                  pytest.param("c4x4", marks=_SLOW), pytest.param("c16x4", marks=_SLOW)])
 @pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (32, 16), (64, 32)])
 def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
     """subm and strided gather tables, ragged row counts (not multiples of the slice), every forward / data-gradient
     shape, against the CPU oracle; bar 2e-4 * max|y| (fp32 sums in a different order)."""
     flags = {"default": 0, "rw64x4": 1 << 16, "rw128": 2 << 16, "split2": 3 << 16, "split2x16": 4 << 16,
              "rw64x8": 5 << 16, "legacy": 256, "gq16": 6 << 16, "gq16x4": 9 << 16, "gq4": 7 << 16, "gq4x4": 8 << 16,
-             "r3": 10 << 16, "c16": 11 << 16, "c4": 12 << 16, "c4x4": 13 << 16, "c16x4": 14 << 16,
-             "p16": 15 << 16, "p16x4": 16 << 16, "pc16": 17 << 16, "pc16x4": 18 << 16}[mode]
+             "r3": 10 << 16, "c16": 11 << 16, "c4": 12 << 16, "c4x4": 13 << 16, "c16x4": 14 << 16}[mode]
     if mode.startswith("split2") and cout != 64:
         pytest.skip("the channel split exists for 64-channel layers")
     if mode == "legacy" and (cin, cout) in ((32, 16), (64, 32)):
@@ -126,7 +128,7 @@ def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
         K.debug_set_spconv(0)
 
 
-@pytest.mark.parametrize("mode", [0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("mode", [0, 8, 9, 10] + [pytest.param(m, marks=_SLOW) for m in (6, 7, 11, 12, 13, 14)])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 32), (16, 32)])
 def test_spconv_balanced_kernel_many_blocks(dev, cin, cout, mode):
     """The balanced kernel's row -> (block, interleaved slice) map past 16384 rows (more than 8 blocks), on a batch of

@@ -222,8 +222,11 @@ def test_pack_plan_matches_individual_packs(dev):
                 assert m._packed_version == K.weight_key(m.weight)
                 assert torch.equal(m._packed, K.spconv_pack_weight(w)); checked["sp"] += 1
                 if m.in_channels >= 16:
-                    gen, pk = AG._sp_t_packs[(m.weight.data_ptr(), (k, m.in_channels, m.out_channels))]
-                    assert gen == K.weight_key(m.weight) and torch.equal(pk, K.spconv_pack_weight_t(w)); checked["spt"] += 1
+                    # submanifold layers differentiate on the forward rulebook: offset-reversed transposed image
+                    rev = isinstance(m, SP.SubMConv3d) and k == 27 and AG.SparseConvFn.subm_on_forward_table
+                    gen, pk = AG._sp_t_packs[(m.weight.data_ptr(), (k, m.in_channels, m.out_channels)) + ((True,) if rev else ())]
+                    ref = K.spconv_pack_weight_t(w.flip(0).contiguous() if rev else w)
+                    assert gen == K.weight_key(m.weight) and torch.equal(pk, ref); checked["spt"] += 1
             elif isinstance(m, _HipConv2d):
                 w = m.weight.detach()
                 key = (w.data_ptr(), tuple(w.shape))

@@ -105,12 +105,39 @@ __device__ __forceinline__ int hash_find(const unsigned *keys, unsigned mask, un
     return -1;
 }
 
-// host-side view of a table buffer of sassd_hash_bytes(cap_rows) bytes: [keys u32 x h][vals i32 x h], h = pow2 >= 2*cap
+// ---- the rulebook's coordinate table: INTERLEAVED entries {key u32, value i32} (round 4) ------------------------
+// A lookup is one 8-byte load per probe; with separate key / value arrays (rounds 1-3) every hit paid a second,
+// dependent load from another cache line -- the level-0 submanifold table and the first strided table (26 / 27 lookups
+// per row) are chains of such round trips.  EMPTY key = 0xFFFFFFFF (the table is cleared with 0xFF bytes).
 struct HashView {
-    unsigned *keys;
-    int *vals;
+    uint2 *ent;                // [h] {key, value}, h = pow2 >= 2 * cap_rows
     unsigned mask;
 };
+
+// slot of `key` (claiming it if absent) or -1 if the table is full
+__device__ __forceinline__ int hash2_insert(uint2 *ent, unsigned mask, unsigned key)
+{
+    unsigned h = hash_u32(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        unsigned prev = atomicCAS(&ent[h].x, SASSD_HASH_EMPTY, key);
+        if (prev == SASSD_HASH_EMPTY || prev == key) return (int)h;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// value stored for `key`, or -1
+__device__ __forceinline__ int hash2_lookup(const uint2 *ent, unsigned mask, unsigned key)
+{
+    unsigned h = hash_u32(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        const uint2 e = ent[h];
+        if (e.x == key) return (int)e.y;
+        if (e.x == SASSD_HASH_EMPTY) return -1;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
 
 static inline unsigned hash_cap(int cap_rows)
 {
@@ -118,13 +145,12 @@ static inline unsigned hash_cap(int cap_rows)
     return h < 1024 ? 1024 : h;
 }
 
+// host-side view of a table buffer of sassd_hash_bytes(cap_rows) = 8 * h bytes
 static inline HashView hash_view(const void *table, int cap_rows)
 {
     HashView v;
-    unsigned h = hash_cap(cap_rows);
-    v.keys = (unsigned *)table;
-    v.vals = (int *)((char *)table + (size_t)h * 4);
-    v.mask = h - 1;
+    v.ent = (uint2 *)table;
+    v.mask = hash_cap(cap_rows) - 1;
     return v;
 }
 

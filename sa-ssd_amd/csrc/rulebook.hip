@@ -22,9 +22,9 @@ __global__ void hash_build_kernel(const int32_t *__restrict__ idx, const int32_t
     if (i >= n) return;
     const int4 c = ((const int4 *)idx)[i];
     const unsigned key = (((unsigned)c.x * D + c.y) * H + c.z) * W + c.w;
-    const int e = hash_insert(hv.keys, hv.mask, key);
+    const int e = hash2_insert(hv.ent, hv.mask, key);
     if (e < 0) { if (status) atomicOr(status, SASSD_ST_HASH_FULL); return; }
-    hv.vals[e] = i;
+    hv.ent[e].y = (unsigned)i;
 }
 
 // one thread per (output row, kernel offset): nbr[row*27+k] = row of voxel at c + (k-1) or -1
@@ -41,8 +41,7 @@ __global__ void nbr_subm_kernel(const int32_t *__restrict__ idx, const int32_t *
     if (k == 13) r = row;
     else if (z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W) {
         const unsigned key = (((unsigned)c.x * D + z) * H + y) * W + x;
-        const int e = hash_find(hv.keys, hv.mask, key);
-        if (e >= 0) r = hv.vals[e];
+        r = hash2_lookup(hv.ent, hv.mask, key);
     }
     nbr[t] = r;
 }
@@ -160,8 +159,7 @@ __global__ void nbr_down_kernel(const int32_t *__restrict__ out_idx, const int32
     int r = -1;
     if (z >= 0 && z < d.D && y >= 0 && y < d.H && x >= 0 && x < d.W) {
         const unsigned key = (((unsigned)c.x * d.D + z) * d.H + y) * d.W + x;
-        const int e = hash_find(hv.keys, hv.mask, key);
-        if (e >= 0) r = hv.vals[e];
+        r = hash2_lookup(hv.ent, hv.mask, key);
     }
     nbr[t] = r;
 }
@@ -199,9 +197,10 @@ inline bool lin_fits(int D, int H, int W, int B) { return (double)D * H * W * B 
 //                     perfect index: row(c) = rank[c >> 5] + popcount(bitmap[c >> 5] below bit c) -- two independent
 //                     loads, no probing, no inserts (hash inserts from the emit kernel were a chain of dependent
 //                     atomic round trips per thread: 50-110 us per level).
-//   rb_level_kernel   one thread per (row of level l, offset k): the subm table of level l, the strided table INTO
-//                     level l (lookup in level l-1) and -- threads k < 8 -- the marks of the row's <= 8 strided
-//                     outputs in the bitmap of level l+1.  All three only read finished structures.
+//   rb_level_kernel   one thread per (row of level l, (kz, ky)): three x-offsets at a time of the subm table of level l
+//                     and of the strided table INTO level l (lookup in level l-1; the three cells share a bitmap word 15
+//                     times out of 16) and -- threads g < 8 -- the marks of the row's <= 8 strided outputs in the bitmap
+//                     of level l+1.  All three only read finished structures.
 //   rb_count_kernel   set bits per 256-word bitmap block + per 64-block super-block.
 //   rb_emit_kernel    ordered compaction of the bitmap: every workgroup sums the (super-)counters before it (a few
 //                     hundred L2-resident ints; no single-workgroup scan pass and no inter-workgroup waiting -- a
@@ -224,8 +223,7 @@ __device__ __forceinline__ int lookup_row(const Lookup &L, unsigned key)
         const int r = L.rank[key >> 5] + __popc(w & (b - 1));
         return r < L.cap ? r : -1;
     }
-    const int e = hash_find(L.hv.keys, L.hv.mask, key);
-    return e >= 0 ? L.hv.vals[e] : -1;
+    return hash2_lookup(L.hv.ent, L.hv.mask, key);
 }
 
 struct LevelArgs {
@@ -239,33 +237,73 @@ struct LevelArgs {
     int OD, OH, OW;
 };
 
+// three lookups along x (keys base + x0 .. base + x0 + 2, columns outside [0, W) = no voxel) in one go: with the bitmap
+// index the three cells share one 32-cell word 15 times out of 16, so a row's 27 neighbours cost 9-10 word + rank loads
+// instead of 54; the hash index (level 0) has nothing to share
+__device__ __forceinline__ void lookup3(const Lookup &L, unsigned base, int x0, int W, int (&r)[3])
+{
+    r[0] = r[1] = r[2] = -1;
+    if (L.bitmap) {
+        const int xa = max(x0, 0), xc = min(x0 + 2, W - 1);
+        if (xa > xc) return;
+        const unsigned ka = base + (unsigned)xa, kc = base + (unsigned)xc;
+        const unsigned wa = L.bitmap[ka >> 5];
+        const int ra = L.rank[ka >> 5];
+        unsigned wc = wa;
+        int rc = ra;
+        if ((kc >> 5) != (ka >> 5)) { wc = L.bitmap[kc >> 5]; rc = L.rank[kc >> 5]; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int x = x0 + d;
+            if (x < 0 || x >= W) continue;
+            const unsigned key = base + (unsigned)x;
+            const bool first = (key >> 5) == (ka >> 5);
+            const unsigned w = first ? wa : wc, b = 1u << (key & 31);
+            if (w & b) {
+                const int row = (first ? ra : rc) + __popc(w & (b - 1));
+                r[d] = row < L.cap ? row : -1;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int x = x0 + d;
+            if (x >= 0 && x < W) r[d] = hash2_lookup(L.hv.ent, L.hv.mask, base + (unsigned)x);
+        }
+    }
+}
+
+// one thread per (row of level l, (kz, ky)): the three x-offsets of the subm table of level l and of the strided table
+// INTO level l, and -- threads g < 8 -- the marks of the row's <= 8 strided outputs in the bitmap of level l+1
 __global__ void __launch_bounds__(256) rb_level_kernel(LevelArgs A)
 {
     const int n = min(*A.n_ptr, A.cap);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * 27) return;
-    const int row = t / 27, k = t - row * 27;
+    if (t >= n * 9) return;
+    const int row = t / 9, g = t - row * 9;
     const int4 c = ((const int4 *)A.idx)[row];
-    const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+    const int kz = g / 3, ky = g - kz * 3;
     if (A.nbr_subm) {
-        const int z = c.y + kz - 1, y = c.z + ky - 1, x = c.w + kx - 1;
-        int r = -1;
-        if (k == 13) r = row;
-        else if (z >= 0 && z < A.D && y >= 0 && y < A.H && x >= 0 && x < A.W)
-            r = lookup_row(A.cur, (((unsigned)c.x * A.D + z) * A.H + y) * A.W + x);
-        A.nbr_subm[t] = r;
+        const int z = c.y + kz - 1, y = c.z + ky - 1;
+        int r[3] = {-1, -1, -1};
+        if (z >= 0 && z < A.D && y >= 0 && y < A.H)
+            lookup3(A.cur, (((unsigned)c.x * A.D + z) * A.H + y) * A.W, c.w - 1, A.W, r);
+        if (g == 4) r[1] = row;                              // the centre offset (k = 13) is the row itself
+        int32_t *dst = A.nbr_subm + (size_t)row * 27 + g * 3;
+        dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2];
     }
     if (A.nbr_down) {
-        const int z = 2 * c.y - 1 + kz, y = 2 * c.z - 1 + ky, x = 2 * c.w - 1 + kx;
-        int r = -1;
-        if (z >= 0 && z < A.pD && y >= 0 && y < A.pH && x >= 0 && x < A.pW)
-            r = lookup_row(A.prev, (((unsigned)c.x * A.pD + z) * A.pH + y) * A.pW + x);
-        A.nbr_down[t] = r;
+        const int z = 2 * c.y - 1 + kz, y = 2 * c.z - 1 + ky;
+        int r[3] = {-1, -1, -1};
+        if (z >= 0 && z < A.pD && y >= 0 && y < A.pH)
+            lookup3(A.prev, (((unsigned)c.x * A.pD + z) * A.pH + y) * A.pW, 2 * c.w - 1, A.pW, r);
+        int32_t *dst = A.nbr_down + (size_t)row * 27 + g * 3;
+        dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2];
     }
-    if (A.bitmap_next && k < 8) {
+    if (A.bitmap_next && g < 8) {
         int oz[2], oy[2], ox[2];
         const int nz = axis_outs(c.y, A.OD, oz), ny = axis_outs(c.z, A.OH, oy), nx = axis_outs(c.w, A.OW, ox);
-        const int a = k & 1, b = (k >> 1) & 1, e = k >> 2;
+        const int a = g & 1, b = (g >> 1) & 1, e = g >> 2;
         if (a < nz && b < ny && e < nx) {
             const unsigned lin = (((unsigned)c.x * A.OD + oz[a]) * A.OH + oy[b]) * A.OW + ox[e];
             atomicOr(&A.bitmap_next[lin >> 5], 1u << (lin & 31));
@@ -346,9 +384,9 @@ bool pyramid_layout(int levels, const int *caps, int D, int H, int W, int B, Pyr
 {
     if (levels < 1 || levels > kMaxLevels) return false;
     size_t o = 0;
-    L.keys = o; o += align_up((size_t)hash_cap(caps[0]) * 4, 256);          // level-0 hash only
+    L.keys = o; o += align_up((size_t)hash_cap(caps[0]) * 8, 256);          // level-0 hash only: {key, value} entries
     L.keys_end = o;
-    L.vals = o; o += align_up((size_t)hash_cap(caps[0]) * 4, 256);
+    L.vals = o;
     L.zero_begin = o;
     L.dims[0][0] = D; L.dims[0][1] = H; L.dims[0][2] = W;
     if (!lin_fits(D, H, W, B)) return false;
@@ -379,7 +417,7 @@ extern "C" int sassd_hash_build(const int32_t *indices, const int32_t *n_ptr, in
     if (table_bytes < sassd_hash_bytes(cap)) return SASSD_ENOSPC;
     HashView hv = hash_view(table, cap);
     int rc;
-    if ((rc = sassd_hip(hipMemsetAsync(hv.keys, 0xFF, (size_t)(hv.mask + 1) * 4, stream)))) return rc;
+    if ((rc = sassd_hip(hipMemsetAsync(hv.ent, 0xFF, (size_t)(hv.mask + 1) * 8, stream)))) return rc;
     hipLaunchKernelGGL(hash_build_kernel, dim3(cdiv(cap, 256)), dim3(256), 0, stream, indices, n_ptr, cap, D, H, W,
                        hv, status);
     return sassd_launch_status();
@@ -492,7 +530,7 @@ extern "C" int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32
         look[l].cap = caps[l];
         if (l == 0) {
             look[l].bitmap = nullptr; look[l].rank = nullptr;
-            look[l].hv.keys = (unsigned *)(w + L.keys); look[l].hv.vals = (int *)(w + L.vals);
+            look[l].hv.ent = (uint2 *)(w + L.keys);
             look[l].hv.mask = hash_cap(caps[0]) - 1;
         } else {
             look[l].bitmap = (const unsigned *)(w + L.bitmap[l - 1]);
@@ -527,7 +565,7 @@ extern "C" int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32
         A.bitmap_next = last ? nullptr : (unsigned *)(w + L.bitmap[l]);
         A.OD = last ? 1 : L.dims[l + 1][0]; A.OH = last ? 1 : L.dims[l + 1][1]; A.OW = last ? 1 : L.dims[l + 1][2];
         if (A.nbr_subm || A.nbr_down || A.bitmap_next)
-            hipLaunchKernelGGL(rb_level_kernel, dim3(cdiv(caps[l] * 27, 256)), dim3(256), 0, stream, A);
+            hipLaunchKernelGGL(rb_level_kernel, dim3(cdiv(caps[l] * 9, 256)), dim3(256), 0, stream, A);
         if (!last)
             hipLaunchKernelGGL(rb_count_kernel, dim3(L.nblk[l]), dim3(256), 0, stream,
                                (const unsigned *)(w + L.bitmap[l]), L.nwords[l], (int *)(w + L.bcnt[l]),

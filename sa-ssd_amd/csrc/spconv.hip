@@ -558,7 +558,8 @@ int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap,
 }
 
 // forward / data-gradient dispatch: gather-GEMM-scatter for 27-offset layers with Cin >= 16, the streaming kernel for the
-// 1x1x1 layer, the register-stationary kernel for the 4-channel input layer and when the legacy switch (debug bit 8) is set
+// 1x1x1 layer, the row-per-16-threads kernel for the 4-channel input layer, the register-stationary kernel when the legacy
+// switch (debug bit 8) is set
 template <int CIN, int COUT>
 int launch_conv(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp, int K,
                 const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
@@ -566,6 +567,9 @@ int launch_conv(const float *x, const int32_t *nbr, const int32_t *n_ptr, int ca
     if constexpr (CIN >= 16) {
         if (nbr && !(g_spconv_dbg & 256)) return launch_gs<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, stream);
         if (!nbr && !(g_spconv_dbg & 256)) return launch_pw<CIN, COUT>(x, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    }
+    if constexpr (CIN == 4) {
+        if (nbr && !(g_spconv_dbg & 256)) return launch_c4<COUT>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     }
     return launch_fwd<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, stream);
 }

@@ -423,3 +423,51 @@ int launch_pw(const float *x, const int32_t *n_ptr, int cap, const float *wp, co
     hipLaunchKernelGGL((spconv_pw_kernel<CIN, COUT>), dim3(grid), dim3(256), 0, stream, x, n_ptr, cap, wp, scale, shift, relu, y);
     return sassd_launch_status();
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The 4-channel input layer (cmn.py:197 conv0[0]: SubMConv3d(4, 16, 3) on the per-voxel means).  108 multiply-adds per
+// output value: nothing for a matrix core to do -- the register-stationary MFMA kernel padded 4 input channels into
+// 16x16x4 steps and took 31 us for 129 k rows.  Here 16 consecutive threads own one output row (one output channel
+// each): the row's rulebook record and its neighbours' 16-byte feature rows are read once per 16 threads (the same
+// address in all of them: one request), W[k][0..3][co] is one conflict-free 16-byte LDS read (the pack [K][1][COUT][4]
+// IS that layout), k ascending -- a fixed summation order.  Latency is hidden by occupancy (few registers, no LDS
+// beyond the 6.9 KB of weights), not by a software pipeline.
+// ------------------------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ void __launch_bounds__(256)
+spconv_c4_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_ptr, int cap,
+                 const float *__restrict__ wp, const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                 float *__restrict__ y)
+{
+    __shared__ float4 ws[kK * COUT];
+    for (int i = threadIdx.x; i < kK * COUT; i += 256) ws[i] = ((const float4 *)wp)[i];
+    __syncthreads();
+    const int n = min(*n_ptr, cap);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int row = t / COUT, co = t - row * COUT;
+    if (row >= n) return;
+    const int32_t *nb = nbr + (size_t)row * kK;
+    float acc = 0.f;
+#pragma unroll 9
+    for (int k = 0; k < kK; ++k) {
+        const int in = nb[k];
+        if (in >= 0) {
+            const float4 xv = *(const float4 *)(x + (size_t)in * 4);
+            const float4 wv = ws[k * COUT + co];
+            acc = fmaf(xv.w, wv.w, fmaf(xv.z, wv.z, fmaf(xv.y, wv.y, fmaf(xv.x, wv.x, acc))));
+        }
+    }
+    float o = acc * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+    if (relu) o = fmaxf(o, 0.f);
+    y[(size_t)row * COUT + co] = o;
+}
+
+template <int COUT>
+int launch_c4(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp, const float *scale,
+              const float *shift, int relu, float *y, hipStream_t stream)
+{
+    hipLaunchKernelGGL((spconv_c4_kernel<COUT>), dim3(cdiv(cap * COUT, 256)), dim3(256), 0, stream, x, nbr, n_ptr, cap, wp,
+                       scale, shift, relu, y);
+    return sassd_launch_status();
+}

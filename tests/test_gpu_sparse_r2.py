@@ -312,3 +312,31 @@ def test_submanifold_data_gradient_on_forward_rulebook(dev, cin, cout):
     assert (got[True][0] - xr.grad).abs().max().item() < tol
     assert (got[False][0] - xr.grad).abs().max().item() < tol
     assert (got[True][1] - wr.grad).abs().max().item() < 2e-4 * max(1.0, wr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_spconv_input_layer_kernel(dev, legacy):
+    """The 4-channel input layer (cmn.py:197, SubMConv3d(4, 16, 3)) on the row-per-16-threads kernel (and on the
+    register-stationary MFMA kernel it replaced, debug bit 8): full K21 level-0 table, device row count below the capacity,
+    rows past it untouched, folded scale / shift / ReLU."""
+    idx = _level0("k21", 0)
+    _, nbr = orb.subm_rulebook(idx, (40, 1600, 1408))
+    n = len(nbr)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, 4, generator=g)
+    w = torch.randn(27, 4, 16, generator=g) * 0.3
+    scale, shift = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
+    raw = onets.sparse_conv(x, nbr, w)
+    cap = n + 777
+    nb = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+    nb[:n] = torch.from_numpy(nbr).to(dev)
+    nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+    K.debug_set_spconv(256 if legacy else 0)
+    try:
+        y = torch.full((cap, 16), 9.0, device=dev)
+        K.spconv_fwd(x.to(dev), nb, nptr, cap, K.spconv_pack_weight(w.to(dev)), 27, 4, 16, scale.to(dev), shift.to(dev), True, y)
+    finally:
+        K.debug_set_spconv(0)
+    ref = torch.relu(raw * scale + shift)
+    assert (y[:n].cpu() - ref).abs().max().item() < 2e-4 * max(1.0, raw.abs().max().item())
+    assert bool((y[n:] == 9.0).all())

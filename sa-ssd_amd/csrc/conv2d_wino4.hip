@@ -29,6 +29,8 @@
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
@@ -320,13 +322,89 @@ struct W4Gemm {
     int dbg;                 // ablation: bit0 stage only the first chunk, bit1 no MFMA
 };
 
-// WM x WN waves; a wave owns a 64 x (32 NB) block = 2 x NB accumulators of v_mfma_f32_32x32x2_f32.
-template <int WM, int WN, int NB, int KC>
-__global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
+// ---- fp32 products on the bf16 MFMA (SPLIT = 1) ------------------------------------------------------------------------
+// The fp32 MFMA runs at 1/16 of the bf16 MFMA's rate.  An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8
+// significand bits, split by truncation: a1 = top 16 bits of a, a2 = top 16 bits of a - a1, a3 = a - a1 - a2, every
+// subtraction exact), and a product of two bf16 values is exact in fp32.  v_mfma_f32_32x32x16_bf16 gives every lane 8
+// K-slots: lane (row, k-half) fills them with ONE channel's pieces,
+//     A side (a1, a1, a1, a2, a2, a2, a3, a3)   B side (w1, w2, w3, w1, w2, w3, w1, w2),
+// so that one instruction (32 cycles for two channels; the fp32 form needs 64) accumulates a w - a3 w3, i.e. the fp32
+// product to 2^-30, in fp32 -- the operands stay fp32 in HBM and LDS, the fragment reads are those of the fp32 kernel, and
+// the split costs 8 VALU instructions per fragment value (two masks, two subtractions, four byte permutes) that run
+// beside the other wave's MFMAs.  tools/probe_bf16x3.hip measures the error against fp64 next to the fp32 MFMA's.
+__device__ __forceinline__ void split3(const float a, unsigned &u0, unsigned &u1, unsigned &u2)
 {
-    constexpr int NWV = WM * WN, BM = 64 * WM, BN = 32 * NB * WN;
-    constexpr int STAGE = (BM + BN) * KC;
-    constexpr int NLA = KC * BM / 256, NLB = KC * BN / 256;          // 1 KB wave-loads per chunk
+    u0 = __float_as_uint(a);
+    const float r1 = a - __uint_as_float(u0 & 0xffff0000u);
+    u1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+    u2 = __float_as_uint(r2);                                   // (its low 16 bits are zero: 8 significant bits are left)
+}
+// v_perm_b32: [hi16(lo) | hi16(hi) << 16]
+__device__ __forceinline__ unsigned hi_pair(const unsigned lo, const unsigned hi)
+{
+    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+// K-slot convention (8 slots of one channel, low half of dword 0 first):
+//     A side  a1 a2 | a3 a1 | a1 a2 | a2 a3        B side  w1 w1 | w1 w2 | w3 w2 | w3 w2
+// i.e. every product of pieces except a3 w3.  The A dwords are S0 = [a1|a2], S1 = [a3|a1], S0 again and X = [a2|a3]: a weight
+// stored PRE-SPLIT as the 8 bytes (S0, S1) needs one move and one byte permute in the kernel instead of the eight
+// instructions of the full split (sassd_conv2d_wino4_pack_weight writes that image behind the fp32 one).
+__device__ __forceinline__ uint2 presplit_a(const float a)
+{
+    unsigned u0, u1, u2;
+    split3(a, u0, u1, u2);
+    return make_uint2(hi_pair(u0, u1), hi_pair(u2, u0));
+}
+__device__ __forceinline__ bf16x8 expand_a(const uint2 sp)
+{
+    u32x4 d;
+    d[0] = sp.x; d[1] = sp.y; d[2] = sp.x;
+    d[3] = __builtin_amdgcn_perm(sp.y, sp.x, 0x05040302u);      // [hi16(S0) | lo16(S1) << 16] = [a2|a3]
+    return __builtin_bit_cast(bf16x8, d);
+}
+__device__ __forceinline__ bf16x8 split_a(const float a) { return expand_a(presplit_a(a)); }
+__device__ __forceinline__ bf16x8 split_b(const float w)
+{
+    unsigned u0, u1, u2;
+    split3(w, u0, u1, u2);
+    u32x4 d;
+    d[0] = hi_pair(u0, u0); d[1] = hi_pair(u0, u1); d[2] = hi_pair(u2, u1); d[3] = d[2];
+    return __builtin_bit_cast(bf16x8, d);
+}
+
+// the pre-split image of the transformed weights: U2[i] = (S0, S1) of U[i]
+__global__ void wino4_presplit_kernel(const float *__restrict__ U, size_t n, uint2 *__restrict__ U2)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) U2[i] = presplit_a(U[i]);
+}
+
+// scheduling groups of one pipelined step: MFMA m, then the VALU work of its share of the next step's values (8 instructions
+// per value split in the kernel, 4 per pre-split A value: three moves into the operand quad and the permute)
+template <int M, int NM, int MT, int NB, int ACOST>
+__device__ __forceinline__ void split_sched()
+{
+    if constexpr (M < NM) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int NV = MT + NB, v0 = M * NV / NM, v1 = (M + 1) * NV / NM;
+        constexpr int na = (v1 < MT ? v1 : MT) - (v0 < MT ? v0 : MT);
+        constexpr int n = na * ACOST + (v1 - v0 - na) * 8;
+        if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x002, n, 0);
+        split_sched<M + 1, NM, MT, NB, ACOST>();
+    }
+}
+
+// WM x WN waves; a wave owns a 64 x (32 NB) block = 2 x NB accumulators of v_mfma_f32_32x32x2_f32 (SPLIT = 0) or of
+// v_mfma_f32_32x32x16_bf16 over split operands (SPLIT = 1: both operands split in the kernel; 3: the A operand arrives
+// pre-split, 8 bytes per weight; 2: ablation without the split arithmetic).
+template <int WM, int WN, int NB, int KC, int SPLIT, int MT>
+__device__ __forceinline__ void w4_gemm_body(const W4Gemm &P)
+{
+    constexpr int NWV = WM * WN, WROWS = 32 * MT, BM = WROWS * WM, BN = 32 * NB * WN;
+    constexpr int AEL = SPLIT == 3 ? 2 : 1;                          // floats per A element in HBM / LDS
+    constexpr int STAGE = (BM * AEL + BN) * KC;
+    constexpr int NLA = KC * BM * AEL / 256, NLB = KC * BN / 256;    // 1 KB wave-loads per chunk
     constexpr int LPW = (NLA + NLB + NWV - 1) / NWV;                 // ... per wave
     extern __shared__ __attribute__((aligned(16))) float w4_lds[];   // [2][A KC x BM | B KC x BN]
     float *lds = w4_lds;
@@ -341,7 +419,7 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
     const int pair = item / P.nseg, nb = (item - pair * P.nseg) * P.seglen + within;
     if (nb >= P.nnb) return;
     const int p = pair / P.nmb, mb = pair - p * P.nmb;
-    const float *Ub = P.U + (size_t)p * P.su + mb * BM;                    // + k * Cout
+    const float *Ub = P.U + (size_t)p * P.su + mb * BM * AEL;              // + k * Cout * AEL
     const float *Vb = P.V + (size_t)p * P.sv + nb * BN;                    // + k * ldv
     // DMA map: wave-load id t = wave + NWV * i; t < NLA: A rows (BM/4 16-byte pieces per row), else B rows.  The LDS
     // destination of a wave-load is lane-linear, i.e. the natural row-major [k][m] / [k][n] image.
@@ -353,14 +431,14 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
         const int t = wave + NWV * i;
         if (t < NLA) {
             const int e = t * 64 + lane;
-            src[i] = Ub + (size_t)(e / (BM / 4)) * P.Cout + (e % (BM / 4)) * 4;
-            kstride[i] = (size_t)KC * P.Cout;
+            src[i] = Ub + (size_t)(e / (BM * AEL / 4)) * P.Cout * AEL + (e % (BM * AEL / 4)) * 4;
+            kstride[i] = (size_t)KC * P.Cout * AEL;
             dst[i] = t * 256;
         } else {
             const int e = (t - NLA) * 64 + lane;
             src[i] = Vb + (size_t)(e / (BN / 4)) * P.ldv + (e % (BN / 4)) * 4;
             kstride[i] = (size_t)KC * P.ldv;
-            dst[i] = BM * KC + (t - NLA) * 256;
+            dst[i] = BM * AEL * KC + (t - NLA) * 256;
         }
     }
     auto dma = [&](int chunk, float *stage) {
@@ -372,9 +450,9 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
     };
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, kh = lane >> 5;
-    f32x16 acc[2][NB];
+    f32x16 acc[MT][NB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -385,40 +463,114 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
     for (int c = 0; c < nchunk; ++c) {
         float *cur = lds + (c & 1) * STAGE;
         if (c + 1 < nchunk && !(P.dbg & 1)) dma(c + 1, lds + ((c + 1) & 1) * STAGE);
-        const float *As = cur + kh * BM + wm * 64 + l31;                      // + 2*kk*BM
-        const float *Bs = cur + BM * KC + kh * BN + wn * 32 * NB + l31;       // + 2*kk*BN
-        if (!(P.dbg & 2)) {
+        const float *As = cur + (kh * BM + wm * WROWS + l31) * AEL;           // + 2*kk*BM*AEL
+        const float *Bs = cur + BM * AEL * KC + kh * BN + wn * 32 * NB + l31; // + 2*kk*BN
+        // (no run-time switches inside the split loop: a second path makes the compiler park the accumulators in the other
+        // register file across the chunk loop, 128 v_accvgpr moves per chunk)
+        if constexpr (SPLIT != 0) {
+            if constexpr (SPLIT == 1 || SPLIT == 3) {
+                // Software pipeline inside the chunk: the fragment values of step kk + 1 are read and split while the MFMAs of
+                // step kk issue, one share of the split arithmetic behind every MFMA (the compiler's own order is all MFMAs
+                // of a step back to back, then all the VALU work: a wave cannot issue past its own queued MFMA, so nothing of
+                // its split overlaps its MFMAs).
+                constexpr int NK = KC / 2, NV = MT + NB, NM = MT * NB;
+                u32x4 raw[NV];
+                bf16x8 fr[2][NV];
+                auto rd = [&](const int kk) {
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) {
+                        if constexpr (AEL == 2) {
+                            const uint2 sp = *reinterpret_cast<const uint2 *>(As + (2 * kk * BM + 32 * a) * 2);
+                            raw[a][0] = sp.x; raw[a][1] = sp.y; raw[a][2] = sp.x; raw[a][3] = sp.y;
+                        } else raw[a][0] = __float_as_uint(As[2 * kk * BM + 32 * a]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) raw[MT + b][0] = __float_as_uint(Bs[2 * kk * BN + 32 * b]);
+                };
+                auto mk = [&](const int v) -> bf16x8 {
+                    if (v >= MT) return split_b(__uint_as_float(raw[v][0]));
+                    if constexpr (AEL == 2) {
+                        u32x4 d = raw[v];
+                        d[3] = __builtin_amdgcn_perm(d[3], d[2], 0x05040302u);      // [hi16(S0) | lo16(S1) << 16] = [a2|a3]
+                        return __builtin_bit_cast(bf16x8, d);
+                    } else return split_a(__uint_as_float(raw[v][0]));
+                };
+                rd(0);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) fr[0][v] = mk(v);
+#pragma unroll
+                for (int kk = 0; kk < NK; ++kk) {
+                    const int cur = kk & 1, nxt = cur ^ 1;
+                    const bool more = kk + 1 < NK;
+                    if (more) rd(kk + 1);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) {
+                            const int m = b * MT + a;
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[cur][a], fr[cur][MT + b], acc[a][b], 0, 0, 0);
+                            if (more) {
+#pragma unroll
+                                for (int v = m * NV / NM; v < (m + 1) * NV / NM; ++v) fr[nxt][v] = mk(v);
+                            }
+                        }
+                    if (more) split_sched<0, NM, MT, NB, (AEL == 2 ? 4 : 8)>();
+                }
+            } else {                                    // ablation (SPLIT = 2): the same reads and MFMAs without the split arithmetic
+#pragma unroll
+                for (int kk = 0; kk < KC / 2; ++kk) {
+                    bf16x8 av[MT];
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) {
+                        const unsigned xa = __float_as_uint(As[2 * kk * BM + 32 * a]);
+                        const u32x4 d = {xa, xa, xa, xa};
+                        av[a] = __builtin_bit_cast(bf16x8, d);
+                    }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const unsigned xb = __float_as_uint(Bs[2 * kk * BN + 32 * b]);
+                        const u32x4 db = {xb, xb, xb, xb};
+#pragma unroll
+                        for (int a = 0; a < MT; ++a)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], __builtin_bit_cast(bf16x8, db), acc[a][b],
+                                                                                0, 0, 0);
+                    }
+                }
+            }
+        } else if (!(P.dbg & 2)) {
 #pragma unroll
             for (int kk = 0; kk < KC / 2; ++kk) {
-                const float a0 = As[2 * kk * BM], a1 = As[2 * kk * BM + 32];
+                float av[MT];
+#pragma unroll
+                for (int a = 0; a < MT; ++a) av[a] = As[2 * kk * BM + 32 * a];
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     const float bv = Bs[2 * kk * BN + 32 * b];
-                    acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][b], 0, 0, 0);
-                    acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][b], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv, acc[a][b], 0, 0, 0);
                 }
             }
         }
         __syncthreads();                                // (the compiler drains vmcnt: chunk c+1 has landed)
     }
     // Epilogue through LDS (the staging buffers are dead): D[row = (r & 3) + 8 * (r >> 2) + 4 * kh][col = l31] goes to the
-    // wave's [64][32 NB] image, then 16-byte row stores (a dword store per accumulator register is ~6x slower per byte)
+    // wave's [32 MT][32 NB] image, then 16-byte row stores (a dword store per accumulator register is ~6x slower per byte)
     constexpr int WCOLS = 32 * NB;
-    float *img = lds + wave * 64 * WCOLS;
+    float *img = lds + wave * WROWS * WCOLS;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 img[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * WCOLS + b * 32 + l31] = acc[a][b][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private image: no barrier needed
-    const int co0 = mb * BM + wm * 64;
+    const int co0 = mb * BM + wm * WROWS;
     float *Mb = P.M + (size_t)p * P.sm + (size_t)co0 * P.ldm + nb * BN + wn * WCOLS;
     constexpr int C4 = WCOLS / 4, RPI = 64 / C4;        // float4 per row, rows per wave-instruction
     const bool epi = P.scale || P.shift || P.relu;
 #pragma unroll
-    for (int i = 0; i < 64 / RPI; ++i) {
+    for (int i = 0; i < WROWS / RPI; ++i) {
         const int row = i * RPI + lane / C4, c4 = lane % C4;
         float4 v = *reinterpret_cast<const float4 *>(img + row * WCOLS + c4 * 4);
         if (epi) {
@@ -430,16 +582,39 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
     }
 }
 
-int g_wino4_cfg = 0, g_wino4_dbg = 0;
+template <int WM, int WN, int NB, int KC, int SPLIT, int MT>
+__global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
+{
+    w4_gemm_body<WM, WN, NB, KC, SPLIT, MT>(P);
+}
+// the 128-row wave tile (128 accumulator registers) held to two waves per SIMD
+template <int WM, int WN, int NB, int KC, int SPLIT, int MT>
+__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) wino4_gemm_tall_kernel(W4Gemm P)
+{
+    w4_gemm_body<WM, WN, NB, KC, SPLIT, MT>(P);
+}
 
-template <int WM, int WN, int NB, int KC>
+int g_wino4_cfg = 0, g_wino4_dbg = 0;
+constexpr bool g_wino4_split_default = false;
+
+template <int WM, int WN, int NB, int KC, int SPLIT = 0, int MT = 2>
 int launch_w4_gemm(W4Gemm P, hipStream_t stream)
 {
-    constexpr int BM = 64 * WM, BN = 32 * NB * WN;
-    constexpr size_t stage_b = (size_t)2 * (BM + BN) * KC * 4, img_b = (size_t)WM * WN * 64 * 32 * NB * 4;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NB * WN;
+    static_assert(BM == kBM, "the channel block is fixed: w4_pick_* and the supported() checks price it");
+    constexpr int AEL = SPLIT == 3 ? 2 : 1;
+    constexpr size_t stage_b = (size_t)2 * (BM * AEL + BN) * KC * 4, img_b = (size_t)WM * WN * 32 * MT * 32 * NB * 4;
     constexpr size_t lds = stage_b > img_b ? stage_b : img_b;        // the epilogue image reuses the staging buffers
+    if constexpr (SPLIT == 1)
+        if (g_wino4_dbg & 4) return launch_w4_gemm<WM, WN, NB, KC, 2, MT>(P, stream);      // ablation instance
+    if constexpr (SPLIT == 3) {                          // the pre-split image sits behind the np fp32 problems
+        P.U += (size_t)P.np * P.su;
+        P.su *= 2;
+    }
     static std::atomic<unsigned long long> attr_done{0};
-    const void *fn = (const void *)wino4_gemm_kernel<WM, WN, NB, KC>;
+    const void *fn;
+    if constexpr (MT == 4) fn = (const void *)wino4_gemm_tall_kernel<WM, WN, NB, KC, SPLIT, MT>;
+    else fn = (const void *)wino4_gemm_kernel<WM, WN, NB, KC, SPLIT, MT>;
     int rc = sassd_dyn_lds(fn, lds, attr_done);
     if (rc) return rc;
     P.nmb = P.Cout / BM; P.nnb = P.ncols / BN;
@@ -450,8 +625,12 @@ int launch_w4_gemm(W4Gemm P, hipStream_t stream)
     P.seglen = cdiv(P.nnb, P.nseg);
     P.pairs_per_xcd = cdiv(pairs * P.nseg, 8);
     P.dbg = g_wino4_dbg;
-    hipLaunchKernelGGL((wino4_gemm_kernel<WM, WN, NB, KC>), dim3(8 * P.pairs_per_xcd * P.seglen), dim3(WM * WN * 64), lds,
-                       stream, P);
+    if constexpr (MT == 4)
+        hipLaunchKernelGGL((wino4_gemm_tall_kernel<WM, WN, NB, KC, SPLIT, MT>), dim3(8 * P.pairs_per_xcd * P.seglen),
+                           dim3(WM * WN * 64), lds, stream, P);
+    else
+        hipLaunchKernelGGL((wino4_gemm_kernel<WM, WN, NB, KC, SPLIT, MT>), dim3(8 * P.pairs_per_xcd * P.seglen),
+                           dim3(WM * WN * 64), lds, stream, P);
     return sassd_launch_status();
 }
 
@@ -477,13 +656,96 @@ inline int w4_pick_wn(int T, int Cout, int np = 36, bool exact = false)
     return best;
 }
 
-inline int w4_wn(int T, int Cout) { return (g_wino4_cfg >= 2 && g_wino4_cfg <= 6) ? g_wino4_cfg : w4_pick_wn(T, Cout); }
+// Geometry of the Winograd GEMM launch: SPLIT (fp32 products on the bf16 MFMA, wave tile 64 x 64) or the fp32 MFMA (wave tile
+// 64 x 32), WN waves across the tile columns.  g_wino4_cfg: 0 = default, 2..6 = fp32 MFMA with 32*cfg columns,
+// 11..13 = split with 64*(cfg-10) columns, 14 = split / 128 columns / 16-channel chunks, 15 = split on the 64 x 32 wave tile,
+// 16 / 17 = split, two waves of 128 x 64 (16- / 32-channel chunks), 18 = four waves of 128 x 64 (256 columns),
+// 21..25 = split with the weights pre-split (w4_tile below),
+// 1 = fp32 MFMA with the picked width (the round-3 default).
+struct W4Tile {
+    int split, wn, nb, kc, mt;
+    int bn() const { return 32 * nb * wn; }
+};
+inline int w4_pick_split_wn(int T, int Cout)
+{
+    int best = 2;
+    double best_cost = 1e30;
+    for (int wn = 1; wn <= 3; ++wn) {
+        const int bn = 64 * wn;
+        const size_t lds = (size_t)2 * (kBM + bn) * kKC * 4;
+        int wgs = (int)((size_t)160 * 1024 / (lds + 1024));             // (co-residency at exactly 160 KB is not relied on)
+        if (wgs > 8 / (2 * wn)) wgs = 8 / (2 * wn);                     // at most two waves per SIMD
+        if (wgs < 1) wgs = 1;
+        const long units = (long)36 * (Cout / kBM) * cdiv(T, bn);
+        const long rounds = (units + 256L * wgs - 1) / (256L * wgs);
+        const double cost = (double)rounds * wgs * bn;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = wn; }
+    }
+    return best;
+}
+inline W4Tile w4_tile(int T, int Cout)
+{
+    const int c = g_wino4_cfg;
+    if (c >= 2 && c <= 6) return W4Tile{0, c, 1, kKC, 2};
+    if (c >= 11 && c <= 13) return W4Tile{1, c - 10, 2, kKC, 2};
+    if (c == 14) return W4Tile{1, 2, 2, 16, 2};
+    if (c == 15) return W4Tile{1, 4, 1, kKC, 2};
+    if (c == 16) return W4Tile{1, 2, 2, 16, 4};
+    if (c == 17) return W4Tile{1, 2, 2, kKC, 4};
+    if (c == 18) return W4Tile{1, 4, 2, 16, 4};
+    if (c == 21) return W4Tile{3, 2, 2, 16, 2};       // pre-split weights: 128 x 128, 16-channel chunks (48 KB: three per CU)
+    if (c == 22) return W4Tile{3, 1, 2, 16, 2};       //                    128 x 64
+    if (c == 23) return W4Tile{3, 3, 2, 16, 2};       //                    128 x 192
+    if (c == 24) return W4Tile{3, 2, 2, kKC, 2};      //                    128 x 128, 32-channel chunks (96 KB: one per CU)
+    if (c == 25) return W4Tile{3, 2, 2, 16, 4};       //                    two waves of 128 x 64
+    if (c == 26) return W4Tile{3, 4, 2, 16, 2};       //                    128 x 256, eight waves (64 KB: two per CU)
+    if (c == 27) return W4Tile{3, 4, 2, kKC, 2};      //                    128 x 256, 32-channel chunks (128 KB: one per CU)
+    if (c == 19) return W4Tile{1, 4, 2, 16, 2};       // split in the kernel, 128 x 256, eight waves (48 KB)
+    if (c == 20) return W4Tile{1, 4, 2, kKC, 2};      //                      32-channel chunks (96 KB: one per CU)
+    if (c == 1 || !g_wino4_split_default) return W4Tile{0, w4_pick_wn(T, Cout), 1, kKC, 2};
+    return W4Tile{1, w4_pick_split_wn(T, Cout), 2, kKC, 2};
+}
 
 inline int w4_tiles_padded(int B, int H, int W, int Cout)
 {
     const int T = B * (H / 4) * (W / 4);
-    const int bn = 32 * w4_wn(T, Cout);
+    const int bn = w4_tile(T, Cout).bn();
     return cdiv(T, bn) * bn;
+}
+
+inline int w4_launch(const W4Tile t, const W4Gemm &P, hipStream_t stream)
+{
+    if (t.split == 3) {
+        if (t.mt == 4) return launch_w4_gemm<1, 2, 2, 16, 3, 4>(P, stream);
+        if (t.wn == 4) return t.kc == 16 ? launch_w4_gemm<2, 4, 2, 16, 3>(P, stream) : launch_w4_gemm<2, 4, 2, kKC, 3>(P, stream);
+        if (t.kc == kKC) return launch_w4_gemm<2, 2, 2, kKC, 3>(P, stream);
+        switch (t.wn) {
+        case 1: return launch_w4_gemm<2, 1, 2, 16, 3>(P, stream);
+        case 2: return launch_w4_gemm<2, 2, 2, 16, 3>(P, stream);
+        default: return launch_w4_gemm<2, 3, 2, 16, 3>(P, stream);
+        }
+    }
+    if (t.split) {
+        if (t.mt == 4) {
+            if (t.wn == 4) return launch_w4_gemm<1, 4, 2, 16, 1, 4>(P, stream);
+            return t.kc == 16 ? launch_w4_gemm<1, 2, 2, 16, 1, 4>(P, stream) : launch_w4_gemm<1, 2, 2, kKC, 1, 4>(P, stream);
+        }
+        if (t.wn == 4 && t.nb == 2) return t.kc == 16 ? launch_w4_gemm<2, 4, 2, 16, 1>(P, stream) : launch_w4_gemm<2, 4, 2, kKC, 1>(P, stream);
+        if (t.kc == 16) return launch_w4_gemm<2, 2, 2, 16, 1>(P, stream);
+        if (t.nb == 1) return launch_w4_gemm<2, 4, 1, kKC, 1>(P, stream);
+        switch (t.wn) {
+        case 1: return launch_w4_gemm<2, 1, 2, kKC, 1>(P, stream);
+        case 2: return launch_w4_gemm<2, 2, 2, kKC, 1>(P, stream);
+        default: return launch_w4_gemm<2, 3, 2, kKC, 1>(P, stream);
+        }
+    }
+    switch (t.wn) {                                                      // 128 channels x 32 WN tiles, 2 x WN waves of 64 x 32
+    case 2: return launch_w4_gemm<2, 2, 1, kKC>(P, stream);
+    case 3: return launch_w4_gemm<2, 3, 1, kKC>(P, stream);
+    case 4: return launch_w4_gemm<2, 4, 1, kKC>(P, stream);
+    case 5: return launch_w4_gemm<2, 5, 1, kKC>(P, stream);
+    default: return launch_w4_gemm<2, 6, 1, kKC>(P, stream);
+    }
 }
 
 }  // namespace
@@ -502,7 +764,7 @@ extern "C" int sassd_conv2d_wino4_supported(int Cin, int Cout, int H, int W)
 extern "C" size_t sassd_conv2d_wino4_packed_floats(int Cin, int Cout)
 {
     if (Cin < 1 || Cout < 1) return 0;
-    return (size_t)36 * Cin * Cout;
+    return (size_t)3 * 36 * Cin * Cout;                  // fp32 image [36][Cin][Cout], then the pre-split one (8 bytes per weight)
 }
 
 extern "C" int sassd_conv2d_wino4_pack_weight(const float *w, int Cout, int Cin, float *packed, void *stream_)
@@ -510,6 +772,9 @@ extern "C" int sassd_conv2d_wino4_pack_weight(const float *w, int Cout, int Cin,
     if (!w || !packed || Cin < 1 || Cout < 1) return SASSD_EINVAL;
     hipLaunchKernelGGL(wino4_pack_kernel, dim3(cdiv(Cout * Cin, 256)), dim3(256), 0, (hipStream_t)stream_, w, Cout, Cin,
                        packed);
+    const size_t n = (size_t)36 * Cin * Cout;
+    hipLaunchKernelGGL(wino4_presplit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                       (const float *)packed, n, (uint2 *)(packed + n));
     return sassd_launch_status();
 }
 
@@ -517,7 +782,7 @@ extern "C" size_t sassd_conv2d_wino4_workspace_bytes(int batch, int Cin, int Cou
 {
     if (!sassd_conv2d_wino4_supported(Cin, Cout, H, W) || batch < 1) return 0;
     // (sized for the widest tile block, so that a forced geometry never outgrows a caller's buffer)
-    const size_t Tp = (size_t)cdiv(batch * (H / 4) * (W / 4), 192) * 192 + 192;
+    const size_t Tp = (size_t)cdiv(batch * (H / 4) * (W / 4), 256) * 256 + 256;
     return align_up(36 * (size_t)Cin * Tp * 4, 256) + align_up(36 * (size_t)Cout * Tp * 4, 256);
 }
 
@@ -544,13 +809,7 @@ extern "C" int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, con
     P.np = 36; P.Cin = Cin; P.Cout = Cout; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;
     P.su = (size_t)Cin * Cout; P.sv = (size_t)Cin * G.Tp; P.sm = (size_t)Cout * G.Tp;
     int rc = SASSD_OK;
-    if (!(g_wino4_dbg & 32)) switch (w4_wn(G.T, Cout)) {                                      // 128 channels x 32 WN tiles, 2 x WN waves of 64 x 32
-    case 2: rc = launch_w4_gemm<2, 2, 1, kKC>(P, stream); break;
-    case 3: rc = launch_w4_gemm<2, 3, 1, kKC>(P, stream); break;
-    case 4: rc = launch_w4_gemm<2, 4, 1, kKC>(P, stream); break;
-    case 5: rc = launch_w4_gemm<2, 5, 1, kKC>(P, stream); break;
-    default: rc = launch_w4_gemm<2, 6, 1, kKC>(P, stream); break;
-    }
+    if (!(g_wino4_dbg & 32)) rc = w4_launch(w4_tile(G.T, Cout), P, stream);
     if (rc) return rc;
     W4Geom Go = G;
     Go.C = Cout;
@@ -575,7 +834,7 @@ extern "C" int sassd_conv2d_wino4_chain_supported(int Cin, int Cout, int H, int 
 extern "C" size_t sassd_conv2d_wino4_chain_workspace_bytes(int batch, int cmax, int H, int W)
 {
     if (batch < 1 || cmax < 1 || H < 4 || W < 4 || H % 4 || W % 4) return 0;
-    const size_t Tp = (size_t)cdiv(batch * (H / 4) * (W / 4), 192) * 192 + 192;          // widest tile block + slack
+    const size_t Tp = (size_t)cdiv(batch * (H / 4) * (W / 4), 256) * 256 + 256;          // widest tile block + slack
     return 2 * align_up(36 * (size_t)cmax * Tp * 4, 256);                              // V | M, each for cmax channels
 }
 
@@ -619,13 +878,7 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
     P.np = 36; P.Cin = Cin; P.Cout = Cout; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;
     P.su = (size_t)Cin * Cout; P.sv = (size_t)Cin * G.Tp; P.sm = (size_t)Cout * G.Tp;
     int rc = SASSD_OK;
-    if (!(g_wino4_dbg & 32)) switch (w4_wn(G.T, Cout)) {
-    case 2: rc = launch_w4_gemm<2, 2, 1, kKC>(P, stream); break;
-    case 3: rc = launch_w4_gemm<2, 3, 1, kKC>(P, stream); break;
-    case 4: rc = launch_w4_gemm<2, 4, 1, kKC>(P, stream); break;
-    case 5: rc = launch_w4_gemm<2, 5, 1, kKC>(P, stream); break;
-    default: rc = launch_w4_gemm<2, 6, 1, kKC>(P, stream); break;
-    }
+    if (!(g_wino4_dbg & 32)) rc = w4_launch(w4_tile(G.T, Cout), P, stream);
     if (rc) return rc;
     if (y && !(g_wino4_dbg & 64)) {
         W4Geom Go = G;

@@ -39,6 +39,36 @@ def test_conv2d_wino4(dev, b, cin, cout, hw, relu):
     assert not K.conv2d_wino4_supported(256, 128, 200, 176)
 
 
+@pytest.mark.parametrize("cfg", [1, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
+def test_conv2d_wino4_gemm_geometries(dev, cfg):
+    """Every launch geometry of the Winograd GEMM behind sassd_debug_set_wino4 -- 1 = the fp32 MFMA, 11..18 = fp32 products
+    on the bf16 MFMA over exactly-split operands (three bf16 pieces per fp32 value, eight of the nine piece products) --
+    against torch-CPU conv2d at the bar of the default path, on the KITTI BEV layer and on a ragged multi-image shape with
+    512 output channels.  The error of each is printed next to the fp32 MFMA's: the split path must not be the looser one
+    by more than 2x (it computes every product to 2^-30 and accumulates in fp32 like the fp32 instruction)."""
+    errs = {}
+    for shape in ((1, 256, 256, (200, 176)), (3, 96, 512, (20, 44))):
+        b, cin, cout, hw = shape
+        g = torch.Generator().manual_seed(cin + cout)
+        x = torch.randn(b, cin, *hw, generator=g)
+        x *= (torch.rand(b, cin, *hw, generator=g) > 0.5).float()
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        raw = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+        wp = K.conv2d_wino4_pack_weight(w.to(dev))
+        tol = 1e-4 * max(1.0, raw.abs().max().item())
+        for c in (1, cfg):
+            K.debug_set_wino4(c, 0)
+            try:
+                y = K.conv2d_wino4_fwd(x.to(dev), wp, cout)
+                torch.cuda.synchronize()
+            finally:
+                K.debug_set_wino4(0, 0)
+            errs[c] = (y.cpu().double() - raw).abs().max().item()
+            assert errs[c] <= tol, (c, shape, errs[c])
+        print("wino4 geometry %d %s: max abs err vs fp64 %.2e (fp32 MFMA %.2e, tol %.2e)" % (cfg, shape, errs[cfg], errs[1], tol))
+        assert errs[cfg] <= 2.0 * errs[1] + 1e-7
+
+
 @pytest.mark.parametrize("b,cin,cout,hw,relu", [(1, 256, 256, (200, 176), True), (2, 64, 128, (12, 16), False),
                                                 (3, 32, 384, (10, 32), True)])
 def test_conv1x1_gemm(dev, b, cin, cout, hw, relu):

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--cin", type=int, default=256)
 ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--cfgs", default="", help="comma-separated geometry numbers of sassd_debug_set_wino4 (default: all)")
 ap.add_argument("--profile", action="store_true", help="default geometry only, `reps` launches: the target of rocprofv3 "
                 "--kernel-trace / --pmc passes")
 args = ap.parse_args()
@@ -49,16 +50,33 @@ if args.profile:
 from sassd import _C  # noqa: E402
 flops = 2.0 * 256 * C * 9 * H * W * B
 ref = K.conv2d_wino_fwd(x, w2, 256, sc, sh, True).clone()
-names = {0: "auto", 2: "128x64", 3: "128x96", 4: "128x128", 5: "128x160", 6: "128x192"}
-for cfg in (0, 2, 3, 4, 5, 6):
-    line = "cfg %d %-18s" % (cfg, names[cfg])
-    for dbg, nm in ((0, "full"), (1, "no-dma"), (2, "no-mfma"), (3, "neither")):
+# fp64 reference: im2col + dgemm on the device
+with torch.no_grad():
+    cols = torch.nn.functional.unfold(x.double(), 3, padding=1)                       # [B, C*9, H*W]
+    ref64 = torch.matmul(w.double().reshape(256, -1), cols).reshape(B, 256, H, W)
+    ref64 = (ref64 * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).clamp(min=0)
+    del cols
+print("F(2x2) fused vs fp64: max abs %.2e   (max |y| %.2f)" % ((ref.double() - ref64).abs().max().item(), ref64.abs().max().item()))
+names = {0: "auto", 1: "fp32 auto", 2: "128x64", 3: "128x96", 4: "128x128", 5: "128x160", 6: "128x192",
+         11: "split 128x64", 12: "split 128x128", 13: "split 128x192", 14: "split 128x128 kc16", 15: "split 128x128 w64x32",
+         16: "split w128x64 kc16", 17: "split w128x64 kc32", 18: "split 128x256 w128x64",
+         21: "presplit 128x128 kc16", 22: "presplit 128x64 kc16", 23: "presplit 128x192 kc16", 24: "presplit 128x128 kc32",
+         25: "presplit w128x64 kc16", 26: "presplit 128x256 kc16", 27: "presplit 128x256 kc32", 19: "split 128x256 kc16",
+         20: "split 128x256 kc32"}
+cfgs = tuple(int(c) for c in args.cfgs.split(",")) if args.cfgs else (0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27)
+for cfg in cfgs:
+    line = "cfg %2d %-22s" % (cfg, names[cfg])
+    split = cfg >= 11
+    modes = ((0, "full"), (1, "no-dma")) if cfg >= 21 else ((0, "full"), (1, "no-dma"), (4, "no-split-valu")) if split else ((0, "full"), (1, "no-dma"), (2, "no-mfma"), (3, "neither"))
+    for dbg, nm in modes:
         _C.lib().sassd_debug_set_wino4(cfg, dbg)
         t4 = timeit(lambda: K.conv2d_wino4_fwd(x, w4, 256, sc, sh, True, y, ws))
         line += "  %s %6.1f us" % (nm, t4)
         if dbg == 0:
-            line += " (%.0f TF eq, err %.1e)" % (flops / t4 / 1e6, (y - ref).abs().max().item())
-    print(line)
+            line += " (%.0f TF eq, err vs F(2x2) %.1e, vs fp64 %.2e rms %.2e)" % (
+                flops / t4 / 1e6, (y - ref).abs().max().item(), (y.double() - ref64).abs().max().item(),
+                (y.double() - ref64).pow(2).mean().sqrt().item())
+    print(line, flush=True)
 _C.lib().sassd_debug_set_wino4(0, 0)
 t2 = timeit(lambda: K.conv2d_wino_fwd(x, w2, 256, sc, sh, True, y))
 print("F(2x2) fused: %.1f us (%.1f TF direct-equivalent)" % (t2, flops / t2 / 1e6))

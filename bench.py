@@ -26,9 +26,12 @@ pass.  `fps_sequential` (one graph after the other on one stream, no host sync) 
 sync + result read-back per frame) are printed next to it.
 
 The JSON line also carries:
-  roofline         dominant kernel (the 36-GEMM launch of a BEV 3x3 layer, Winograd F(4x4,3x3) on the fp32 MFMA):
-                   `achieved` / `frac` = the flops the kernel EXECUTES on the MFMA pipe (1/4 of the direct convolution)
-                   over its mean launch duration (HIP events on the launch stream) vs the 157.3 TF fp32-MFMA peak;
+  roofline         dominant kernel (the 36-GEMM launch of a BEV 3x3 layer, Winograd F(4x4,3x3); fp32 products computed as
+                   8 bf16 piece products each on the bf16 MFMA over exactly-split operands):
+                   `achieved` / `frac` = the flops the kernel EXECUTES on the MFMA pipe (1/4 of the direct convolution,
+                   x 8 bf16 multiply-adds per fp32 one) over its mean launch duration (HIP events on the launch stream)
+                   vs the 2500 TF bf16-MFMA peak (`frac_of_fp32_mfma_peak`: the same launch against the 157.3 TF
+                   fp32-MFMA peak; --wino4-cfg 1 runs the fp32-MFMA kernel of rounds 2-3);
                    `layer.effective` = the direct-convolution flops of SURVEY 8(d) over the whole layer (input
                    transform + GEMM + output transform).
   roofline_sparse  7 rulebooks + 14 sparse convs against the HBM roofline (B_gs bytes of SURVEY 8d), timed as a
@@ -56,6 +59,8 @@ from sassd import synth  # noqa: E402
 from sassd.pipeline import InferencePlan  # noqa: E402
 
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TF = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+SPLIT_SLOTS = 8                   # bf16 multiplies the split GEMM spends per fp32 product (8 of the 9 piece products)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured float4 copy)
 MEASURED_HBM_GBS = 6290.0
 PUBLISHED_FPS = 25.0              # /root/reference/readme.md:2 "can run at 25 FPS" 
@@ -369,6 +374,8 @@ def main():
     ap.add_argument("--spconv-cfg", type=int, default=0, help="workgroup geometry of the sparse gather-GEMM-scatter kernel "
                     "(A/B): 0 = default (8 waves, 128 KB of LDS slabs: one workgroup per CU), 1 = 4 waves / 64 KB (two per "
                     "CU, and room beside a BEV GEMM workgroup of another frame in flight)")
+    ap.add_argument("--wino4-cfg", type=int, default=0, help="geometry of the Winograd GEMM (A/B): 0 = fp32 products on the "
+                    "bf16 MFMA over split operands (default), 1 = the fp32 MFMA (the default of rounds 2-3)")
     ap.add_argument("--eager", action="store_true", help="issue the ~80 launches per frame from the host instead of "
                     "replaying the captured hipGraph (A/B)")
     args = ap.parse_args()
@@ -389,6 +396,9 @@ def main():
     if args.spconv_cfg:
         from sassd import kernels as K0
         K0.debug_set_spconv(args.spconv_cfg << 16)
+    if args.wino4_cfg:
+        from sassd import kernels as K0
+        K0.debug_set_wino4(args.wino4_cfg, 0)
     model, w = build_model(0, dev, args.config)
     B = args.batch if args.batch > 0 else w["batch"]
     S = max(1, args.inflight)
@@ -500,7 +510,7 @@ def main():
         chained = any(iso_plan.chain)
 
         def timed_part(flags, call):
-            K.debug_set_wino4(0, flags)
+            K.debug_set_wino4(args.wino4_cfg, flags)
             for _ in range(3):
                 call()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -509,7 +519,7 @@ def main():
                 call()
             e1.record()
             torch.cuda.synchronize()
-            K.debug_set_wino4(0, 0)
+            K.debug_set_wino4(args.wino4_cfg, 0)
             return e0.elapsed_time(e1) / 20
         with torch.cuda.stream(streams[0]):
             prev = (scale, shift, True)
@@ -558,9 +568,13 @@ def main():
     kernel_ms = w4_parts.get("gemm", conv_iso)                 # the dominant KERNEL: the F(4x4) GEMM launch alone
     exec_tf = exec_flops / (kernel_ms * 1e-3) / 1e12
     eff_tf = conv_flops / (conv_iso * 1e-3) / 1e12
-    kname = {4: "wino4_gemm_kernel (36 GEMMs 256 x 256 x tiles of the BEV 256->256 3x3 layer, Winograd F(4x4,3x3), fp32 "
-                "MFMA 32x32x2)", 2: "conv2d_wino_kernel (BEV 256->256 3x3, fused Winograd F(2x2,3x3), fp32 MFMA 32x32x2)",
+    split = kind == 4 and args.wino4_cfg in (0, 11, 12, 13, 14)
+    kname = {4: "wino4_gemm_kernel (36 GEMMs 256 x 256 x tiles of the BEV 256->256 3x3 layer, Winograd F(4x4,3x3), " +
+                ("fp32 products as 8 bf16 piece products each on v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if split else
+                 "fp32 MFMA 32x32x2)"), 2: "conv2d_wino_kernel (BEV 256->256 3x3, fused Winograd F(2x2,3x3), fp32 MFMA 32x32x2)",
              0: "conv2d_kernel (BEV 256->256 3x3, direct, fp32 MFMA 32x32x2)"}[kind]
+    # split geometry: the pipe executes SPLIT_SLOTS bf16 multiply-adds per fp32 one, priced against the bf16 MFMA peak
+    mfma_mult, mfma_peak = (SPLIT_SLOTS, PEAK_BF16_MFMA_TF) if split else (1, PEAK_F32_MFMA_TF)
     bev_total_ms = sum(iso_ms["bev_conv%d" % i] for i in range(8))
     sp_gbs = (work["bytes_gs"] + work["rulebook_bytes"]) / (sp_ms * 1e-3) / 1e9
     # PMC passes cannot run inside this process: the committed measurement is read -- and dropped unless it was taken on
@@ -597,8 +611,10 @@ def main():
         "fps_in_flight": round(fps, 3), "fps_sequential": round(B * 1e3 / seq_ms, 3),
         "latency_ms_sync_per_frame": round(lat_ms, 3), "frame_graph_ms": None if frame_ms is None else round(frame_ms, 4),
         "roofline": {"bound": "mfma", "kernel": kname,
-                     "achieved": round(exec_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                     "frac": round(exec_tf / PEAK_F32_MFMA_TF, 4),
+                     "achieved": round(exec_tf * mfma_mult, 2), "peak": mfma_peak, "unit": "TFLOP/s",
+                     "frac": round(exec_tf * mfma_mult / mfma_peak, 4),
+                     "fp32_product_tflops": round(exec_tf, 2),
+                     "frac_of_fp32_mfma_peak": round(exec_tf / PEAK_F32_MFMA_TF, 4),
                      "ms_per_launch": round(kernel_ms, 4), "executed_flops_per_launch": exec_flops,
                      "layer": {"ms": round(conv_iso, 4), "direct_conv_flops": conv_flops,
                                "effective": round(eff_tf, 2), "effective_frac": round(eff_tf / PEAK_F32_MFMA_TF, 4),
@@ -610,7 +626,10 @@ def main():
                              "1/4 of the direct convolution) / its mean launch duration, HIP events on the launch stream "
                              "(= what rocprofv3 --kernel-trace reports, profiles/); layer.effective = the layer's direct-"
                              "convolution flops of SURVEY 8(d) over the whole layer (input transform + GEMM + output "
-                             "transform)"},
+                             "transform).  Split geometry (default since round 4): every fp32 product is 8 bf16 piece "
+                             "products on the bf16 MFMA, so achieved = 8 x fp32_product_tflops against the 2500 TF bf16 "
+                             "peak; frac_of_fp32_mfma_peak prices the same launch against the 157.3 TF fp32-MFMA peak "
+                             "the rounds 2-3 kernel ran on (--wino4-cfg 1 runs that kernel)"},
         "roofline_sparse": {"bound": "hbm", "kernels": "7 rulebooks (fused pyramid) + 14 sparse-conv launches, timed as "
                                                        "one hipGraph" if not args.eager else "eager, isolated pass",
                             "achieved": round(sp_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -8,7 +8,7 @@
 // its in-loop input transform (every transformed value feeds only 32 output channels); here the transforms are taken
 // OUT of the contraction, so that the hot loop is a plain batched GEMM with no VALU work at all:
 //   1. wino4_in_kernel    V[p][ci][t] = (B^T d B)[p]         x [B,Cin,H,W] -> V [36][Cin][Tp]       (HBM stream)
-//   2. wino4_gemm_kernel  M[p][co][t] = sum_ci U[p][ci][co] V[p][ci][t]     36 GEMMs 256 x Cin x T   (fp32 MFMA)
+//   2. wino4_gemm_kernel  M[p][co][t] = sum_ci U[p][ci][co] V[p][ci][t]     36 GEMMs 256 x Cin x T   (MFMA)
 //   3. wino4_out_kernel   Y = A^T M A, folded BatchNorm / bias / ReLU        M [36][Cout][Tp] -> y    (HBM stream)
 // with U = G g G^T packed once per weight update as [36][Cin][Cout].  T = B * (H/4) * (W/4) tiles (2200 per KITTI
 // BEV map), padded to a multiple of the GEMM's 64-column block.  Per 256->256 layer: 10.4 GFLOP on the MFMA (41.5
@@ -17,7 +17,11 @@
 // it (below): ~8x the max-abs error of the direct convolution on a 256-channel layer instead of ~40x with the textbook
 // points -- inside the 2e-4 BEV-feature and 1e-4 box parity bars (tests/test_gpu_pipeline.py prints the measured errors).
 //
-// GEMM kernel: workgroup = 128 output channels x 32 WN tiles of one Winograd position, 2 x WN waves, each wave a 64 x 32
+// GEMM kernel, round 4: the fp32 products run on the bf16 MFMA (16 x the fp32 MFMA's rate) over operands split exactly into
+// three bf16 pieces in registers -- half the MFMA cycles per fp32 product, the error of the fp32 instruction (2.1e-5 against
+// fp64 on a KITTI layer for both), operands still fp32 in HBM and LDS: see "fp32 products on the bf16 MFMA" below.  Workgroup
+// = 128 output channels x 128 tiles, four waves of 64 x 64.  The fp32-MFMA form (geometry 1..6 of sassd_debug_set_wino4,
+// the default of rounds 2-3): workgroup = 128 output channels x 32 WN tiles of one Winograd position, 2 x WN waves, each a 64 x 32
 // block = two v_mfma_f32_32x32x2_f32 accumulators sharing one B fragment.  A ([k][128 co]) and B ([k][32 WN t]) chunks
 // of 32 input channels are staged by global->LDS DMA in their natural row-major form (both operands are K-major with
 // the M / N index contiguous, so fragment reads are 32 consecutive dwords: conflict free), double buffered, one
@@ -347,23 +351,17 @@ __device__ __forceinline__ unsigned hi_pair(const unsigned lo, const unsigned hi
 }
 // K-slot convention (8 slots of one channel, low half of dword 0 first):
 //     A side  a1 a2 | a3 a1 | a1 a2 | a2 a3        B side  w1 w1 | w1 w2 | w3 w2 | w3 w2
-// i.e. every product of pieces except a3 w3.  The A dwords are S0 = [a1|a2], S1 = [a3|a1], S0 again and X = [a2|a3]: a weight
-// stored PRE-SPLIT as the 8 bytes (S0, S1) needs one move and one byte permute in the kernel instead of the eight
-// instructions of the full split (sassd_conv2d_wino4_pack_weight writes that image behind the fp32 one).
-__device__ __forceinline__ uint2 presplit_a(const float a)
+// i.e. every product of pieces except a3 w3.  (The A dwords are S0 = [a1|a2], S1 = [a3|a1], S0 again and [a2|a3]: weights
+// stored pre-split as the 8 bytes (S0, S1) need 4 VALU instructions instead of 8 -- built and measured in round 4: the
+// doubled weight stream through the LDS DMA costs what the VALU saves)
+__device__ __forceinline__ bf16x8 split_a(const float a)
 {
     unsigned u0, u1, u2;
     split3(a, u0, u1, u2);
-    return make_uint2(hi_pair(u0, u1), hi_pair(u2, u0));
-}
-__device__ __forceinline__ bf16x8 expand_a(const uint2 sp)
-{
     u32x4 d;
-    d[0] = sp.x; d[1] = sp.y; d[2] = sp.x;
-    d[3] = __builtin_amdgcn_perm(sp.y, sp.x, 0x05040302u);      // [hi16(S0) | lo16(S1) << 16] = [a2|a3]
+    d[0] = hi_pair(u0, u1); d[1] = hi_pair(u2, u0); d[2] = d[0]; d[3] = hi_pair(u1, u2);
     return __builtin_bit_cast(bf16x8, d);
 }
-__device__ __forceinline__ bf16x8 split_a(const float a) { return expand_a(presplit_a(a)); }
 __device__ __forceinline__ bf16x8 split_b(const float w)
 {
     unsigned u0, u1, u2;
@@ -373,38 +371,28 @@ __device__ __forceinline__ bf16x8 split_b(const float w)
     return __builtin_bit_cast(bf16x8, d);
 }
 
-// the pre-split image of the transformed weights: U2[i] = (S0, S1) of U[i]
-__global__ void wino4_presplit_kernel(const float *__restrict__ U, size_t n, uint2 *__restrict__ U2)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) U2[i] = presplit_a(U[i]);
-}
-
-// scheduling groups of one pipelined step: MFMA m, then the VALU work of its share of the next step's values (8 instructions
-// per value split in the kernel, 4 per pre-split A value: three moves into the operand quad and the permute)
-template <int M, int NM, int MT, int NB, int ACOST>
+// scheduling groups of one pipelined step: MFMA m, then the split arithmetic (8 VALU instructions per value) of its share
+// of the next step's NV fragment values
+template <int M, int NM, int NV>
 __device__ __forceinline__ void split_sched()
 {
     if constexpr (M < NM) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        constexpr int NV = MT + NB, v0 = M * NV / NM, v1 = (M + 1) * NV / NM;
-        constexpr int na = (v1 < MT ? v1 : MT) - (v0 < MT ? v0 : MT);
-        constexpr int n = na * ACOST + (v1 - v0 - na) * 8;
-        if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x002, n, 0);
-        split_sched<M + 1, NM, MT, NB, ACOST>();
+        constexpr int n = (M + 1) * NV / NM - M * NV / NM;
+        if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x002, 8 * n, 0);
+        split_sched<M + 1, NM, NV>();
     }
 }
 
 // WM x WN waves; a wave owns a 64 x (32 NB) block = 2 x NB accumulators of v_mfma_f32_32x32x2_f32 (SPLIT = 0) or of
-// v_mfma_f32_32x32x16_bf16 over split operands (SPLIT = 1: both operands split in the kernel; 3: the A operand arrives
-// pre-split, 8 bytes per weight; 2: ablation without the split arithmetic).
-template <int WM, int WN, int NB, int KC, int SPLIT, int MT>
-__device__ __forceinline__ void w4_gemm_body(const W4Gemm &P)
+// v_mfma_f32_32x32x16_bf16 over split operands (SPLIT = 1; 2: ablation without the split arithmetic).
+template <int WM, int WN, int NB, int KC, int SPLIT>
+__global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
 {
+    constexpr int MT = 2;
     constexpr int NWV = WM * WN, WROWS = 32 * MT, BM = WROWS * WM, BN = 32 * NB * WN;
-    constexpr int AEL = SPLIT == 3 ? 2 : 1;                          // floats per A element in HBM / LDS
-    constexpr int STAGE = (BM * AEL + BN) * KC;
-    constexpr int NLA = KC * BM * AEL / 256, NLB = KC * BN / 256;    // 1 KB wave-loads per chunk
+    constexpr int STAGE = (BM + BN) * KC;
+    constexpr int NLA = KC * BM / 256, NLB = KC * BN / 256;          // 1 KB wave-loads per chunk
     constexpr int LPW = (NLA + NLB + NWV - 1) / NWV;                 // ... per wave
     extern __shared__ __attribute__((aligned(16))) float w4_lds[];   // [2][A KC x BM | B KC x BN]
     float *lds = w4_lds;
@@ -419,7 +407,7 @@ __device__ __forceinline__ void w4_gemm_body(const W4Gemm &P)
     const int pair = item / P.nseg, nb = (item - pair * P.nseg) * P.seglen + within;
     if (nb >= P.nnb) return;
     const int p = pair / P.nmb, mb = pair - p * P.nmb;
-    const float *Ub = P.U + (size_t)p * P.su + mb * BM * AEL;              // + k * Cout * AEL
+    const float *Ub = P.U + (size_t)p * P.su + mb * BM;                    // + k * Cout
     const float *Vb = P.V + (size_t)p * P.sv + nb * BN;                    // + k * ldv
     // DMA map: wave-load id t = wave + NWV * i; t < NLA: A rows (BM/4 16-byte pieces per row), else B rows.  The LDS
     // destination of a wave-load is lane-linear, i.e. the natural row-major [k][m] / [k][n] image.
@@ -431,14 +419,14 @@ __device__ __forceinline__ void w4_gemm_body(const W4Gemm &P)
         const int t = wave + NWV * i;
         if (t < NLA) {
             const int e = t * 64 + lane;
-            src[i] = Ub + (size_t)(e / (BM * AEL / 4)) * P.Cout * AEL + (e % (BM * AEL / 4)) * 4;
-            kstride[i] = (size_t)KC * P.Cout * AEL;
+            src[i] = Ub + (size_t)(e / (BM / 4)) * P.Cout + (e % (BM / 4)) * 4;
+            kstride[i] = (size_t)KC * P.Cout;
             dst[i] = t * 256;
         } else {
             const int e = (t - NLA) * 64 + lane;
             src[i] = Vb + (size_t)(e / (BN / 4)) * P.ldv + (e % (BN / 4)) * 4;
             kstride[i] = (size_t)KC * P.ldv;
-            dst[i] = BM * AEL * KC + (t - NLA) * 256;
+            dst[i] = BM * KC + (t - NLA) * 256;
         }
     }
     auto dma = [&](int chunk, float *stage) {
@@ -463,38 +451,26 @@ __device__ __forceinline__ void w4_gemm_body(const W4Gemm &P)
     for (int c = 0; c < nchunk; ++c) {
         float *cur = lds + (c & 1) * STAGE;
         if (c + 1 < nchunk && !(P.dbg & 1)) dma(c + 1, lds + ((c + 1) & 1) * STAGE);
-        const float *As = cur + (kh * BM + wm * WROWS + l31) * AEL;           // + 2*kk*BM*AEL
-        const float *Bs = cur + BM * AEL * KC + kh * BN + wn * 32 * NB + l31; // + 2*kk*BN
+        const float *As = cur + kh * BM + wm * WROWS + l31;                   // + 2*kk*BM
+        const float *Bs = cur + BM * KC + kh * BN + wn * 32 * NB + l31;       // + 2*kk*BN
         // (no run-time switches inside the split loop: a second path makes the compiler park the accumulators in the other
         // register file across the chunk loop, 128 v_accvgpr moves per chunk)
         if constexpr (SPLIT != 0) {
-            if constexpr (SPLIT == 1 || SPLIT == 3) {
+            if constexpr (SPLIT == 1) {
                 // Software pipeline inside the chunk: the fragment values of step kk + 1 are read and split while the MFMAs of
                 // step kk issue, one share of the split arithmetic behind every MFMA (the compiler's own order is all MFMAs
                 // of a step back to back, then all the VALU work: a wave cannot issue past its own queued MFMA, so nothing of
                 // its split overlaps its MFMAs).
                 constexpr int NK = KC / 2, NV = MT + NB, NM = MT * NB;
-                u32x4 raw[NV];
+                float raw[NV];
                 bf16x8 fr[2][NV];
                 auto rd = [&](const int kk) {
 #pragma unroll
-                    for (int a = 0; a < MT; ++a) {
-                        if constexpr (AEL == 2) {
-                            const uint2 sp = *reinterpret_cast<const uint2 *>(As + (2 * kk * BM + 32 * a) * 2);
-                            raw[a][0] = sp.x; raw[a][1] = sp.y; raw[a][2] = sp.x; raw[a][3] = sp.y;
-                        } else raw[a][0] = __float_as_uint(As[2 * kk * BM + 32 * a]);
-                    }
+                    for (int a = 0; a < MT; ++a) raw[a] = As[2 * kk * BM + 32 * a];
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) raw[MT + b][0] = __float_as_uint(Bs[2 * kk * BN + 32 * b]);
+                    for (int b = 0; b < NB; ++b) raw[MT + b] = Bs[2 * kk * BN + 32 * b];
                 };
-                auto mk = [&](const int v) -> bf16x8 {
-                    if (v >= MT) return split_b(__uint_as_float(raw[v][0]));
-                    if constexpr (AEL == 2) {
-                        u32x4 d = raw[v];
-                        d[3] = __builtin_amdgcn_perm(d[3], d[2], 0x05040302u);      // [hi16(S0) | lo16(S1) << 16] = [a2|a3]
-                        return __builtin_bit_cast(bf16x8, d);
-                    } else return split_a(__uint_as_float(raw[v][0]));
-                };
+                auto mk = [&](const int v) -> bf16x8 { return v < MT ? split_a(raw[v]) : split_b(raw[v]); };
                 rd(0);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) fr[0][v] = mk(v);
@@ -514,7 +490,7 @@ __device__ __forceinline__ void w4_gemm_body(const W4Gemm &P)
                                 for (int v = m * NV / NM; v < (m + 1) * NV / NM; ++v) fr[nxt][v] = mk(v);
                             }
                         }
-                    if (more) split_sched<0, NM, MT, NB, (AEL == 2 ? 4 : 8)>();
+                    if (more) split_sched<0, NM, NV>();
                 }
             } else {                                    // ablation (SPLIT = 2): the same reads and MFMAs without the split arithmetic
 #pragma unroll
@@ -582,39 +558,19 @@ __device__ __forceinline__ void w4_gemm_body(const W4Gemm &P)
     }
 }
 
-template <int WM, int WN, int NB, int KC, int SPLIT, int MT>
-__global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
-{
-    w4_gemm_body<WM, WN, NB, KC, SPLIT, MT>(P);
-}
-// the 128-row wave tile (128 accumulator registers) held to two waves per SIMD
-template <int WM, int WN, int NB, int KC, int SPLIT, int MT>
-__global__ void __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) wino4_gemm_tall_kernel(W4Gemm P)
-{
-    w4_gemm_body<WM, WN, NB, KC, SPLIT, MT>(P);
-}
-
 int g_wino4_cfg = 0, g_wino4_dbg = 0;
-constexpr bool g_wino4_split_default = false;
 
-template <int WM, int WN, int NB, int KC, int SPLIT = 0, int MT = 2>
+template <int WM, int WN, int NB, int KC, int SPLIT = 0>
 int launch_w4_gemm(W4Gemm P, hipStream_t stream)
 {
-    constexpr int BM = 32 * MT * WM, BN = 32 * NB * WN;
-    static_assert(BM == kBM, "the channel block is fixed: w4_pick_* and the supported() checks price it");
-    constexpr int AEL = SPLIT == 3 ? 2 : 1;
-    constexpr size_t stage_b = (size_t)2 * (BM * AEL + BN) * KC * 4, img_b = (size_t)WM * WN * 32 * MT * 32 * NB * 4;
+    constexpr int BM = 64 * WM, BN = 32 * NB * WN;
+    static_assert(BM == kBM, "the channel block is fixed: w4_pick_wn and the supported() checks price it");
+    constexpr size_t stage_b = (size_t)2 * (BM + BN) * KC * 4, img_b = (size_t)WM * WN * 64 * 32 * NB * 4;
     constexpr size_t lds = stage_b > img_b ? stage_b : img_b;        // the epilogue image reuses the staging buffers
     if constexpr (SPLIT == 1)
-        if (g_wino4_dbg & 4) return launch_w4_gemm<WM, WN, NB, KC, 2, MT>(P, stream);      // ablation instance
-    if constexpr (SPLIT == 3) {                          // the pre-split image sits behind the np fp32 problems
-        P.U += (size_t)P.np * P.su;
-        P.su *= 2;
-    }
+        if (g_wino4_dbg & 4) return launch_w4_gemm<WM, WN, NB, KC, 2>(P, stream);      // ablation instance
     static std::atomic<unsigned long long> attr_done{0};
-    const void *fn;
-    if constexpr (MT == 4) fn = (const void *)wino4_gemm_tall_kernel<WM, WN, NB, KC, SPLIT, MT>;
-    else fn = (const void *)wino4_gemm_kernel<WM, WN, NB, KC, SPLIT, MT>;
+    const void *fn = (const void *)wino4_gemm_kernel<WM, WN, NB, KC, SPLIT>;
     int rc = sassd_dyn_lds(fn, lds, attr_done);
     if (rc) return rc;
     P.nmb = P.Cout / BM; P.nnb = P.ncols / BN;
@@ -625,16 +581,12 @@ int launch_w4_gemm(W4Gemm P, hipStream_t stream)
     P.seglen = cdiv(P.nnb, P.nseg);
     P.pairs_per_xcd = cdiv(pairs * P.nseg, 8);
     P.dbg = g_wino4_dbg;
-    if constexpr (MT == 4)
-        hipLaunchKernelGGL((wino4_gemm_tall_kernel<WM, WN, NB, KC, SPLIT, MT>), dim3(8 * P.pairs_per_xcd * P.seglen),
-                           dim3(WM * WN * 64), lds, stream, P);
-    else
-        hipLaunchKernelGGL((wino4_gemm_kernel<WM, WN, NB, KC, SPLIT, MT>), dim3(8 * P.pairs_per_xcd * P.seglen),
-                           dim3(WM * WN * 64), lds, stream, P);
+    hipLaunchKernelGGL((wino4_gemm_kernel<WM, WN, NB, KC, SPLIT>), dim3(8 * P.pairs_per_xcd * P.seglen), dim3(WM * WN * 64),
+                       lds, stream, P);
     return sassd_launch_status();
 }
 
-// Tile-block width of the GEMM (32 WN columns, WN waves across): all workgroups do equal work, so the launch takes
+// Tile-block width of the fp32-MFMA GEMM (32 WN columns, WN waves across): all workgroups do equal work, so the launch takes
 // ceil(units / resident slots) rounds -- pick the width whose LAST round is fullest.  KITTI B=1 (2200 tiles): 160
 // columns -> 1008 units = 1.97 rounds of 512 slots (64 / 96 / 128 / 192 columns all waste 17 %).
 inline int w4_pick_wn(int T, int Cout, int np = 36, bool exact = false)
@@ -656,54 +608,23 @@ inline int w4_pick_wn(int T, int Cout, int np = 36, bool exact = false)
     return best;
 }
 
-// Geometry of the Winograd GEMM launch: SPLIT (fp32 products on the bf16 MFMA, wave tile 64 x 64) or the fp32 MFMA (wave tile
-// 64 x 32), WN waves across the tile columns.  g_wino4_cfg: 0 = default, 2..6 = fp32 MFMA with 32*cfg columns,
-// 11..13 = split with 64*(cfg-10) columns, 14 = split / 128 columns / 16-channel chunks, 15 = split on the 64 x 32 wave tile,
-// 16 / 17 = split, two waves of 128 x 64 (16- / 32-channel chunks), 18 = four waves of 128 x 64 (256 columns),
-// 21..25 = split with the weights pre-split (w4_tile below),
-// 1 = fp32 MFMA with the picked width (the round-3 default).
+// Geometry of the Winograd GEMM launch.  Default: fp32 products on the bf16 MFMA over split operands, 128 channels x 128
+// tiles per workgroup, four waves of 64 x 64 (measured at 2200 tiles: 142 us per 256 -> 256 layer with its two transform
+// launches against 157 for the best fp32-MFMA geometry; 64 columns 160, 192 columns 170).  g_wino4_cfg: 0 = default, 1 = the
+// fp32 MFMA at its picked width (the round-3 default), 2..6 = the fp32 MFMA with 32 cfg columns, 11..13 = split with
+// 64 (cfg - 10) columns, 14 = split, 128 columns, 16-channel chunks.
 struct W4Tile {
-    int split, wn, nb, kc, mt;
+    int split, wn, nb, kc;
     int bn() const { return 32 * nb * wn; }
 };
-inline int w4_pick_split_wn(int T, int Cout)
-{
-    int best = 2;
-    double best_cost = 1e30;
-    for (int wn = 1; wn <= 3; ++wn) {
-        const int bn = 64 * wn;
-        const size_t lds = (size_t)2 * (kBM + bn) * kKC * 4;
-        int wgs = (int)((size_t)160 * 1024 / (lds + 1024));             // (co-residency at exactly 160 KB is not relied on)
-        if (wgs > 8 / (2 * wn)) wgs = 8 / (2 * wn);                     // at most two waves per SIMD
-        if (wgs < 1) wgs = 1;
-        const long units = (long)36 * (Cout / kBM) * cdiv(T, bn);
-        const long rounds = (units + 256L * wgs - 1) / (256L * wgs);
-        const double cost = (double)rounds * wgs * bn;
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = wn; }
-    }
-    return best;
-}
 inline W4Tile w4_tile(int T, int Cout)
 {
     const int c = g_wino4_cfg;
-    if (c >= 2 && c <= 6) return W4Tile{0, c, 1, kKC, 2};
-    if (c >= 11 && c <= 13) return W4Tile{1, c - 10, 2, kKC, 2};
-    if (c == 14) return W4Tile{1, 2, 2, 16, 2};
-    if (c == 15) return W4Tile{1, 4, 1, kKC, 2};
-    if (c == 16) return W4Tile{1, 2, 2, 16, 4};
-    if (c == 17) return W4Tile{1, 2, 2, kKC, 4};
-    if (c == 18) return W4Tile{1, 4, 2, 16, 4};
-    if (c == 21) return W4Tile{3, 2, 2, 16, 2};       // pre-split weights: 128 x 128, 16-channel chunks (48 KB: three per CU)
-    if (c == 22) return W4Tile{3, 1, 2, 16, 2};       //                    128 x 64
-    if (c == 23) return W4Tile{3, 3, 2, 16, 2};       //                    128 x 192
-    if (c == 24) return W4Tile{3, 2, 2, kKC, 2};      //                    128 x 128, 32-channel chunks (96 KB: one per CU)
-    if (c == 25) return W4Tile{3, 2, 2, 16, 4};       //                    two waves of 128 x 64
-    if (c == 26) return W4Tile{3, 4, 2, 16, 2};       //                    128 x 256, eight waves (64 KB: two per CU)
-    if (c == 27) return W4Tile{3, 4, 2, kKC, 2};      //                    128 x 256, 32-channel chunks (128 KB: one per CU)
-    if (c == 19) return W4Tile{1, 4, 2, 16, 2};       // split in the kernel, 128 x 256, eight waves (48 KB)
-    if (c == 20) return W4Tile{1, 4, 2, kKC, 2};      //                      32-channel chunks (96 KB: one per CU)
-    if (c == 1 || !g_wino4_split_default) return W4Tile{0, w4_pick_wn(T, Cout), 1, kKC, 2};
-    return W4Tile{1, w4_pick_split_wn(T, Cout), 2, kKC, 2};
+    if (c >= 2 && c <= 6) return W4Tile{0, c, 1, kKC};
+    if (c >= 11 && c <= 13) return W4Tile{1, c - 10, 2, kKC};
+    if (c == 14) return W4Tile{1, 2, 2, 16};
+    if (c == 1) return W4Tile{0, w4_pick_wn(T, Cout), 1, kKC};
+    return W4Tile{1, 2, 2, kKC};
 }
 
 inline int w4_tiles_padded(int B, int H, int W, int Cout)
@@ -715,24 +636,8 @@ inline int w4_tiles_padded(int B, int H, int W, int Cout)
 
 inline int w4_launch(const W4Tile t, const W4Gemm &P, hipStream_t stream)
 {
-    if (t.split == 3) {
-        if (t.mt == 4) return launch_w4_gemm<1, 2, 2, 16, 3, 4>(P, stream);
-        if (t.wn == 4) return t.kc == 16 ? launch_w4_gemm<2, 4, 2, 16, 3>(P, stream) : launch_w4_gemm<2, 4, 2, kKC, 3>(P, stream);
-        if (t.kc == kKC) return launch_w4_gemm<2, 2, 2, kKC, 3>(P, stream);
-        switch (t.wn) {
-        case 1: return launch_w4_gemm<2, 1, 2, 16, 3>(P, stream);
-        case 2: return launch_w4_gemm<2, 2, 2, 16, 3>(P, stream);
-        default: return launch_w4_gemm<2, 3, 2, 16, 3>(P, stream);
-        }
-    }
     if (t.split) {
-        if (t.mt == 4) {
-            if (t.wn == 4) return launch_w4_gemm<1, 4, 2, 16, 1, 4>(P, stream);
-            return t.kc == 16 ? launch_w4_gemm<1, 2, 2, 16, 1, 4>(P, stream) : launch_w4_gemm<1, 2, 2, kKC, 1, 4>(P, stream);
-        }
-        if (t.wn == 4 && t.nb == 2) return t.kc == 16 ? launch_w4_gemm<2, 4, 2, 16, 1>(P, stream) : launch_w4_gemm<2, 4, 2, kKC, 1>(P, stream);
         if (t.kc == 16) return launch_w4_gemm<2, 2, 2, 16, 1>(P, stream);
-        if (t.nb == 1) return launch_w4_gemm<2, 4, 1, kKC, 1>(P, stream);
         switch (t.wn) {
         case 1: return launch_w4_gemm<2, 1, 2, kKC, 1>(P, stream);
         case 2: return launch_w4_gemm<2, 2, 2, kKC, 1>(P, stream);
@@ -750,9 +655,10 @@ inline int w4_launch(const W4Tile t, const W4Gemm &P, hipStream_t stream)
 
 }  // namespace
 
-// ablation / geometry switches of the F(4x4) GEMM (tools/run_wino4.py): cfg 0 = pick the tile-block width from the
-// tile count, 2..6 = force 32*cfg columns; dbg bit0 stage only the first chunk, bit1 no MFMA, bits 4 / 5 / 6 skip the
-// input transform / the GEMM / the output transform (per-kernel timing on live buffers, bench.py)
+// ablation / geometry switches of the F(4x4) GEMM (tools/run_wino4.py): cfg as listed at w4_tile (0 = split operands on the
+// bf16 MFMA, 1 = the fp32 MFMA, ...); dbg bit0 stage only the first chunk, bit1 no MFMA (fp32-MFMA geometries), bit2 no
+// split arithmetic (split geometries), bits 4 / 5 / 6 skip the input transform / the GEMM / the output transform (per-kernel
+// timing on live buffers, bench.py)
 extern "C" void sassd_debug_set_wino4(int cfg, int dbg) { g_wino4_cfg = cfg; g_wino4_dbg = dbg; }
 
 extern "C" int sassd_conv2d_wino4_supported(int Cin, int Cout, int H, int W)
@@ -764,7 +670,7 @@ extern "C" int sassd_conv2d_wino4_supported(int Cin, int Cout, int H, int W)
 extern "C" size_t sassd_conv2d_wino4_packed_floats(int Cin, int Cout)
 {
     if (Cin < 1 || Cout < 1) return 0;
-    return (size_t)3 * 36 * Cin * Cout;                  // fp32 image [36][Cin][Cout], then the pre-split one (8 bytes per weight)
+    return (size_t)36 * Cin * Cout;
 }
 
 extern "C" int sassd_conv2d_wino4_pack_weight(const float *w, int Cout, int Cin, float *packed, void *stream_)
@@ -772,9 +678,6 @@ extern "C" int sassd_conv2d_wino4_pack_weight(const float *w, int Cout, int Cin,
     if (!w || !packed || Cin < 1 || Cout < 1) return SASSD_EINVAL;
     hipLaunchKernelGGL(wino4_pack_kernel, dim3(cdiv(Cout * Cin, 256)), dim3(256), 0, (hipStream_t)stream_, w, Cout, Cin,
                        packed);
-    const size_t n = (size_t)36 * Cin * Cout;
-    hipLaunchKernelGGL(wino4_presplit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
-                       (const float *)packed, n, (uint2 *)(packed + n));
     return sassd_launch_status();
 }
 
@@ -926,6 +829,7 @@ extern "C" int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, con
     P.np = batch; P.Cin = Cin; P.Cout = Cout; P.ldv = hw; P.ldm = hw; P.ncols = hw;
     P.su = 0; P.sv = (size_t)Cin * hw; P.sm = (size_t)Cout * hw;
     hipStream_t stream = (hipStream_t)stream_;
+    if (g_wino4_cfg != 1 && hw % 128 == 0) return launch_w4_gemm<2, 2, 2, kKC, 1>(P, stream);     // split operands, as above
     switch (w4_pick_wn(hw, Cout, batch, true)) {
     case 2: return launch_w4_gemm<2, 2, 1, kKC>(P, stream);
     case 3: return launch_w4_gemm<2, 3, 1, kKC>(P, stream);

@@ -39,10 +39,11 @@ def test_conv2d_wino4(dev, b, cin, cout, hw, relu):
     assert not K.conv2d_wino4_supported(256, 128, 200, 176)
 
 
-@pytest.mark.parametrize("cfg", [1, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
+@pytest.mark.parametrize("cfg", [0, 11, 13, 14])
 def test_conv2d_wino4_gemm_geometries(dev, cfg):
-    """Every launch geometry of the Winograd GEMM behind sassd_debug_set_wino4 -- 1 = the fp32 MFMA, 11..18 = fp32 products
-    on the bf16 MFMA over exactly-split operands (three bf16 pieces per fp32 value, eight of the nine piece products) --
+    """The launch geometries of the Winograd GEMM behind sassd_debug_set_wino4 -- 1 = the fp32 MFMA, 0 (default) and 11..14 =
+    fp32 products on the bf16 MFMA over exactly-split operands (three bf16 pieces per fp32 value, eight of the nine piece
+    products) --
     against torch-CPU conv2d at the bar of the default path, on the KITTI BEV layer and on a ragged multi-image shape with
     512 output channels.  The error of each is printed next to the fp32 MFMA's: the split path must not be the looser one
     by more than 2x (it computes every product to 2^-30 and accumulates in fp32 like the fp32 instruction)."""

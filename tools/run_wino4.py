@@ -57,17 +57,13 @@ with torch.no_grad():
     ref64 = (ref64 * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).clamp(min=0)
     del cols
 print("F(2x2) fused vs fp64: max abs %.2e   (max |y| %.2f)" % ((ref.double() - ref64).abs().max().item(), ref64.abs().max().item()))
-names = {0: "auto", 1: "fp32 auto", 2: "128x64", 3: "128x96", 4: "128x128", 5: "128x160", 6: "128x192",
-         11: "split 128x64", 12: "split 128x128", 13: "split 128x192", 14: "split 128x128 kc16", 15: "split 128x128 w64x32",
-         16: "split w128x64 kc16", 17: "split w128x64 kc32", 18: "split 128x256 w128x64",
-         21: "presplit 128x128 kc16", 22: "presplit 128x64 kc16", 23: "presplit 128x192 kc16", 24: "presplit 128x128 kc32",
-         25: "presplit w128x64 kc16", 26: "presplit 128x256 kc16", 27: "presplit 128x256 kc32", 19: "split 128x256 kc16",
-         20: "split 128x256 kc32"}
-cfgs = tuple(int(c) for c in args.cfgs.split(",")) if args.cfgs else (0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27)
+names = {0: "split 128x128 (default)", 1: "fp32 auto", 2: "fp32 128x64", 3: "fp32 128x96", 4: "fp32 128x128", 5: "fp32 128x160",
+         6: "fp32 128x192", 11: "split 128x64", 12: "split 128x128", 13: "split 128x192", 14: "split 128x128 kc16"}
+cfgs = tuple(int(c) for c in args.cfgs.split(",")) if args.cfgs else (0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 14)
 for cfg in cfgs:
     line = "cfg %2d %-22s" % (cfg, names[cfg])
-    split = cfg >= 11
-    modes = ((0, "full"), (1, "no-dma")) if cfg >= 21 else ((0, "full"), (1, "no-dma"), (4, "no-split-valu")) if split else ((0, "full"), (1, "no-dma"), (2, "no-mfma"), (3, "neither"))
+    split = cfg >= 11 or cfg == 0
+    modes = ((0, "full"), (1, "no-dma"), (4, "no-split-valu")) if split else ((0, "full"), (1, "no-dma"), (2, "no-mfma"), (3, "neither"))
     for dbg, nm in modes:
         _C.lib().sassd_debug_set_wino4(cfg, dbg)
         t4 = timeit(lambda: K.conv2d_wino4_fwd(x, w4, 256, sc, sh, True, y, ws))

@@ -47,12 +47,12 @@ for name in ("bench_inflight3", "bench_inflight1", "bench_multi", "bench_waymo",
         if d:
             json.dump(d, open(os.path.join(DST, "%s_%s_under_rocprof.json" % (tag, name)), "w"), indent=1)
 for name in ("bench_default", "bench_train_bf16", "bench_train_fp32", "bench_train_waymo", "bench_train_forceddp",
-             "bench_multi", "bench_waymo", "bench_20steps"):
+             "bench_multi", "bench_waymo", "bench_20steps", "bench_fp32mfma"):
     lg = os.path.join(SRC, name + ".log")
     d = json_line(lg) if os.path.exists(lg) else None
     if d:
         json.dump(d, open(os.path.join(DST, "%s_%s.json" % (tag, name)), "w"), indent=1)
-for name in ("spconv_layers_car", "spconv_layers_multi", "spconv_layers_waymo", "mfma4x4_probe"):
+for name in ("spconv_layers_car", "spconv_layers_multi", "spconv_layers_waymo", "mfma4x4_probe", "wino4_geometries"):
     src = os.path.join(SRC, name + ".txt")
     if os.path.exists(src) and os.path.getsize(src) > 10:
         shutil.copy(src, os.path.join(DST, "%s_%s.txt" % (tag, name)))
@@ -68,17 +68,18 @@ for k in ("wino4_in", "wino4_out", "wino4_gemm"):
     a, na = counter(os.path.join(SRC, "wino4_FETCH_SIZE.json"), "FETCH_SIZE", k)
     b, nb = counter(os.path.join(SRC, "wino4_WRITE_SIZE.json"), "WRITE_SIZE", k)
     parts[k] = dict(FETCH_SIZE_kb_raw=a / max(na, 1), WRITE_SIZE_kb_raw=b / max(nb, 1))
-Tp, cin, cout = 2240, 256, 256
+Tp, cin, cout = 2304, 256, 256          # 2200 tiles padded to the 128-column block of the split geometry
 alg = 36 * cin * Tp * 4 + 36 * cin * cout * 4 + 36 * cout * Tp * 4
 rec = dict(
     csrc_hash=CSRC,
-    kernel="wino4_gemm_kernel (36 GEMMs 256 x 256 x 2240 tiles of the BEV 256->256 3x3 layer @ 1x256x200x176, fp32)",
+    kernel="wino4_gemm_kernel (36 GEMMs 256 x 256 x 2304 tiles of the BEV 256->256 3x3 layer @ 1x256x200x176, fp32 operands, "
+           "products on the bf16 MFMA over split operands)",
     command="rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python tools/run_wino4.py --profile --reps 5 ; the same with "
             "--pmc WRITE_SIZE (two separate passes, tools/rocprof_pmc.py on each results.db)",
     FETCH_SIZE_kb_per_dispatch_raw=f / max(nf, 1), WRITE_SIZE_kb_per_dispatch_raw=w / max(nw, 1),
     correction="MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) "
                "coalesced reads -- both operands enter through 16 B/lane global->LDS DMA -- so fetch bytes = 2 x raw; "
-               "WRITE_SIZE equals the product tensor exactly (36 x 256 x 2240 x 4 B = 80 640 KiB) and is used as is; "
+               "WRITE_SIZE equals the product tensor (36 x 256 x 2304 x 4 B = 82 944 KiB) and is used as is; "
                "counters sit on the L2 fabric side, Infinity-Cache hits included",
     fetch_bytes_per_launch=int(2 * f / max(nf, 1) * 1024), write_bytes_per_launch=int(w / max(nw, 1) * 1024),
     algorithmic_bytes_per_launch=alg,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 evidence: bench JSON lines, rocprofv3 kernel-trace summaries, PMC passes (FETCH_SIZE / WRITE_SIZE, SQ stall counters),
-# per-layer sparse-conv timings with the load-preserving ablation switches, the 4x4x1 MFMA probe.
+# per-layer sparse-conv timings with the load-preserving ablation switches, the Winograd GEMM geometry table.
 # usage (on the GPU box): bash tools/gpu_profiles_r4.sh      -> gpurun_out/prof/*, copied to profiles/ by tools/collect_profiles.py r04
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/prof; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/prof; R=$GRAFT_REPO_ROOT
@@ -18,7 +18,6 @@ pmc() {  # name, counter(s), command...
   [ -n "$DB" ] && python $R/tools/rocprof_pmc.py $DB > $O/${name}_${tag}.json 2>&1
 }
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
-timeout 120 tools/bin/probe_mfma4x4 > $O/mfma4x4_probe.txt 2>&1; echo "probe rc=$?"
 pmc wino4 FETCH_SIZE python $R/tools/run_wino4.py --profile --reps 5
 pmc wino4 WRITE_SIZE python $R/tools/run_wino4.py --profile --reps 5
 pmc sparse_car FETCH_SIZE python $R/tools/run_sparse_only.py --config car --reps 5
@@ -35,9 +34,10 @@ pmc stall_sparse_car_r3geom "$SQ" python $R/tools/run_sparse_only.py --config ca
 pmc stall_sparse_multi "$SQ" python $R/tools/run_sparse_only.py --config multi --reps 3
 pmc stall_wino4 "$SQ" python $R/tools/run_wino4.py --profile --reps 5
 python tools/collect_profiles.py r04 > $O/collect.log 2>&1; echo "collect rc=$?"
-for c in car multi waymo; do
+for c in car multi; do
   timeout 400 python tools/ablate_spconv.py --config $c --ablate 2>&1 | grep -v "^/opt" > $O/spconv_layers_$c.txt; echo "layers $c rc=$?"
 done
+timeout 300 python tools/run_wino4.py --reps 30 2>&1 | grep -v "^/opt" > $O/wino4_geometries.txt; echo "wino4 geometries rc=$?"
 trace bench_inflight3 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train
 trace bench_inflight1 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train --inflight 1
 trace bench_multi python $R/bench.py --config multi --steps 20 --warmup 5
@@ -49,8 +49,9 @@ timeout 600 python bench.py --mode train --precision fp32 --steps 30 --warmup 6 
 timeout 600 python bench.py --mode train --config waymo --steps 12 --warmup 4 > $O/bench_train_waymo.log 2>&1; echo "train waymo rc=$?"
 timeout 300 python bench.py --config multi --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_multi.log 2>&1; echo "multi rc=$?"
 timeout 300 python bench.py --config waymo --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_waymo.log 2>&1; echo "waymo rc=$?"
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-train > $O/bench_20steps.log 2>&1; echo "20 steps rc=$?"
+timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-train > $O/bench_20steps.log 2>&1; echo "200 steps rc=$?"
+timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-train --wino4-cfg 1 > $O/bench_fp32mfma.log 2>&1; echo "fp32-MFMA A/B rc=$?"
 timeout 300 python tools/run_bf16_conv.py --ablate > $O/bf16_conv_timing.json 2>/dev/null; echo "bf16 timing rc=$?"
 timeout 900 python bench.py > $O/bench_default.log 2>&1; echo "bench default rc=$?"
 python tools/collect_profiles.py r04 >> $O/collect.log 2>&1; echo "collect rc=$?"
-grep -o '"traffic_measured_at": [^,]*' $O/bench_default.log | head -3; grep -o '"value": [0-9.]*' $O/bench_default.log $O/bench_train_bf16.log $O/bench_multi.log $O/bench_waymo.log
+grep -o '"traffic_measured_at": [^,]*' $O/bench_default.log | head -3; grep -o '"value": [0-9.]*' $O/bench_default.log $O/bench_train_bf16.log $O/bench_multi.log $O/bench_waymo.log $O/bench_20steps.log $O/bench_fp32mfma.log

@@ -196,13 +196,21 @@ int sassd_conv2d_wino_pack_weight(const float *w, int Cout, int Cin, float *pack
 int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, const float *scale, const float *shift, int relu,
                           float *y, int batch, int Cin, int Cout, int H, int W, void *stream);
 
-/* The same layers through Winograd F(4x4,3x3) as THREE launches: input transform -> 36 fp32-MFMA GEMMs
+/* The same layers through Winograd F(4x4,3x3) as THREE launches: input transform -> 36 GEMMs
  * (Cout x Cin x tiles) -> output transform with the folded BatchNorm / bias / ReLU epilogue.  4x fewer multiplications
- * than the direct convolution (1.78x fewer than F(2x2)) and no VALU work inside the contraction; fp32 rounding error
- * ~6x the direct kernel's (2.4e-6 relative after seven layers).  Needs Cin % 32 == 0, Cout % 256 == 0, H % 4 == 0,
+ * than the direct convolution (1.78x fewer than F(2x2)); fp32 rounding error ~6x the direct kernel's (2.4e-6 relative after
+ * seven layers).  The GEMMs compute their fp32 products on the bf16 MFMA over operands split exactly into three bf16
+ * pieces in registers (eight of the nine piece products, fp32 accumulation: the error of the fp32 MFMA at half its
+ * cycles); tensors, packed weights and workspace stay fp32.  Needs Cin % 32 == 0, Cout % 256 == 0, H % 4 == 0,
  * W % 4 == 0 and a caller workspace (transformed input + product tensors, 36 planes each). */
 int sassd_conv2d_wino4_supported(int Cin, int Cout, int H, int W);
-void sassd_debug_set_wino4(int cfg, int dbg);     /* GEMM tile geometry / ablation switches (tools/run_wino4.py) */
+/* GEMM geometry / ablation switches (tools/run_wino4.py, bench.py --wino4-cfg).  cfg 0 = split operands on the bf16 MFMA,
+ * 128 x 128 workgroups (default); 1 = the fp32 MFMA (v_mfma_f32_32x32x2_f32) at its picked width -- the kernel of rounds 2-3,
+ * kept for the A/B; 2..6 = fp32 MFMA with 32 cfg tile columns; 11..14 = split with other workgroup shapes.  dbg: bit 0
+ * stage only the first chunk, bit 1 no MFMA (fp32 geometries), bit 2 no split arithmetic (split geometries), bits 4 / 5 /
+ * 6 / 7 skip the input transform / GEMM / output transform / fused transform.  Process-wide, not thread-safe: set it
+ * before building plans or capturing graphs. */
+void sassd_debug_set_wino4(int cfg, int dbg);
 size_t sassd_conv2d_wino4_packed_floats(int Cin, int Cout);
 int sassd_conv2d_wino4_pack_weight(const float *w /*[Cout,Cin,3,3]*/, int Cout, int Cin, float *packed, void *stream);
 size_t sassd_conv2d_wino4_workspace_bytes(int batch, int Cin, int Cout, int H, int W);

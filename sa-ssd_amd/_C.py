@@ -166,6 +166,9 @@ def lib():
         flags = os.environ.get("SASSD_SPCONV_DEBUG")
         if flags:
             l.sassd_debug_set_spconv(int(flags, 0))
+        cfg = os.environ.get("SASSD_WINO4_CFG")          # likewise: the Winograd GEMM geometry (1 = the fp32 MFMA)
+        if cfg:
+            l.sassd_debug_set_wino4(int(cfg, 0), 0)
     return _lib
 
 

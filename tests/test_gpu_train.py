@@ -293,8 +293,17 @@ def test_training_step_k21_vs_oracle(dev, precision):
     (21 500 points each, 32 245 voxels), 8 boxes per frame, the weights bench.py trains -- forward_train + backward on the
     HIP kernels, batch built by the product's own device_batch, against the CPU oracle's step read from
     tests/golden/train_k21_ref.npz (tests/golden/make_golden_train_k21.py; imported here for the shared seeded inputs).
-    fp32: six loss terms 1e-3 relative, gradients 2e-3 relative L2 -- elementwise for the stored layers, through the norm
-    and a seeded projection for every other parameter (the bars of the car_cfg case above).  bf16 (BEV convs on the bf16
+    fp32: six loss terms 1e-3 relative; gradients: the stored layers TAKEN TOGETHER 2e-3 relative L2 (measured 6.6e-4), each
+    stored tensor 2e-2 (measured 6.4e-3), every parameter's norm 5e-3 (1.8e-3) and seeded projection 2e-2 (7.2e-3).  The
+    per-tensor bar is this workload's own fp32 floor, not a kernel tolerance: tools/train_order_sensitivity.py runs the CPU
+    ORACLE against its own stored golden with nothing changed but the order in which its 4-channel input layer adds the 27
+    offset terms -- forward activations move by <= 5e-5 on values of 40, FOUR of 3.9 M ReLU decisions flip (|z| < 1e-6),
+    and the BatchNorm-parameter gradients of the first sparse blocks (small residuals of cancelling sums over 30 k rows)
+    move by 6.4e-3 (descending order) / 8.8e-3 (three interleaved partial sums), the same tensors in the same ranking as
+    the GPU's deviation (down1.1.bias 6.4e-3, conv1.1.bias 5.3e-3, conv0.1.bias 5.0e-3, ...).  With the round-1 kernel on
+    the input layer the GPU happened to land on the golden's side of those decisions (7.7e-4); the round-4 input-layer
+    kernel (k ascending, one fmaf chain) lands on the other (tests/test_train_order_sensitivity_cpu.py holds the oracle-
+    vs-oracle number on CPU).  bf16 (BEV convs on the bf16
     MFMA, what the bench line runs): the six loss terms 3 % (measured 0.3 %), and the gradient of the SELECTION-FREE part of
     the objective (all terms but the rescoring head's loss_cls) -- stored layers taken together 1.2e-1 relative L2 with
     cosine >= 0.99 (measured 7.8e-2), every parameter's gradient norm within 25 % (measured 17 %).  These are the numbers
@@ -379,10 +388,11 @@ def test_training_step_k21_vs_oracle(dev, precision):
     print("largest norm errors:", sorted(((round(v, 4), k) for k, v in worst_n.items()), reverse=True)[:10])
     assert len(worst) >= 40 and len(worst_n) >= 70
     if precision == "fp32":
-        bad = {k: v for k, v in worst.items() if not v < 2e-3}
+        assert allrel < 2e-3 and cosine > 0.999999, (allrel, cosine)
+        bad = {k: v for k, v in worst.items() if not v < 2e-2}
         assert not bad, bad
-        assert max(worst_n.values()) < 2e-3, {k: v for k, v in worst_n.items() if v >= 2e-3}
-        assert max(worst_p.values()) < 5 * 2e-3, {k: v for k, v in worst_p.items() if v >= 1e-2}
+        assert max(worst_n.values()) < 5e-3, {k: v for k, v in worst_n.items() if v >= 5e-3}
+        assert max(worst_p.values()) < 2e-2, {k: v for k, v in worst_p.items() if v >= 2e-2}
     else:
         assert allrel < 1.2e-1 and cosine > 0.99, (allrel, cosine)
         assert max(worst_n.values()) < 0.25, {k: v for k, v in worst_n.items() if v >= 0.25}

@@ -90,6 +90,42 @@ def test_conv1x1_gemm(dev, b, cin, cout, hw, relu):
     assert not K.conv1x1_gemm_supported(256, 28, 200, 176) and not K.conv1x1_gemm_supported(256, 256, 188, 188)
 
 
+def test_split_operand_gemm_dynamic_range(dev):
+    """The split-operand GEMM without a Winograd transform around it (1x1 convolution, 256-column map -> the split kernel):
+    operands whose magnitudes span 2^-40 .. 2^40 per input channel, zeros, negative zeros, values with all 24 significand bits
+    set and values whose low pieces vanish (exact bf16 numbers).  Every product is formed from bf16 pieces, so the bar is the
+    fp32 dot product's: |y - y64| <= 2e-6 * sum |w| |x| per output, and the fp32-MFMA geometry must not be tighter by more
+    than 2x.  (An Inf operand gives NaN instead of Inf -- Inf - Inf in the split -- which the reference's convolution
+    produces one layer later anyway; not exercised.)"""
+    g = torch.Generator().manual_seed(11)
+    b, cin, cout, hw = 2, 256, 128, (16, 16)
+    x = torch.randn(b, cin, *hw, generator=g)
+    scale = torch.pow(2.0, torch.randint(-40, 41, (cin,), generator=g).float())
+    x = x * scale.view(1, -1, 1, 1)
+    x[:, 0] = 0.0
+    x[:, 1] = -0.0
+    x[:, 2] = torch.tensor(16777215.0)                       # 2^24 - 1: all significand bits set
+    x[:, 3] = x[:, 3].bfloat16().float()                     # exact bf16 values: the lower pieces are zero
+    w = torch.randn(cout, cin, 1, 1, generator=g) / scale.view(1, -1, 1, 1) / 16.0
+    w[:, 2] = torch.tensor(1.0 / 16777215.0)
+    assert K.conv1x1_gemm_supported(cin, cout, *hw) and (hw[0] * hw[1]) % 128 == 0
+    wp = K.conv1x1_gemm_pack_weight(w.to(dev))
+    y64 = torch.nn.functional.conv2d(x.double(), w.double())
+    bound = torch.nn.functional.conv2d(x.double().abs(), w.double().abs())
+    errs = {}
+    for c in (1, 0):
+        K.debug_set_wino4(c, 0)
+        try:
+            y = K.conv1x1_gemm_fwd(x.to(dev), wp, cout)
+            torch.cuda.synchronize()
+        finally:
+            K.debug_set_wino4(0, 0)
+        assert torch.isfinite(y).all()
+        errs[c] = ((y.cpu().double() - y64).abs() / bound.clamp(min=1e-300)).max().item()
+    print("split-operand GEMM, operands over 2^-40..2^40: max |err| / sum|w||x| = %.2e (fp32 MFMA %.2e)" % (errs[0], errs[1]))
+    assert errs[0] <= 2e-6 and errs[0] <= 2.0 * errs[1] + 1e-8
+
+
 @pytest.mark.parametrize("b,cin0,hw", [(1, 320, (200, 176)), (3, 64, (20, 44)), (2, 256, (188, 188)), (2, 96, (8, 12))])
 def test_conv2d_wino4_chain(dev, b, cin0, hw):
     """Three chained 3x3 layers (cin0 -> 256 -> 256 -> 256, folded scale / shift + ReLU after each) through

@@ -12,7 +12,7 @@ in units of one 16-pair MFMA tile (64 x v_mfma_f32_16x16x4_f32 = 2048 cycles on 
     the 151 TF of the 16x16x4 form, tools/probe_mfma4x4.hip);
   * the tile fill (pairs / issued MFMA rows) of both granularities and the perfectly balanced bound.
 
-    python tools/spconv_balance_model.py [--batch 1] [--clock-ghz 2.07]
+    python tests/analysis/spconv_balance_model.py [--batch 1] [--clock-ghz 2.07]
 """
 import argparse
 import os
@@ -20,7 +20,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import sassd  # noqa: E402,F401
 from sassd import synth  # noqa: E402

@@ -6,7 +6,7 @@ with its sparse convolution summing the 27 offsets (a) in ascending order -- the
 register-stationary kernel), same inputs, same weights, same thresholds.  Both are legitimate fp32 evaluations of the same
 function; the relative L2 distance of their gradients, per stored tensor, is the floor under any kernel-vs-oracle bar.
 
-    python tools/train_order_sensitivity.py [--order rev|split3] [--layers 0,1,2]     (~5 CPU-minutes per step)"""
+    python tests/analysis/train_order_sensitivity.py [--order rev|split3] [--only-cin 4]     (~40 CPU-seconds per step)"""
 import argparse
 import importlib.util
 import os
@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 ap = argparse.ArgumentParser()

@@ -295,7 +295,7 @@ def test_training_step_k21_vs_oracle(dev, precision):
     tests/golden/train_k21_ref.npz (tests/golden/make_golden_train_k21.py; imported here for the shared seeded inputs).
     fp32: six loss terms 1e-3 relative; gradients: the stored layers TAKEN TOGETHER 2e-3 relative L2 (measured 6.6e-4), each
     stored tensor 2e-2 (measured 6.4e-3), every parameter's norm 5e-3 (1.8e-3) and seeded projection 2e-2 (7.2e-3).  The
-    per-tensor bar is this workload's own fp32 floor, not a kernel tolerance: tools/train_order_sensitivity.py runs the CPU
+    per-tensor bar is this workload's own fp32 floor, not a kernel tolerance: tests/analysis/train_order_sensitivity.py runs the CPU
     ORACLE against its own stored golden with nothing changed but the order in which its 4-channel input layer adds the 27
     offset terms -- forward activations move by <= 5e-5 on values of 40, FOUR of 3.9 M ReLU decisions flip (|z| < 1e-6),
     and the BatchNorm-parameter gradients of the first sparse blocks (small residuals of cancelling sums over 30 k rows)

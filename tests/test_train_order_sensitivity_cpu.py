@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_oracle_gradient_moves_with_the_summation_order_of_its_input_layer():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_order_sensitivity.py"), "--order", "rev",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "analysis", "train_order_sensitivity.py"), "--order", "rev",
                           "--only-cin", "4"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     m = re.search(r"worst rel L2 ([0-9.e+-]+) over (\d+) tensors, taken together ([0-9.e+-]+)", out.stdout)

@@ -403,7 +403,8 @@ def conv2d_wino4_workspace(b, cin, cout, h, w, device):
 
 
 def conv2d_wino4_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=None, ws=None):
-    """3x3 pad-1 conv through Winograd F(4x4,3x3): input transform, 36 fp32-MFMA GEMMs, output transform + epilogue."""
+    """3x3 pad-1 conv through Winograd F(4x4,3x3): input transform, 36 GEMMs (fp32 products on the bf16 MFMA over exactly
+    split operands; `debug_set_wino4(1)` = the fp32 MFMA), output transform + epilogue."""
     _chk_cuda(x, w_packed)
     b, cin, h, w = x.shape
     if y is None:
@@ -447,7 +448,7 @@ def conv1x1_gemm_supported(cin, cout, h, w):
 
 
 def conv1x1_gemm_pack_weight(w):
-    """w [Cout,Cin,1,1] -> [Cin][Cout] (K-major operand of the fp32-MFMA GEMM)."""
+    """w [Cout,Cin,1,1] -> [Cin][Cout] (K-major operand of the Winograd GEMM kernel)."""
     _chk_cuda(w)
     cout, cin = w.shape[0], w.shape[1]
     packed = torch.empty(cin * cout, dtype=torch.float32, device=w.device)

@@ -1,5 +1,6 @@
-"""-m gpu parity of the Winograd F(4x4,3x3) BEV convolution (input transform -> 36 fp32-MFMA GEMMs -> output
-transform) against torch-CPU conv2d (plain fp32 reference of the same op)."""
+"""-m gpu parity of the Winograd F(4x4,3x3) BEV convolution (input transform -> 36 GEMMs -> output transform) against
+torch-CPU conv2d (plain fp32 reference of the same op).  The GEMMs run their fp32 products on the bf16 MFMA over exactly
+split operands by default; the fp32-MFMA form and the other workgroup shapes are held to the same bar against fp64."""
 import pytest
 import torch
 

@@ -168,6 +168,8 @@ def train_measure(args, dev, rank, world, config="car", precision="bf16", steps=
     (rank 0; None on the other ranks).  Reference loop: tools/train_utils/__init__.py:36-61, DDP wrap tools/train.py:78."""
     from sassd import dist as D, train, autograd as AG
     AG.set_bev_precision(precision)
+    sparse_prec = getattr(args, "sparse_precision", "fp32") if precision == "bf16" else "fp32"
+    AG.set_sparse_precision(sparse_prec)
     if fused_bn is not None:
         from sassd import spconv as SP
         SP.SparseSequential.fuse_bn_relu = bool(fused_bn)
@@ -284,6 +286,9 @@ def train_measure(args, dev, rank, world, config="car", precision="bf16", steps=
             "Waymo-scale synthetic training (BASELINE configs[4]): car head, batch=%d/GPU, 180000 pts/frame, 0.1x0.1x0.15 "
             "m voxels (grid 40x1504x1504, %d active voxels in the last batch), BEV 188x188, %s, 12 synthetic car "
             "boxes/frame on occupied voxels, adam_onecycle, grad clip 10" % (B, voxels, bev))
+    if sparse_prec == "bf16":
+        desc = desc.replace("fp32 sparse trunk", "64-channel sparse convs (forward / data gradient) on the bf16 MFMA")
+    AG.set_sparse_precision("fp32")                      # process-wide kernel switch: back to the inference default
     return {
         "metric": "%s training samples/sec (whole job)" % ("KITTI-Car" if config == "car" else "Waymo-scale synthetic"),
         "value": round(sps, 3), "unit": "samples/s",
@@ -351,6 +356,8 @@ def main():
                     help="infer = BASELINE configs[1] (headline); train = configs[2] shape, extra measurement")
     ap.add_argument("--config", choices=("car", "multi", "waymo"), default="car",
                     help="car = configs[1] (headline); multi = configs[3] (batch 8); waymo = configs[4] shape (batch 4)")
+    ap.add_argument("--sparse-precision", choices=("bf16", "fp32"), default="fp32", help="training, with --precision bf16: "
+                    "the 64-channel sparse convolutions on the bf16 MFMA too (operands rounded in registers)")
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
                     help="--mode train: arithmetic of the dense BEV convolutions (BASELINE configs[2] trains in bf16)")
     ap.add_argument("--torch-bn", action="store_true", help="--mode train: torch's BatchNorm1d + ReLU for the sparse blocks "

@@ -26,6 +26,24 @@ def bev_precision():
     return _BEV_PRECISION
 
 
+_SPARSE_PRECISION = "fp32"
+
+
+def set_sparse_precision(precision):
+    """Arithmetic of the 64-channel sparse convolutions (forward and data gradient) in TRAINING: "fp32" = the fp32 MFMA,
+    "bf16" = operands rounded to bf16 in registers on their way into the bf16 MFMA (fp32 accumulation, fp32 tensors and
+    weights).  A process-wide kernel switch (sassd_spconv_set_bf16): inference in the same process must run with "fp32"."""
+    global _SPARSE_PRECISION
+    if precision not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+    K.spconv_set_bf16(precision == "bf16")
+    _SPARSE_PRECISION = precision
+
+
+def sparse_precision():
+    return _SPARSE_PRECISION
+
+
 _n_ptr_cache = {}
 
 

@@ -17,6 +17,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 
 constexpr int kK = 27;
@@ -63,6 +64,7 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int K, float *__
     packed[i] = transposed ? w[((size_t)k * COUT + co) * CIN + ci] : w[((size_t)k * CIN + ci) * COUT + co];
 }
 
+int g_spconv_bf16 = 0;          // 1: 16x16 tiles of spconv_gq_kernel on the bf16 MFMA (training in the bf16 mode; sassd_spconv_set_bf16)
 int g_spconv_dbg = 0;           // reserved debug switch (tools/ablate_spconv.py); 0 in production
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -925,6 +927,10 @@ namespace {
 // gradient, bit8 legacy
 // register-stationary kernel; bits 16.. select the workgroup geometry (0 default)
 extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags & 0xFFFF; g_spconv_cfg = flags >> 16; }
+
+// 1: forward / data-gradient launches of the 64-channel layers multiply on the bf16 MFMA (operands rounded to bf16 in
+// registers, fp32 accumulation, fp32 tensors and weight packs); 0 (default): fp32 MFMA.  Process-wide, like the debug switch.
+extern "C" void sassd_spconv_set_bf16(int on) { g_spconv_bf16 = on ? 1 : 0; }
 
 extern "C" size_t sassd_spconv_packed_floats(int K, int Cin, int Cout) { return (size_t)K * Cin * Cout; }
 

@@ -185,6 +185,60 @@ def test_spconv_1x1x1_streaming_kernel(dev, cin, cout, n):
         assert (y2[:n].cpu() - (x[:n].double() @ w[0].double()).float()).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("geom", [0, 9, 6, 14])
+def test_spconv_bf16_mfma_tiles(dev, geom):
+    """sassd_spconv_set_bf16(1): the 64 -> 64 layers of the balanced kernel multiply on v_mfma_f32_16x16x32_bf16 over operands
+    rounded to bf16 in registers (round to nearest even), fp32 accumulation.  Reference: the oracle's sparse conv in float64
+    over operands rounded by torch.bfloat16 -- only the fp32 summation order differs (bar 2e-5 * max|y|); against the
+    unrounded fp32 oracle the bf16 operand rounding shows (bar 2e-2 * max|y|, printed).  Submanifold and strided tables,
+    ragged row counts, epilogue, rows past the device row count untouched; narrower layers must be unaffected by the switch."""
+    idx = _level0("small", 1)
+    shape = (40, 1600, 1408)
+    idx1, nbr_d1, shape1 = orb.conv_rulebook(idx, shape, 1)
+    idx2, nbr_d2, shape2 = orb.conv_rulebook(idx1, shape1, 1)
+    _, nbr_s = orb.subm_rulebook(idx2, shape2)
+    K.debug_set_spconv(geom << 16)
+    K.spconv_set_bf16(True)
+    try:
+        for cin, cout in ((64, 64), (32, 32)):
+            for nbr, n_in in ((nbr_s, len(idx2)), (nbr_d2, len(idx1))):
+                n = len(nbr)
+                g = torch.Generator().manual_seed(cin * 100 + cout)
+                x = torch.randn(n_in, cin, generator=g)
+                w = torch.randn(27, cin, cout, generator=g) * 0.2
+                scale = torch.rand(cout, generator=g) + 0.5
+                shift = torch.randn(cout, generator=g) * 0.1
+                bf = cin == 64
+                xr, wr = (x.bfloat16().double(), w.bfloat16().double()) if bf else (x.double(), w.double())
+                nbt = torch.from_numpy(nbr).long()
+                raw = torch.zeros(n, cout, dtype=torch.float64)
+                for k in range(27):
+                    o = torch.nonzero(nbt[:, k] >= 0).view(-1)
+                    if o.numel():
+                        raw.index_add_(0, o, xr[nbt[o, k]] @ wr[k])
+                ref = torch.relu(raw * scale.double() + shift.double())
+                cap = n + 37
+                nb = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+                nb[:n] = torch.from_numpy(nbr).to(dev)
+                nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+                wp = K.spconv_pack_weight(w.to(dev))
+                y = torch.full((cap, cout), 7.0, device=dev)
+                K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout, scale.to(dev), shift.to(dev), True, y)
+                torch.cuda.synchronize()
+                top = max(1.0, raw.abs().max().item())
+                err = (y[:n].cpu().double() - ref).abs().max().item()
+                full = onets.sparse_conv(x, nbr, w)
+                err32 = (K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout)[:n].cpu() - full).abs().max().item()
+                print("bf16 MFMA tiles, geometry %d, %d -> %d, %d rows: vs rounded-operand float64 %.2e, vs the fp32 oracle %.2e "
+                      "(max |y| %.1f)" % (geom, cin, cout, n, err, err32, top))
+                assert err < (2e-5 if bf else 2e-4) * top, err
+                assert err32 < (2e-2 if bf else 2e-4) * top, err32
+                assert bool((y[n:] == 7.0).all()), "rows past the device row count must stay untouched"
+    finally:
+        K.spconv_set_bf16(False)
+        K.debug_set_spconv(0)
+
+
 def test_spconv_empty_and_tiny(dev):
     """0 rows and fewer rows than one MFMA tile."""
     for n in (0, 1, 5):

@@ -287,11 +287,12 @@ def test_training_step_waymo_scale(dev):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16sp"])
 def test_training_step_k21_vs_oracle(dev, precision):
     """BASELINE configs[2], parity ON THE WORKLOAD bench.py MEASURES: car_cfg on its full grid, batch 2 of K21 frames
     (21 500 points each, 32 245 voxels), 8 boxes per frame, the weights bench.py trains -- forward_train + backward on the
-    HIP kernels, batch built by the product's own device_batch, against the CPU oracle's step read from
+    HIP kernels, batch built by the product's own device_batch (fp32; bf16 = BEV convs on the bf16 MFMA; bf16sp = the 64-channel
+    sparse convs on it as well, the opt-in mode), against the CPU oracle's step read from
     tests/golden/train_k21_ref.npz (tests/golden/make_golden_train_k21.py; imported here for the shared seeded inputs).
     fp32: six loss terms 1e-3 relative; gradients: the stored layers TAKEN TOGETHER 2e-3 relative L2 (measured 6.6e-4), each
     stored tensor 2e-2 (measured 6.4e-3), every parameter's norm 5e-3 (1.8e-3) and seeded projection 2e-2 (7.2e-3).  The
@@ -329,7 +330,10 @@ def test_training_step_k21_vs_oracle(dev, precision):
     cal = w["cal"]
     anchors = dict(Car=torch.from_numpy(w["anchors"]).to(dev))
     anchors_bv = dict(Car=torch.from_numpy(w["anchors_bv"]).to(dev))
+    sparse_bf16 = precision == "bf16sp"                  # bf16sp: the 64-channel sparse convs on the bf16 MFMA as well
+    precision = "bf16" if sparse_bf16 else precision
     AG.set_bev_precision(precision)
+    AG.set_sparse_precision("bf16" if sparse_bf16 else "fp32")
     try:
         batch = train.device_batch([torch.from_numpy(p).to(dev) for p in clouds], [torch.from_numpy(g).to(dev) for g in gts],
                                    [np.array(["Car"] * len(g)) for g in gts], ["Car"], anchors, anchors_bv, cal["voxel_size"],
@@ -342,6 +346,7 @@ def test_training_step_k21_vs_oracle(dev, precision):
         torch.cuda.synchronize()
     finally:
         AG.set_bev_precision("fp32")
+        AG.set_sparse_precision("fp32")
     got_l = {k: float(v.detach().sum()) for k, v in losses.items()}
     ref_l = dict(zip([str(k) for k in G["loss_names"]], G["losses"]))
     assert set(got_l) == set(ref_l) and len(ref_l) == 6
@@ -379,7 +384,8 @@ def test_training_step_k21_vs_oracle(dev, precision):
         worst_p[name] = 0.0 if proj is None else abs(float(torch.dot(gd, MG.projection(name, gd.numel()))) - proj) / norm
     allrel = (num / den) ** 0.5
     cosine = dot / max((den * gg) ** 0.5, 1e-30)
-    print("K21 x 2 training step (%s) vs oracle: stored-layer gradient cosine %.5f; losses" % (precision, cosine),
+    print("K21 x 2 training step (%s%s) vs oracle: stored-layer gradient cosine %.5f; losses" % (
+        precision, " + bf16 sparse MFMA" if sparse_bf16 else "", cosine),
           {k: (round(got_l[k], 5), round(float(v), 5)) for k, v in ref_l.items()},
           "| stored-layer gradients: worst rel L2 %.2e over %d tensors, taken together %.2e | all %d parameters: worst norm "
           "error %.2e, worst projection error %.2e" % (max(worst.values()), len(worst), allrel, len(worst_n),
@@ -393,8 +399,14 @@ def test_training_step_k21_vs_oracle(dev, precision):
         assert not bad, bad
         assert max(worst_n.values()) < 5e-3, {k: v for k, v in worst_n.items() if v >= 5e-3}
         assert max(worst_p.values()) < 2e-2, {k: v for k, v in worst_p.items() if v >= 2e-2}
-    else:
+    elif not sparse_bf16:
         assert allrel < 1.2e-1 and cosine > 0.99, (allrel, cosine)
+        assert max(worst_n.values()) < 0.25, {k: v for k, v in worst_n.items() if v >= 0.25}
+    else:
+        # the opt-in mode (bench.py --sparse-precision bf16; +4.6 % samples/s): rounding the operands of the 64-channel
+        # sparse convs as well roughly doubles the gradient noise of this workload -- measured 1.44e-1 together, cosine
+        # 0.9897, norms 12 %; that is why it is not the default
+        assert allrel < 2e-1 and cosine > 0.98, (allrel, cosine)
         assert max(worst_n.values()) < 0.25, {k: v for k, v in worst_n.items() if v >= 0.25}
 
 

@@ -34,6 +34,9 @@ pmc stall_sparse_car_r3geom "$SQ" python $R/tools/run_sparse_only.py --config ca
 pmc stall_sparse_multi "$SQ" python $R/tools/run_sparse_only.py --config multi --reps 3
 pmc stall_wino4 "$SQ" python $R/tools/run_wino4.py --profile --reps 5
 python tools/collect_profiles.py r04 > $O/collect.log 2>&1; echo "collect rc=$?"
+timeout 900 python bench.py > $O/bench_default.log 2>&1; echo "bench default rc=$?"
+timeout 600 python bench.py --mode train --steps 40 --warmup 8 --sparse-precision bf16 > $O/bench_train_bf16sp.log 2>&1; echo "train bf16 + bf16 sparse rc=$?"
+python tools/collect_profiles.py r04 >> $O/collect.log 2>&1; echo "collect rc=$?"
 for c in car multi; do
   timeout 400 python tools/ablate_spconv.py --config $c --ablate 2>&1 | grep -v "^/opt" > $O/spconv_layers_$c.txt; echo "layers $c rc=$?"
 done
@@ -52,6 +55,5 @@ timeout 300 python bench.py --config waymo --steps 20 --warmup 5 --no-cpu-baseli
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-train > $O/bench_20steps.log 2>&1; echo "200 steps rc=$?"
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-train --wino4-cfg 1 > $O/bench_fp32mfma.log 2>&1; echo "fp32-MFMA A/B rc=$?"
 timeout 300 python tools/run_bf16_conv.py --ablate > $O/bf16_conv_timing.json 2>/dev/null; echo "bf16 timing rc=$?"
-timeout 900 python bench.py > $O/bench_default.log 2>&1; echo "bench default rc=$?"
 python tools/collect_profiles.py r04 >> $O/collect.log 2>&1; echo "collect rc=$?"
 grep -o '"traffic_measured_at": [^,]*' $O/bench_default.log | head -3; grep -o '"value": [0-9.]*' $O/bench_default.log $O/bench_train_bf16.log $O/bench_multi.log $O/bench_waymo.log $O/bench_20steps.log $O/bench_fp32mfma.log

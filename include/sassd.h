@@ -51,6 +51,12 @@ const char *sassd_last_hip_error_string(void);
  * binding at load time) sets the same word for an unmodified test / bench command. */
 void sassd_debug_set_spconv(int flags);
 
+/* Training option (off by default, process-wide like the switch above; no reference counterpart -- the reference trains its
+ * spconv layers in fp32): on = the forward / data-gradient launches of the 64-channel sparse layers (sassd_spconv_fwd,
+ * sassd_spconv_bwd_data on the balanced kernel) multiply on the bf16 MFMA -- operands rounded to bf16 in registers (round to
+ * nearest even), fp32 accumulation, fp32 tensors and weight packs unchanged.  Inference parity is stated for off. */
+void sassd_spconv_set_bf16(int on);
+
 /* hipGraph capture of a launch sequence issued through this ABI (the reference has no counterpart: its frame is
  * ~10^2 host-issued launches with >= 6 host syncs).  begin -> any sassd_* calls on `stream` (streams
  * joined to it through events are captured too) -> end returns an executable graph; launch replays it. */

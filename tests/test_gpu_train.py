@@ -287,7 +287,8 @@ def test_training_step_waymo_scale(dev):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16sp"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16sp", pytest.param("bf16sp-fwd", marks=pytest.mark.slow),
+                                       pytest.param("bf16sp-bwd", marks=pytest.mark.slow)])
 def test_training_step_k21_vs_oracle(dev, precision):
     """BASELINE configs[2], parity ON THE WORKLOAD bench.py MEASURES: car_cfg on its full grid, batch 2 of K21 frames
     (21 500 points each, 32 245 voxels), 8 boxes per frame, the weights bench.py trains -- forward_train + backward on the
@@ -330,10 +331,11 @@ def test_training_step_k21_vs_oracle(dev, precision):
     cal = w["cal"]
     anchors = dict(Car=torch.from_numpy(w["anchors"]).to(dev))
     anchors_bv = dict(Car=torch.from_numpy(w["anchors_bv"]).to(dev))
-    sparse_bf16 = precision == "bf16sp"                  # bf16sp: the 64-channel sparse convs on the bf16 MFMA as well
-    precision = "bf16" if sparse_bf16 else precision
+    sparse_bf16 = precision.startswith("bf16sp")         # bf16sp: the 64-channel sparse convs on the bf16 MFMA as well
+    sparse_mode = {"bf16sp": "bf16", "bf16sp-fwd": "bf16-fwd", "bf16sp-bwd": "bf16-bwd"}.get(precision, "fp32")
+    precision = "bf16" if sparse_bf16 else precision     # (-fwd / -bwd: one half only; SASSD_FULL_TESTS=1, printed, same bars)
     AG.set_bev_precision(precision)
-    AG.set_sparse_precision("bf16" if sparse_bf16 else "fp32")
+    AG.set_sparse_precision(sparse_mode)
     try:
         batch = train.device_batch([torch.from_numpy(p).to(dev) for p in clouds], [torch.from_numpy(g).to(dev) for g in gts],
                                    [np.array(["Car"] * len(g)) for g in gts], ["Car"], anchors, anchors_bv, cal["voxel_size"],
@@ -385,7 +387,7 @@ def test_training_step_k21_vs_oracle(dev, precision):
     allrel = (num / den) ** 0.5
     cosine = dot / max((den * gg) ** 0.5, 1e-30)
     print("K21 x 2 training step (%s%s) vs oracle: stored-layer gradient cosine %.5f; losses" % (
-        precision, " + bf16 sparse MFMA" if sparse_bf16 else "", cosine),
+        precision, " + bf16 sparse MFMA (%s)" % sparse_mode if sparse_bf16 else "", cosine),
           {k: (round(got_l[k], 5), round(float(v), 5)) for k, v in ref_l.items()},
           "| stored-layer gradients: worst rel L2 %.2e over %d tensors, taken together %.2e | all %d parameters: worst norm "
           "error %.2e, worst projection error %.2e" % (max(worst.values()), len(worst), allrel, len(worst_n),

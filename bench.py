@@ -161,6 +161,18 @@ def stamped_traffic(fname):
 
 def train_measure(args, dev, rank, world, config="car", precision="bf16", steps=40, warmup=8, batch=0, frames=16,
                   fused_bn=None):
+    """_train_measure with the process-wide training switches (BEV precision, fused sparse BatchNorm) restored afterwards,
+    whatever happens inside: the inference half of the default line runs in the same process."""
+    from sassd import autograd as AG, spconv as SP
+    prev = (AG.bev_precision(), SP.SparseSequential.fuse_bn_relu)
+    try:
+        return _train_measure(args, dev, rank, world, config, precision, steps, warmup, batch, frames, fused_bn)
+    finally:
+        AG.set_bev_precision(prev[0])
+        SP.SparseSequential.fuse_bn_relu = prev[1]
+
+
+def _train_measure(args, dev, rank, world, config, precision, steps, warmup, batch, frames, fused_bn):
     """The training half of the BASELINE metric.  config "car": BASELINE configs[2] (car_cfg training, batch 2 / GPU,
     bf16 MFMA operands in the BEV convs); "waymo": configs[4] (180k-point frames, 0.1 m voxels, batch 4 / GPU).
     A step = device voxelize + anchor masks + rulebooks (side stream) + forward_train + backward + bucketed gradient
@@ -168,8 +180,6 @@ def train_measure(args, dev, rank, world, config="car", precision="bf16", steps=
     (rank 0; None on the other ranks).  Reference loop: tools/train_utils/__init__.py:36-61, DDP wrap tools/train.py:78."""
     from sassd import dist as D, train, autograd as AG
     AG.set_bev_precision(precision)
-    sparse_prec = getattr(args, "sparse_precision", "fp32") if precision == "bf16" else "fp32"
-    AG.set_sparse_precision(sparse_prec)
     if fused_bn is not None:
         from sassd import spconv as SP
         SP.SparseSequential.fuse_bn_relu = bool(fused_bn)
@@ -286,9 +296,6 @@ def train_measure(args, dev, rank, world, config="car", precision="bf16", steps=
             "Waymo-scale synthetic training (BASELINE configs[4]): car head, batch=%d/GPU, 180000 pts/frame, 0.1x0.1x0.15 "
             "m voxels (grid 40x1504x1504, %d active voxels in the last batch), BEV 188x188, %s, 12 synthetic car "
             "boxes/frame on occupied voxels, adam_onecycle, grad clip 10" % (B, voxels, bev))
-    if sparse_prec == "bf16":
-        desc = desc.replace("fp32 sparse trunk", "64-channel sparse convs (forward / data gradient) on the bf16 MFMA")
-    AG.set_sparse_precision("fp32")                      # process-wide kernel switch: back to the inference default
     return {
         "metric": "%s training samples/sec (whole job)" % ("KITTI-Car" if config == "car" else "Waymo-scale synthetic"),
         "value": round(sps, 3), "unit": "samples/s",
@@ -356,8 +363,6 @@ def main():
                     help="infer = BASELINE configs[1] (headline); train = configs[2] shape, extra measurement")
     ap.add_argument("--config", choices=("car", "multi", "waymo"), default="car",
                     help="car = configs[1] (headline); multi = configs[3] (batch 8); waymo = configs[4] shape (batch 4)")
-    ap.add_argument("--sparse-precision", choices=("bf16", "fp32"), default="fp32", help="training, with --precision bf16: "
-                    "the 64-channel sparse convolutions on the bf16 MFMA too (operands rounded in registers)")
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16",
                     help="--mode train: arithmetic of the dense BEV convolutions (BASELINE configs[2] trains in bf16)")
     ap.add_argument("--torch-bn", action="store_true", help="--mode train: torch's BatchNorm1d + ReLU for the sparse blocks "

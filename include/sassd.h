@@ -45,17 +45,11 @@ const char *sassd_last_hip_error_string(void);
  * bit1 no LDS slab update, bit2 no MFMA, bit4 ticket offset assignment (round-3 kernel), bit5 every gather reads row 0,
  * bit6 one weight image for every offset (bits 5 / 6 keep the number of loads in flight unchanged: a load under a branch
  * changes the compiler's wait counts, the very thing being measured), bit8 register-stationary kernel everywhere.
- * Bits 16+: kernel / workgroup geometry -- 0 the per-shape default, 1-5 and 10 geometries of spconv_gs_kernel (10 = the
- * round-3 default everywhere), 6-9 / 11-14 the balanced kernel spconv_gq_kernel (16x16x4 tiles or 4x4x1 quads, 8 or 4
- * waves, interleaved or consecutive row slices).  The environment variable SASSD_SPCONV_DEBUG (read once by the Python
+ * Bits 16+: kernel / workgroup geometry -- 0 the per-shape, per-capacity default; 1 / 5 = spconv_gs_kernel on 4 / 8 waves,
+ * 8 / 9 = the balanced kernel spconv_gq_kernel with 4x4x1 quads / 16x16x4 tiles (the four geometries the default picks
+ * from), 10 = the round-3 default (1 or 5 by capacity) for every layer; any other value makes the launch return SASSD_EINVAL.  The environment variable SASSD_SPCONV_DEBUG (read once by the Python
  * binding at load time) sets the same word for an unmodified test / bench command. */
 void sassd_debug_set_spconv(int flags);
-
-/* Training option (off by default, process-wide like the switch above; no reference counterpart -- the reference trains its
- * spconv layers in fp32): on = the forward / data-gradient launches of the 64-channel sparse layers (sassd_spconv_fwd,
- * sassd_spconv_bwd_data on the balanced kernel) multiply on the bf16 MFMA -- operands rounded to bf16 in registers (round to
- * nearest even), fp32 accumulation, fp32 tensors and weight packs unchanged.  Inference parity is stated for off. */
-void sassd_spconv_set_bf16(int on);
 
 /* hipGraph capture of a launch sequence issued through this ABI (the reference has no counterpart: its frame is
  * ~10^2 host-issued launches with >= 6 host syncs).  begin -> any sassd_* calls on `stream` (streams

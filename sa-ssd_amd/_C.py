@@ -53,7 +53,6 @@ _SIGS = {
     "sassd_graph_launch": (_I, [_P, _P]),
     "sassd_graph_destroy": (_I, [_P]),
     "sassd_debug_set_spconv": (None, [_I]),
-    "sassd_spconv_set_bf16": (None, [_I]),
     "sassd_spconv_packed_floats": (_SZ, [_I, _I, _I]),
     "sassd_spconv_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
     "sassd_spconv_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P]),

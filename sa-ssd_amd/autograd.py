@@ -26,41 +26,6 @@ def bev_precision():
     return _BEV_PRECISION
 
 
-_SPARSE_PRECISION = "fp32"
-
-
-def set_sparse_precision(precision):
-    """Arithmetic of the 64-channel sparse convolutions (forward and data gradient) in TRAINING: "fp32" = the fp32 MFMA,
-    "bf16" = operands rounded to bf16 in registers on their way into the bf16 MFMA (fp32 accumulation, fp32 tensors and
-    weights).  A process-wide kernel switch (sassd_spconv_set_bf16): inference in the same process must run with "fp32".
-    "bf16-fwd" / "bf16-bwd" round in the forward / the data-gradient launches only (the switch is flipped around the
-    launches of SparseConvFn): for measuring which half carries the gradient noise of the mode."""
-    global _SPARSE_PRECISION
-    if precision not in ("fp32", "bf16", "bf16-fwd", "bf16-bwd"):
-        raise ValueError("precision must be 'fp32', 'bf16', 'bf16-fwd' or 'bf16-bwd', got %r" % (precision,))
-    K.spconv_set_bf16(precision == "bf16")
-    _SPARSE_PRECISION = precision
-
-
-class _sparse_bf16_if:
-    """flips the kernel switch around one launch when only that half of the step runs in bf16"""
-
-    def __init__(self, mode):
-        self.on = _SPARSE_PRECISION == mode
-
-    def __enter__(self):
-        if self.on:
-            K.spconv_set_bf16(True)
-
-    def __exit__(self, *exc):
-        if self.on:
-            K.spconv_set_bf16(False)
-
-
-def sparse_precision():
-    return _SPARSE_PRECISION
-
-
 _n_ptr_cache = {}
 
 
@@ -126,8 +91,7 @@ class SparseConvFn(Function):
         k, cin, cout = weight.shape
         x = x.contiguous()
         dev = x.device
-        with _sparse_bf16_if("bf16-fwd"):
-            y = K.spconv_fwd(x, nbr, _n_ptr(n_out, dev), max(n_out, 1), packed, k, cin, cout)
+        y = K.spconv_fwd(x, nbr, _n_ptr(n_out, dev), max(n_out, 1), packed, k, cin, cout)
         ctx.save_for_backward(x, weight)
         ctx.nbr, ctx.n_out = nbr, n_out
         ctx.subm = bool(subm) and nbr is not None and k == 27 and x.shape[0] == n_out
@@ -151,11 +115,9 @@ class SparseConvFn(Function):
             on_fwd = ctx.subm and SparseConvFn.subm_on_forward_table and n_in > 0
             wt = _spconv_t_pack(weight, reverse=on_fwd)
             if nbr is None:
-                with _sparse_bf16_if("bf16-bwd"):
-                    dx = K.spconv_bwd_data(dyc, None, _n_ptr(n_in, dev), max(n_in, 1), wt, 1, cin, cout)[:n_in]
+                dx = K.spconv_bwd_data(dyc, None, _n_ptr(n_in, dev), max(n_in, 1), wt, 1, cin, cout)[:n_in]
             elif on_fwd:
-                with _sparse_bf16_if("bf16-bwd"):
-                    dx = K.spconv_bwd_data(dyc, nbr, _n_ptr(n_in, dev), nbr.shape[0], wt, 27, cin, cout)[:n_in]
+                dx = K.spconv_bwd_data(dyc, nbr, _n_ptr(n_in, dev), nbr.shape[0], wt, 27, cin, cout)[:n_in]
             else:
                 # the transposed table depends on the rulebook alone: layers sharing an `indice_key` (conv2.0-2, ...)
                 # build it once per batch (kept on the rulebook tensor, which lives as long as the batch)
@@ -165,8 +127,7 @@ class SparseConvFn(Function):
                 else:
                     nbr_t = K.rulebook_transpose(nbr, _n_ptr(n_out, dev), nbr.shape[0], max(n_in, 1))
                     nbr._sassd_transposed = ((n_out, n_in), nbr_t)
-                with _sparse_bf16_if("bf16-bwd"):
-                    dx = K.spconv_bwd_data(dyc, nbr_t, _n_ptr(n_in, dev), max(n_in, 1), wt, 27, cin, cout)[:n_in]
+                dx = K.spconv_bwd_data(dyc, nbr_t, _n_ptr(n_in, dev), max(n_in, 1), wt, 27, cin, cout)[:n_in]
         if ctx.needs_input_grad[1]:
             if nbr is None and n_in > 0 and (cin, cout) in _SP_PAIRS:
                 # 1x1x1 layer: X^T dY through the sparse weight-gradient kernel over an identity table (centre offset only)

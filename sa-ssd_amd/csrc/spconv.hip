@@ -17,7 +17,6 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 
 constexpr int kK = 27;
@@ -64,7 +63,6 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int K, float *__
     packed[i] = transposed ? w[((size_t)k * COUT + co) * CIN + ci] : w[((size_t)k * CIN + ci) * COUT + co];
 }
 
-int g_spconv_bf16 = 0;          // 1: 16x16 tiles of spconv_gq_kernel on the bf16 MFMA (training in the bf16 mode; sassd_spconv_set_bf16)
 int g_spconv_dbg = 0;           // reserved debug switch (tools/ablate_spconv.py); 0 in production
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -493,7 +491,7 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
 
 #include "spconv_gq.h"
 
-int g_spconv_cfg = 0;           // 0 = default; 1..5, 10 geometries of spconv_gs_kernel, 6..9 of spconv_gq_kernel (tools/, tests)
+int g_spconv_cfg = 0;           // 0 = default dispatch; 1 / 5 / 8 / 9 force one of its geometries, 10 = the round-3 ones (tools/, tests)
 
 template <int CIN, int COUT, int RW, int NW, int CS, int WPS>
 int launch_gs_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp,
@@ -516,30 +514,18 @@ int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap,
               const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
 {
     (void)K;
-    // geometries (64-row slices unless noted): cfg 0 = 8 waves; 1 = 4 waves, two workgroups per CU at 64 channels;
-    // 2 = 128-row slices; 3 = 8 waves with the output channels split over wave pairs (64-channel layers)
+    // forced geometries (sassd_debug_set_spconv bits 16+): exactly the ones the default dispatch below picks by layer shape
+    // and capacity, so that tests / tools can run each of them on any input size.  (Rounds 2-4 carried nine more -- 128-row
+    // slices, channel-split wave pairs, 8-wave and consecutive-slice forms of the balanced kernel -- as measured-and-
+    // rejected alternatives; removed in round 5, their timings are in profiles/r04_spconv_layers_*.txt.)
+    //   1 = spconv_gs_kernel, 4 waves, two workgroups per CU      5 = spconv_gs_kernel, 8 waves (10 = 1 or 5 by capacity)
+    //   8 = balanced kernel, 4x4x1 quads, 4 waves                 9 = balanced kernel, 16x16x4 tiles, 4 waves
+    constexpr int Q = (COUT >= 32) ? 1 : 0;                  // (16-channel outputs have no quad form: 16x16x4 tile)
     if (g_spconv_cfg == 1) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 2) {
-        if constexpr (COUT <= 32) return launch_gs_cfg<CIN, COUT, 128, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-        else return launch_gs_cfg<CIN, COUT, 128, 4, 1, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    }
-    if constexpr (COUT == 64) {
-        if (g_spconv_cfg == 3) return launch_gs_cfg<CIN, COUT, 64, 8, 2, 4>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-        if (g_spconv_cfg == 4) return launch_gs_cfg<CIN, COUT, 64, 16, 2, 4>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    }
     if (g_spconv_cfg == 5) return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    // balanced kernel (spconv_gq.h): 6 / 9 = 16x16x4 tiles on 8 / 4 waves, 7 / 8 = 4x4x1 quads on 8 / 4 waves (16-channel
-    // outputs have no quad form and take the 16x16x4 tile)
-    constexpr int Q = (COUT >= 32) ? 1 : 0;
-    if (g_spconv_cfg == 6) return launch_gq_cfg<CIN, COUT, 8, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 9) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 7) return launch_gq_cfg<CIN, COUT, 8, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     if (g_spconv_cfg == 8) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    // 11..14: the same four on consecutive 64-row slices
-    if (g_spconv_cfg == 11) return launch_gq_cfg<CIN, COUT, 8, 2, 0, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 14) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 12) return launch_gq_cfg<CIN, COUT, 8, 2, Q, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 13) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 0>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg == 9) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (g_spconv_cfg != 0 && g_spconv_cfg != 10) return SASSD_EINVAL;
     // default (round 4, measured per layer shape; profiles/r04_spconv_layers_*.txt).  The balanced kernel pays for its
     // cooperative compaction and pays off where a layer is long enough to be bound by its heaviest workgroup: the
     // 64 -> 64 layers.  KITTI-scale single frames (one round of workgroups; level capacity 40 k rows): 16x16x4 tiles on 4
@@ -927,10 +913,6 @@ namespace {
 // gradient, bit8 legacy
 // register-stationary kernel; bits 16.. select the workgroup geometry (0 default)
 extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags & 0xFFFF; g_spconv_cfg = flags >> 16; }
-
-// 1: forward / data-gradient launches of the 64-channel layers multiply on the bf16 MFMA (operands rounded to bf16 in
-// registers, fp32 accumulation, fp32 tensors and weight packs); 0 (default): fp32 MFMA.  Process-wide, like the debug switch.
-extern "C" void sassd_spconv_set_bf16(int on) { g_spconv_bf16 = on ? 1 : 0; }
 
 extern "C" size_t sassd_spconv_packed_floats(int K, int Cin, int Cout) { return (size_t)K * Cin * Cout; }
 

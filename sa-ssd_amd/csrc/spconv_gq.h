@@ -42,20 +42,17 @@ static inline int gq_grid(int cap, int ilv) { return ilv ? 256 * (cap <= 16384 ?
 // workgroups and lasts as long as its heaviest one).  ILV = 0: 64 consecutive rows per workgroup in the XCD-aware order
 // of spconv_gs_kernel -- many rounds of workgroups per CU balance themselves, and consecutive rows share their gathered
 // neighbours in the CU's vector cache.
-// BF = 1 (training in the bf16 mode; tensors and the weight pack stay fp32): the 16x16 tile runs on
-// v_mfma_f32_16x16x32_bf16 -- a lane's KSEG gathered channels are rounded to bf16 (v_cvt_pk_bf16_f32, round to nearest
-// even) into KSEG / 8 B operands per tile, the offset's weight registers once per offset into A operands (the lane of the
-// fp32 path already holds exactly the channels q KSEG + 8 j + i the 8 K-slots of a lane want), fp32 accumulation into the
-// same slabs: KSEG / 8 * COUT / 16 instructions of 16 cycles per tile instead of KSEG * COUT / 16 of 32
-// (tools/probe_bf16_mfma.hip: layout, 248 vs 2140 cycles per 64 -> 64 tile).
-template <int CIN, int COUT, int NW, int WPS, int QUAD, int ILV, int BF = 0>
+// (Rounds 3-4 carried an opt-in bf16 form of the 16x16 tile -- operands rounded in registers onto v_mfma_f32_16x16x32_bf16,
+// +4.6 % training samples/s -- behind a process-wide switch.  Removed in round 5: it doubled the gradient noise of the bench
+// workload, failed its own whole-step bars, covered only the <= 64 k-row dispatch of the 64 -> 64 layers, and a process-wide
+// arithmetic switch is the wrong shape for an ABI.  DESIGN.md appendix A keeps the measurements.)
+template <int CIN, int COUT, int NW, int WPS, int QUAD, int ILV>
 __global__ void __launch_bounds__(NW * 64, WPS)
 spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, const int32_t *__restrict__ n_ptr,
                  int cap, const float *__restrict__ wp, const float *__restrict__ scale,
                  const float *__restrict__ shift, int relu, float *__restrict__ y, int dbg)
 {
     static_assert(!QUAD || COUT == 64 || COUT == 32, "the 4x4x1 path covers 32 / 64 output channels");
-    static_assert(!BF || (!QUAD && (CIN / 4) % 8 == 0), "the bf16 tile needs 8 gathered channels per lane and MFMA");
     constexpr int RW = 64, T = NW * 64;
     constexpr int KSEG = CIN / 4;                            // input channels per lane of a gathered tile
     constexpr int NH2 = QUAD ? 64 / COUT : 1;                // pair quads one 4x4x1 instruction covers (1 or 2)
@@ -191,22 +188,7 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
                 }
         }
     };
-    constexpr int NJ = BF ? KSEG / 8 : 1, NWB = BF ? NTW * NJ : 1;      // bf16 tile: MFMAs per channel tile, weight operands
-    auto cvt8 = [](const float *v) -> bf16x8 {
-        bf16x8 r;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
-        return r;
-    };
-    auto cvt_w = [&](const float (&b)[NB], bf16x8 (&wb)[NWB]) {            // wb[u * NJ + j] = bf16(W[k][q KSEG + 8 j + i][u 16 + m16])
-        if constexpr (BF) {
-#pragma unroll
-            for (int u = 0; u < NTW; ++u)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) wb[u * NJ + j] = cvt8(&b[u * KSEG + 8 * j]);
-        }
-    };
-    auto tile = [&](const Tile &tl, const float (&af)[KSEG], const float (&b)[NB], const bf16x8 (&wb)[NWB]) {
+    auto tile = [&](const Tile &tl, const float (&af)[KSEG], const float (&b)[NB]) {
         const int *lst = lists + tl.k * RW + tl.pb;
         if constexpr (QUAD) {
             // one instruction set = PPS pairs x COUT channels x CIN: four accumulator chains (one per input-channel
@@ -263,21 +245,11 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
                 d[u] = (f32x4){c.x, c.y, c.z, c.w};
             }
             if (!(dbg & 4)) {
-                if constexpr (BF) {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const bf16x8 xb = cvt8(&af[8 * j]);
+                for (int kk = 0; kk < KSEG; ++kk)
 #pragma unroll
-                        for (int u = 0; u < NTW; ++u)
-                            d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u * NJ + j], xb, d[u], 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < KSEG; ++kk)
-#pragma unroll
-                        for (int u = 0; u < NTW; ++u)
-                            d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u * KSEG + kk], af[kk], d[u], 0, 0, 0);
-                }
+                    for (int u = 0; u < NTW; ++u)
+                        d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u * KSEG + kk], af[kk], d[u], 0, 0, 0);
             }
             if (valid) {
 #pragma unroll
@@ -304,14 +276,12 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
         auto run_slot = [&](const float (&b)[NB], float (&bn)[NB]) -> bool {
             const int slot = cur.slot;
             bool first = true;
-            bf16x8 wb[NWB];
-            cvt_w(b, wb);                                    // (BF: the offset's weights were requested one offset ago)
             for (;;) {
                 bool more = g < hi;
                 nxt = cur;
                 if (more) g += locate(g, nxt);
                 fetch_a(nxt, a1);
-                tile(cur, a0, b, wb);
+                tile(cur, a0, b);
                 if (first) {
                     const int kn = next_slot_k(slot);
                     load_w(kn >= 0 ? kn : cur.k, bn);
@@ -328,7 +298,7 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
                 nxt = cur;
                 if (more) g += locate(g, nxt);
                 fetch_a(nxt, a0);
-                tile(cur, a1, b, wb);
+                tile(cur, a1, b);
                 if (!more) return false;
                 cur = nxt;
                 if (cur.slot != slot) return true;
@@ -361,20 +331,18 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
     }
 }
 
-template <int CIN, int COUT, int NW, int WPS, int QUAD, int ILV, int BF = 0>
+template <int CIN, int COUT, int NW, int WPS, int QUAD, int ILV>
 int launch_gq_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp,
                   const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
 {
-    if constexpr (!BF && !QUAD && (CIN / 4) % 8 == 0)
-        if (g_spconv_bf16) return launch_gq_cfg<CIN, COUT, NW, WPS, QUAD, ILV, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     constexpr size_t lds = gq_lds_bytes<COUT, NW>();
     static_assert(lds <= 160 * 1024, "workgroup slabs exceed the 160 KB LDS");
     if (cap >= (1 << 25)) return SASSD_EINVAL;               // packed list entries: input row << 6 | local row
     static std::atomic<unsigned long long> attr_done{0};
-    const void *fn = (const void *)spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD, ILV, BF>;
+    const void *fn = (const void *)spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD, ILV>;
     int rc = sassd_dyn_lds(fn, lds, attr_done);
     if (rc) return rc;
-    hipLaunchKernelGGL((spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD, ILV, BF>), dim3(gq_grid(cap, ILV)), dim3(NW * 64), lds, stream, x,
+    hipLaunchKernelGGL((spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD, ILV>), dim3(gq_grid(cap, ILV)), dim3(NW * 64), lds, stream, x,
                        nbr, n_ptr, cap, wp, scale, shift, relu, y, g_spconv_dbg & 127);
     return sassd_launch_status();
 }

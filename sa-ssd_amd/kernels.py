@@ -243,12 +243,6 @@ def debug_set_wino4(cfg=0, dbg=0):
     _C.lib().sassd_debug_set_wino4(int(cfg), int(dbg))
 
 
-def spconv_set_bf16(on):
-    """Forward / data-gradient launches of the 64-channel sparse layers on the bf16 MFMA (operands rounded in registers,
-    fp32 accumulation, fp32 tensors and packs): the training step's bf16 mode.  Process-wide; off by default."""
-    _C.lib().sassd_spconv_set_bf16(1 if on else 0)
-
-
 def debug_set_spconv(flags):
     _C.lib().sassd_debug_set_spconv(int(flags))
 

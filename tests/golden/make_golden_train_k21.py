@@ -4,7 +4,12 @@ its own full grid, batch 2 of synthetic lidar64 K21 frames (21 500 points each),
 (bench.synth_gt_on_points), random-init weights of synth.build_detector_for(seed 0, cls_bias -3) -- computed by the CPU
 oracle oracle/train_ref.py::train_step (torch-CPU autograd over oracle rulebooks; a few CPU-minutes, hence a fixture).
 Stored like tests/golden/make_golden_waymo_train.py: the six loss terms, the threshold-safe guided-anchor threshold, label /
-candidate counts, the full gradient of a subset of layers, and for EVERY parameter its gradient norm and a seeded projection.
+candidate counts, the full gradient of a subset of layers, and for EVERY parameter its gradient norm and a seeded projection
+-- in FOUR variants of the step (round 5): the fp32 oracle (keys without prefix), its float64 arbiter ("f64/"), and the
+rounded-operand step of BASELINE configs[2] (dense-conv operands rounded to bf16 where the HIP kernels round them) in fp32
+("b32/") and float64 ("b64/"); all four differentiate the full objective over the candidate set the fp32 oracle selects
+("sel0", "sel1").  "grad_dist" / "b32/grad_dist" hold every parameter's distance ||g_fp32 - g_float64||: the floor of this
+workload that the GPU bars are stated in multiples of.
 
     python tests/golden/make_golden_train_k21.py        # writes tests/golden/train_k21_ref.npz
 
@@ -43,10 +48,9 @@ def build():
     return model, cfg, w, clouds, gts
 
 
-def main():
-    import helpers as H
-    from oracle import clib, nets as onets, train_ref
-    model, c, w, clouds, gts = build()
+def step_args(model, c, w, clouds, gts):
+    """positional arguments of oracle.train_ref.train_step for this workload, plus the [B, A] anchor masks"""
+    from oracle import clib, nets as onets
     cal = w["cal"]
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     feats, coors, masks = [], [], []
@@ -60,17 +64,25 @@ def main():
     a = c.train_cfg.rpn.assigner["Car"]
     an = np.broadcast_to(w["anchors"][None], (B,) + w["anchors"].shape).copy()
     shape = tuple(model.neck.sparse_shape) if hasattr(model.neck, "sparse_shape") else (41, 1600, 1408)
-    args = (sd, feats, coors, B, shape, gts, types, ["Car"], {"Car": an}, {"Car": m}, {"Car": (a.pos_iou_thr, a.neg_iou_thr)})
-    losses, grads, ex = train_ref.train_step(*args)
-    top = torch.sigmoid(ex["cls"]).reshape(B, -1)[torch.from_numpy(m)].numpy()
-    thr = H.safe_threshold(0.1, top, margin=1e-4, step=2.5e-4)
-    if abs(thr - 0.1) > 1e-9:
-        losses, grads, ex = train_ref.train_step(*args, anchor_thr=thr)
-    out = dict(anchor_thr=np.float64(thr), n_voxels=np.int64(len(coors)), n_masked=np.int64(m.sum()),
-               n_pos=np.int64((ex["labels"] > 0).sum()), n_ext_pos=np.int64((ex["ext_labels"] > 0).sum()),
-               n_guided=np.int64(sum(len(g) for g in ex["guided"])), loss_names=np.array(sorted(losses)),
-               losses=np.array([losses[k] for k in sorted(losses)], np.float64))
-    names, norms, projs = [], [], []
+    return (sd, feats, coors, B, shape, gts, types, ["Car"], {"Car": an}, {"Car": m}, {"Car": (a.pos_iou_thr, a.neg_iou_thr)}), m
+
+
+def stored(k, g):
+    """-> (key prefix, array) of the slice of gradient `k` the fixture keeps elementwise, or None"""
+    if k in FULL or ".bn" in k or k.split(".")[-2].isdigit() and g.dim() == 1:
+        return "grad:", g.numpy().astype(np.float32)
+    if k in SLICED:
+        return "grad8:", g[:8].numpy().astype(np.float32)
+    return None
+
+
+def pack(tag, losses, grads, arbiter=None):
+    """one variant of the step under the key prefix `tag` ("" = the fp32 oracle): loss terms, stored-layer gradients
+    (float32 storage: 6e-8 relative, three orders below anything compared), norm + seeded projection of EVERY parameter's
+    gradient, and -- when `arbiter` (the float64 gradients of the same arithmetic) is given -- every parameter's distance
+    to it, ||g - g_arbiter||: the floor the GPU bars of tests/test_gpu_train.py are multiples of."""
+    out = {tag + "losses": np.array([losses[k] for k in sorted(losses)], np.float64)}
+    names, norms, projs, dn = [], [], [], []
     for k, g in grads.items():
         if g is None:
             continue
@@ -78,31 +90,57 @@ def main():
         names.append(k)
         norms.append(float(gd.norm()))
         projs.append(float(torch.dot(gd, projection(k, gd.numel()))))
-        if k in FULL or ".bn" in k or k.split(".")[-2].isdigit() and g.dim() == 1:
-            out["grad:" + k] = g.numpy().astype(np.float32)
-        elif k in SLICED:
-            out["grad8:" + k] = g[:8].numpy().astype(np.float32)
-    out.update(grad_names=np.array(names), grad_norms=np.array(norms), grad_projs=np.array(projs))
-    # the same step with the rescoring head's loss_cls left out of the differentiated sum: the part of the objective that
-    # does not depend on WHICH anchors pass the guided-anchor threshold (the bf16 comparison uses it: bf16 moves the
-    # classification scores by ~1e-2, far more than any threshold margin, and ~2000 candidates sit near the threshold)
-    _, grads_x, _ = train_ref.train_step(*args, anchor_thr=thr, grad_exclude=("loss_cls",))
-    xn, xnorm = [], []
-    for k, g in grads_x.items():
-        if g is None:
-            continue
-        xn.append(k)
-        xnorm.append(float(g.double().norm()))
-        if k in FULL or ".bn" in k or k.split(".")[-2].isdigit() and g.dim() == 1:
-            out["gradx:" + k] = g.numpy().astype(np.float32)
-        elif k in SLICED:
-            out["gradx8:" + k] = g[:8].numpy().astype(np.float32)
-    out.update(gradx_names=np.array(xn), gradx_norms=np.array(xnorm))
+        if arbiter is not None:
+            dn.append(float((gd - arbiter[k].double().reshape(-1)).norm()))
+        st = stored(k, g)
+        if st is not None:
+            out[tag + st[0] + k] = st[1]
+    out.update({tag + "grad_names": np.array(names), tag + "grad_norms": np.array(norms), tag + "grad_projs": np.array(projs)})
+    if arbiter is not None:
+        out[tag + "grad_dist"] = np.array(dn)
+    return out
+
+
+def main():
+    import time
+    import helpers as H
+    from oracle import train_ref
+    model, c, w, clouds, gts = build()
+    args, m = step_args(model, c, w, clouds, gts)
+    losses, grads, ex = train_ref.train_step(*args)
+    top = torch.sigmoid(ex["cls"]).reshape(B, -1)[torch.from_numpy(m)].numpy()
+    thr = H.safe_threshold(0.1, top, margin=1e-4, step=2.5e-4)
+    if abs(thr - 0.1) > 1e-9:
+        losses, grads, ex = train_ref.train_step(*args, anchor_thr=thr)
+    sel = ex["guided_sel"]                          # per sample: ranks among the masked anchors
+    out = dict(anchor_thr=np.float64(thr), n_voxels=np.int64(len(args[2])), n_masked=np.int64(m.sum()),
+               n_pos=np.int64((ex["labels"] > 0).sum()), n_ext_pos=np.int64((ex["ext_labels"] > 0).sum()),
+               n_guided=np.int64(sum(len(g) for g in ex["guided"])), loss_names=np.array(sorted(losses)))
+    for b in range(B):                              # the selection as indices into ALL anchors (what sassd_guided_select emits)
+        out["sel%d" % b] = np.nonzero(m[b])[0][sel[b]].astype(np.int32)
+    # the three other variants differentiate the SAME candidate set (guided_sel): the float64 arbiter of the fp32 step, and
+    # the rounded-operand step (BASELINE configs[2], bf16 dense convs) in fp32 and in float64
+    t0 = time.time()
+    l64, g64, _ = train_ref.train_step(*args, anchor_thr=thr, guided_sel=sel, dtype=torch.float64)
+    print("f64 %.0f s" % (time.time() - t0), flush=True)
+    lb32, gb32, _ = train_ref.train_step(*args, anchor_thr=thr, guided_sel=sel, bf16=("bev",))
+    lb64, gb64, _ = train_ref.train_step(*args, anchor_thr=thr, guided_sel=sel, bf16=("bev",), dtype=torch.float64)
+    out.update(pack("", losses, grads, g64))
+    out.update(pack("f64/", l64, g64))
+    out.update(pack("b32/", lb32, gb32, gb64))
+    out.update(pack("b64/", lb64, gb64))
     path = os.path.join(HERE, "train_k21_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", {k: round(v, 5) for k, v in losses.items()},
-          "thr", thr, "voxels", len(coors), "pos", int(out["n_pos"]), "ext_pos", int(out["n_ext_pos"]), "guided",
+          "thr", thr, "voxels", len(args[2]), "pos", int(out["n_pos"]), "ext_pos", int(out["n_ext_pos"]), "guided",
           int(out["n_guided"]))
+    for tag, a, b in (("fp32 vs float64", grads, g64), ("rounded fp32 vs rounded float64", gb32, gb64),
+                      ("rounded float64 vs float64", gb64, g64)):
+        ks = [k for k in a if a[k] is not None and float(b[k].norm()) > 1e-7]
+        num = sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in ks)
+        den = sum(float(b[k].double().pow(2).sum()) for k in ks)
+        per = sorted(((float((a[k].double() - b[k].double()).norm() / b[k].double().norm()), k) for k in ks), reverse=True)
+        print("%s: whole-model gradient %.2e; worst tensors %s" % (tag, (num / den) ** 0.5, [(round(v, 5), k) for v, k in per[:5]]))
 
 
 if __name__ == "__main__":

@@ -211,3 +211,73 @@ def calibrate_cls_head(model, cloud, anchors_bv, cfg, target_count=400, target_s
         model.rpn_head.conv_cls.weight.mul_(s)
         model.rpn_head.conv_cls.bias.copy_((b_old - b_old.mean()) * s + (thr_logit - qv))
     return model
+
+
+# ---- training-step parity: selection tap + arbiter bars (round 5) --------------------------------------------------------
+class GuidedSelectionTap:
+    """Context manager around sassd.kernels.guided_select (the one discrete decision of a training step that depends on
+    network outputs).  Records the selection the HIP kernel makes -- `.selected[b]`: ascending anchor indices of sample b --
+    or, with `force` (per sample an ascending int array of anchor indices), replaces the kernel's selection by the given one
+    (the kernel still runs; its result is recorded in `.own`), so that two implementations whose scores differ by more than
+    any threshold margin (bf16) differentiate the same candidate set."""
+
+    def __init__(self, force=None):
+        self.force, self.selected, self.own = force, None, None
+
+    def __enter__(self):
+        import torch
+        from sassd import kernels as K
+        self._K, self._orig = K, K.guided_select
+
+        def tapped(cls_preds, anchor_mask, score_thr, cap, overflow):
+            sel, cnt = self._orig(cls_preds, anchor_mask, score_thr, cap, overflow)
+            c = cnt.cpu().numpy()
+            self.own = [sel[b, :int(c[b])].cpu().numpy() for b in range(sel.shape[0])]
+            self.selected = self.own
+            if self.force is not None:
+                assert len(self.force) == sel.shape[0]
+                sel = torch.arange(cap, dtype=torch.int64, device=sel.device).repeat(sel.shape[0], 1)   # padding: sel[b][p] = p
+                for b, f in enumerate(self.force):
+                    assert len(f) <= cap
+                    sel[b, :len(f)] = torch.as_tensor(np.asarray(f, np.int64), device=sel.device)
+                cnt = torch.tensor([len(f) for f in self.force], dtype=torch.int32, device=sel.device)
+                self.selected = [np.asarray(f, np.int64) for f in self.force]
+            return sel, cnt
+        K.guided_select = tapped
+        return self
+
+    def __exit__(self, *exc):
+        self._K.guided_select = self._orig
+
+
+def selection_as_mask_ranks(selected, mask):
+    """anchor indices (into all anchors of a sample) -> ranks among the sample's masked anchors (oracle guided_sel form)"""
+    rank = np.cumsum(np.asarray(mask).astype(np.int64)) - 1
+    sel = np.asarray(selected, np.int64)
+    assert np.asarray(mask)[sel].all(), "a selected anchor lies outside the anchor mask"
+    return rank[sel]
+
+
+def arbiter_report(got, arb, floor32, factor=3.0, rel_floor=2e-4, whole_factor=2.0, whole_floor=5e-5):
+    """The round-5 gradient bar.  got / arb / floor32: {name: tensor} -- the GPU gradient, the ARBITER (the same arithmetic
+    in float64) and the CPU oracle's own fp32 evaluation of it.  A tensor passes when the GPU is no farther from the arbiter
+    than `factor` x the CPU oracle is (or than rel_floor x ||arbiter||, for tensors the two CPU evaluations happen to agree
+    on); the whole model (all tensors concatenated) likewise with whole_factor / whole_floor.
+    -> (bad {name: (e_gpu, e_cpu)} relative, whole (E_gpu, E_cpu) relative, rows sorted by e_gpu)."""
+    rows, bad = [], {}
+    ng = nc = den = 0.0
+    for k, a in arb.items():
+        a = a.detach().double().cpu().reshape(-1)
+        n = float(a.norm())
+        if n < 1e-7 or k not in got or got[k] is None:
+            continue
+        eg = float((got[k].detach().double().cpu().reshape(-1) - a).norm())
+        ec = float((floor32[k].detach().double().cpu().reshape(-1) - a).norm())
+        ng, nc, den = ng + eg * eg, nc + ec * ec, den + n * n
+        rows.append((eg / n, ec / n, k))
+        if not eg <= max(factor * ec, rel_floor * n):
+            bad[k] = (eg / n, ec / n)
+    rows.sort(reverse=True)
+    whole = ((ng / den) ** 0.5, (nc / den) ** 0.5)
+    whole_ok = whole[0] <= max(whole_factor * whole[1], whole_floor)
+    return bad, whole, whole_ok, rows

@@ -107,27 +107,16 @@ def _gt(seed, n, types=None, xmax=32.0):
     return b
 
 
-# (each case runs the CPU oracle's step inside the test: ~1 minute.  The default run keeps the three-class half grid and the
-# bf16 whole-step bar; car_cfg fp32 on its full grid is held by the stored golden of test_training_step_k21_vs_oracle
-# (the bench workload) and, like multi_cfg on its full grid, runs here under SASSD_FULL_TESTS=1)
-@pytest.mark.parametrize("cfgfile,names,HALF,precision",
-                         [pytest.param("configs/car_cfg.py", ["Car"], FULL, "fp32", marks=pytest.mark.slow),
-                          ("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"], HALF, "fp32"),
-                          pytest.param("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"], FULL, "fp32",
-                                       marks=pytest.mark.slow),
-                          ("configs/car_cfg.py", ["Car"], FULL, "bf16")])
-def test_training_step_vs_oracle(dev, cfgfile, names, HALF, precision):
-    """forward_train on the GPU (HIP kernels under autograd) vs oracle/train_ref.train_step on the CPU: the six loss
-    terms and the gradient of their sum with respect to every parameter.  car_cfg on its own full 1408-wide grid
-    (BASELINE configs[2]); the three-class multi_cfg (per-class anchors / masks / thresholds, 18 + 42 + 12 head
-    channels) on a half-width grid AND on its own full 1408-wide grid (211 200 anchors)."""
-    from oracle import clib, nets as onets, train_ref
+def oracle_case(cfgfile, names, HALF):
+    """The seeded two-cloud workload of test_training_step_vs_oracle, built on the CPU (shared with the CPU-only arbiter tests,
+    tests/test_train_arbiter_cpu.py): -> dict(c, model (CPU), sd, types, gts, masks, np_inputs (per-sample voxel arrays / anchors
+    / masks as numpy), ref_args (positional arguments of oracle.train_ref.train_step))."""
+    from oracle import clib, nets as onets
     c = Config.fromfile(cfgfile)
     mcfg = dict(c.model)
     mcfg["neck"] = dict(mcfg["neck"], output_shape=list(HALF["sparse_shape"]))
     model = H.randomize_detector(build_detector(mcfg, c.train_cfg, c.test_cfg), seed=7, cls_bias=-3.0)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    model = model.to(dev).train()
     anbv = {n: _half_anchors(n, HALF["bev_w"]) for n in names}
     clouds = [H.frame("small", 31), H.frame("k17", 32)[::3]]
     clouds = [p[p[:, 0] < HALF["pc_range"][3]] for p in clouds]
@@ -137,113 +126,112 @@ def test_training_step_vs_oracle(dev, cfgfile, names, HALF, precision):
         types = [np.array(["Car", "Pedestrian", "Cyclist", "Car", "Pedestrian"]),
                  np.array(["Cyclist", "Car", "Car", "Pedestrian", "Cyclist", "Van", "Car"])]
     gts = [_gt(1, len(types[0]), types[0], HALF["xmax"]), _gt(2, len(types[1]), types[1], HALF["xmax"])]
-    kw = dict(voxels=[], coordinates=[], num_points=[], anchors={n: [] for n in names},
-              anchors_mask={n: [] for n in names}, gt_bboxes=[], gt_labels=[], gt_types=types)
+    npi = dict(voxels=[], coordinates=[], num_points=[], anchors={n: [] for n in names}, anchors_mask={n: [] for n in names},
+               gt_bboxes=gts, gt_labels=[[names.index(t) + 1 if t in names else 0 for t in ty] for ty in types])
     feats, coors, masks = [], [], {n: [] for n in names}
     for b, p in enumerate(clouds):
         v, co, n = clib.points_to_voxel(p, HALF["voxel_size"], HALF["pc_range"], 5, True, 20000)
         feats.append(clib.voxel_mean(v, n))
         coors.append(np.concatenate([np.full((len(co), 1), b, np.int32), co], 1))
-        kw["voxels"].append(torch.from_numpy(v).to(dev)); kw["coordinates"].append(torch.from_numpy(co).to(dev))
-        kw["num_points"].append(torch.from_numpy(n).to(dev))
+        npi["voxels"].append(v); npi["coordinates"].append(co); npi["num_points"].append(n)
         for nm in names:
             m = onets.anchors_mask(co, anbv[nm][1], HALF["voxel_size"], HALF["pc_range"], HALF["grid_xyz"], 1)
             masks[nm].append(m)
-            kw["anchors"][nm].append(torch.from_numpy(anbv[nm][0]).to(dev))
-            kw["anchors_mask"][nm].append(torch.from_numpy(m).to(dev))
-        kw["gt_bboxes"].append(torch.from_numpy(gts[b]).to(dev))
-        lab = [names.index(t) + 1 if t in names else 0 for t in types[b]]
-        kw["gt_labels"].append(torch.tensor(lab, dtype=torch.int64, device=dev))
+            npi["anchors"][nm].append(anbv[nm][0]); npi["anchors_mask"][nm].append(m)
     acfg = {n: (c.train_cfg.rpn.assigner[n].pos_iou_thr, c.train_cfg.rpn.assigner[n].neg_iou_thr) for n in names}
     ref_args = (sd, np.concatenate(feats), np.concatenate(coors), 2, HALF["sparse_shape"], gts, types, names,
                 {n: np.stack([anbv[n][0]] * 2) for n in names}, {n: np.stack(masks[n]) for n in names}, acfg)
-    ref_l, ref_g, ex = train_ref.train_step(*ref_args)
-    # threshold-safe guided-anchor selection: move train_cfg.rpn.anchor_thr (0.1) to a nearby value that no masked
-    # anchor score of the oracle approaches, so that GPU and CPU select the same anchors (a different selection would put
-    # a PSWarp-sampling gradient of a borderline box into the box head of one side only)
-    top = torch.sigmoid(ex["cls"]).reshape(2, -1, len(names)).max(-1)[0]
-    msk = torch.from_numpy(np.concatenate([np.stack(masks[n]) for n in names], 1)).reshape(2, -1)
-    vals = top[msk].numpy()
-    # (round 4: the middle of the WIDEST gap between neighbouring scores within 0.1 +- 0.02 instead of the first threshold
-    # with a 1e-5 ... 1e-4 margin: a new fp32 summation order inside the sparse convs moved one score across a 1e-5
-    # margin -- one borderline anchor in the box head of one side only is a 2e-2 error of that head's gradient)
-    thr, near = H.widest_gap_threshold(0.1, vals, span=0.02)
-    assert near > 2e-5, near
-    if abs(thr - 0.1) > 1e-9:
-        ref_l, ref_g, ex = train_ref.train_step(*ref_args, anchor_thr=thr)
-    model.train_cfg.rpn.anchor_thr = thr
+    return dict(c=c, model=model, sd=sd, types=types, gts=gts, masks=masks, np_inputs=npi, ref_args=ref_args)
+
+
+# (each case runs the CPU oracle's step inside the test, twice -- float64 arbiter + fp32 floor: ~1-2 minutes.  The default run
+# holds car_cfg on its own full grid in fp32 and bf16 and the three-class half grid; multi_cfg on its full grid runs under
+# SASSD_FULL_TESTS=1)
+@pytest.mark.parametrize("cfgfile,names,HALF,precision",
+                         [("configs/car_cfg.py", ["Car"], FULL, "fp32"),
+                          ("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"], HALF, "fp32"),
+                          pytest.param("configs/multi_cfg.py", ["Car", "Pedestrian", "Cyclist"], FULL, "fp32",
+                                       marks=pytest.mark.slow),
+                          ("configs/car_cfg.py", ["Car"], FULL, "bf16")])
+def test_training_step_vs_oracle(dev, cfgfile, names, HALF, precision):
+    """forward_train on the GPU (HIP kernels under autograd) vs oracle/train_ref.train_step on the CPU: the six loss
+    terms and the gradient of their sum with respect to every parameter.  car_cfg on its own full 1408-wide grid
+    (BASELINE configs[2]) in fp32 and with the bf16 dense convs; the three-class multi_cfg (per-class anchors / masks /
+    thresholds, 18 + 42 + 12 head channels) on a half-width grid AND on its own full 1408-wide grid (211 200 anchors).
+    Round 5: the reference value is the oracle's step in FLOAT64 (bf16: with the dense-conv operands rounded like the HIP
+    kernels round them), evaluated on the candidate set the GPU selected at the configured threshold; the GPU gradient must
+    be no farther from it than a small multiple of the distance the CPU oracle's own fp32 evaluation has."""
+    from oracle import train_ref
+    case = oracle_case(cfgfile, names, HALF)
+    c, sd, types, gts, masks, ref_args = (case[k] for k in ("c", "sd", "types", "gts", "masks", "ref_args"))
+    model = case["model"].to(dev).train()
+    npi = case["np_inputs"]
+    kw = dict(voxels=[torch.from_numpy(v).to(dev) for v in npi["voxels"]],
+              coordinates=[torch.from_numpy(v).to(dev) for v in npi["coordinates"]],
+              num_points=[torch.from_numpy(v).to(dev) for v in npi["num_points"]],
+              anchors={n: [torch.from_numpy(a).to(dev) for a in npi["anchors"][n]] for n in names},
+              anchors_mask={n: [torch.from_numpy(a).to(dev) for a in npi["anchors_mask"][n]] for n in names},
+              gt_bboxes=[torch.from_numpy(g).to(dev) for g in gts],
+              gt_labels=[torch.tensor(l, dtype=torch.int64, device=dev) for l in npi["gt_labels"]], gt_types=types)
     from sassd import autograd as AG
+    # 1. the GPU step, at the CONFIGURED guided-anchor threshold (train_cfg.rpn.anchor_thr = 0.1); the selection its kernel
+    #    makes is recorded
     try:
         AG.set_bev_precision(precision)
-        losses = model(None, [dict(sample_idx=0), dict(sample_idx=1)], return_loss=True, **kw)
+        with H.GuidedSelectionTap() as tap:
+            losses = model(None, [dict(sample_idx=0), dict(sample_idx=1)], return_loss=True, **kw)
         total = sum(v.sum() for v in losses.values())
         total.backward()
         torch.cuda.synchronize()
     finally:
         AG.set_bev_precision("fp32")
-    if precision == "bf16":
-        # BASELINE configs[2]: the step with bf16 MFMA operands in the BEV convs against the fp32 oracle.  Stated
-        # tolerance: every loss term within 3 % (absolute 3e-3 for the small ones), the gradient of the whole model
-        # (all parameters concatenated) within 2 % relative L2 and cosine >= 0.9995 (measured: losses <= 1.4 %, gradient
-        # 6.1e-3, cosine 0.99998).  (Per-tensor bars are not meaningful
-        # here: the guided-anchor selection is a threshold on BEV outputs, so single borderline anchors may differ.)
-        for k, v in ref_l.items():
-            got = float(losses[k].detach().sum())
-            assert np.isfinite(got) and abs(got - v) <= max(3e-2 * abs(v), 3e-3), (k, got, v)
-        g_got = torch.cat([p.grad.detach().double().cpu().reshape(-1) for n, p in model.named_parameters() if n in ref_g])
-        g_ref = torch.cat([ref_g[n].double().reshape(-1) for n, p in model.named_parameters() if n in ref_g])
-        rel = float((g_got - g_ref).norm() / g_ref.norm())
-        cos = float(torch.dot(g_got, g_ref) / (g_got.norm() * g_ref.norm()))
-        print("bf16 training step vs fp32 oracle: losses",
-              {k: (round(float(losses[k].detach().sum()), 5), round(float(v), 5)) for k, v in ref_l.items()},
-              "whole-model gradient rel L2 %.3e cosine %.6f" % (rel, cos))
-        assert rel < 2e-2 and cos > 0.9995, (rel, cos)
-        return
-    assert set(losses) == set(ref_l) == {"aux_loss_cls", "aux_loss_reg", "rpn_loc_loss", "rpn_cls_loss",
-                                        "rpn_dir_loss", "loss_cls"}
+    # 2. the CPU oracle on the same candidate set (guided_sel): the ARBITER -- the step in float64 -- and the oracle's own
+    #    fp32 evaluation, whose distance to the arbiter is the floor of this workload.  bf16: both with the dense-conv
+    #    operands rounded where the HIP kernels round them.
+    msk = np.concatenate([np.stack(masks[n]) for n in names], 1).reshape(2, -1)
+    gsel = [H.selection_as_mask_ranks(tap.selected[b], msk[b]) for b in range(2)]
+    okw = dict(bf16=("bev",)) if precision == "bf16" else {}
+    arb_l, arb_g, ex = train_ref.train_step(*ref_args, guided_sel=gsel, dtype=torch.float64, **okw)
+    ref_l, ref_g, _ = train_ref.train_step(*ref_args, guided_sel=gsel, **okw)
+    # 3. the selection itself: the GPU may differ from the arbiter's own selection only in candidates whose arbiter score lies
+    #    within the score tolerance of the threshold (fp32: 1e-4, the north_star's box / score tolerance; bf16: 2e-3)
+    stol = 1e-4 if precision == "fp32" else 2e-3
+    nsel = ndiff = 0
+    for b in range(2):
+        diff = np.setxor1d(gsel[b], ex["guided_free"][b])
+        nsel, ndiff = nsel + len(gsel[b]), ndiff + len(diff)
+        far = [int(i) for i in diff if abs(ex["masked_top"][b][i] - 0.1) > stol]
+        assert not far, (b, far[:5], [float(ex["masked_top"][b][i]) for i in far[:5]])
+    assert set(losses) == set(arb_l) == {"aux_loss_cls", "aux_loss_reg", "rpn_loc_loss", "rpn_cls_loss", "rpn_dir_loss",
+                                         "loss_cls"}
     assert int((ex["labels"] > 0).sum()) > 10 and int((ex["ext_labels"] > 0).sum()) >= len(types[0]) + len(types[1])
     if len(names) > 1:
         assert set(np.unique(ex["labels"].numpy())) >= {0, 1, 2, 3}
-    for k, v in ref_l.items():
+    # 4. losses: fp32 1e-4 relative to the arbiter (round 4: 1e-3 against the fp32 oracle); bf16: 3 x the distance of the two
+    #    rounded CPU evaluations, at least 2e-3 (round 4: 3e-2 against the UNROUNDED oracle)
+    for k, v in arb_l.items():
         got = float(losses[k].detach().sum())
-        assert np.isfinite(got) and abs(got - v) <= 1e-3 * max(1.0, abs(v)), (k, got, v)
-    worst = {}
-    checked = 0
+        bar = 1e-4 * max(1.0, abs(v)) if precision == "fp32" else max(3 * abs(ref_l[k] - v), 2e-3 * max(1.0, abs(v)))
+        assert np.isfinite(got) and abs(got - v) <= bar, (k, got, v, ref_l[k], bar)
+    # 5. gradients, every parameter: ||g_gpu - g_arbiter|| <= 3 x ||g_cpu32 - g_arbiter|| (floor 2e-4 / bf16 2e-3 of the
+    #    tensor's norm), the whole model 2 x (floor 5e-5 / 1e-3).  No fixed per-tensor tolerance is left: round 4 held
+    #    1e-2 ... 4e-2 on the three-class heads, which said "two fp32 orders disagree", not which one is right.
+    got_g = {n: p.grad for n, p in model.named_parameters()}
     for name, p in model.named_parameters():
-        rg = ref_g.get(name)
-        if rg is None:
+        if arb_g.get(name) is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0, name
-            continue
-        assert p.grad is not None, name
-        if float(rg.norm()) < 1e-7:
-            continue
-        worst[name] = _rel(p.grad, rg)
-        checked += 1
-    # car_cfg: every tensor < 2e-3 (measured < 6e-4).
-    # Three classes: the box head's gradient sums 42 channels over 105 600 / 211 200 anchors with heavy cancellation, and
-    # the tensors at the sparse / dense seam (extra_conv, bn0, conv0) collect that rounding through eight train-mode BN
-    # layers: their relative error is set by the last bits of the sparse activations, i.e. by the ORDER in which a sparse
-    # conv sums its <= 27 offset contributions.  Measured on the half grid with three orders of round 4 (balanced kernel,
-    # round-3 geometry, register-stationary kernel) AND with the round-3 sources forced onto their own register-stationary
-    # kernel: whole-model gradient 4.9e-4 ... 5.1e-4, box head 2.0e-2 / 1.8e-2, seam tensors 2.5e-3 ... 2.7e-3 -- every
-    # one of them; only the round-3 default order, which happens to follow the oracle's ascending-offset sum, measured
-    # 4.0e-5 / 9e-4 / 7e-4 (and its bars of 2e-3 / 6e-3 were set on that).  The loss terms carry the strict bar above;
-    # the three-class gradient is held as a whole (2e-3 relative L2 over all parameters), 1e-2 per tensor, 4e-2 for the
-    # box head.
-    tols, per_tensor = {}, 2e-3
-    g_got = torch.cat([p.grad.detach().double().cpu().reshape(-1) for n, p in model.named_parameters() if n in worst])
-    g_ref = torch.cat([ref_g[n].double().reshape(-1) for n, p in model.named_parameters() if n in worst])
-    whole = float((g_got - g_ref).norm() / g_ref.norm())
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
-    print("training step vs oracle (%s, %d-wide grid, %s): whole-model gradient rel L2 %.2e; worst tensors %s"
-          % (cfgfile, HALF["sparse_shape"][2], precision, whole, [(k, "%.1e" % v) for k, v in top]))
-    if len(names) > 1:
-        assert whole < 2e-3, whole
-        per_tensor, tols = 1e-2, {"rpn_head.conv_box.bias": 4e-2, "rpn_head.conv_box.weight": 4e-2}
-    else:
-        assert whole < 5e-4, whole
-    bad = {k: v for k, v in worst.items() if not v < tols.get(k, per_tensor)}
-    assert checked >= 60 and not bad, (checked, bad)
+        else:
+            assert p.grad is not None, name
+    fl = dict(rel_floor=2e-4, whole_floor=5e-5) if precision == "fp32" else dict(rel_floor=2e-3, whole_floor=1e-3)
+    bad, whole, whole_ok, rows = H.arbiter_report(got_g, {k: v for k, v in arb_g.items() if v is not None}, ref_g, **fl)
+    print("training step vs float64 arbiter (%s, %d-wide grid, %s): %d candidates selected, %d differ from the arbiter's own "
+          "selection (all within %.0e of the threshold); whole-model gradient GPU %.2e / CPU oracle %.2e; worst tensors "
+          "(GPU, CPU oracle) %s" % (cfgfile, HALF["sparse_shape"][2], precision, nsel, ndiff, stol, whole[0], whole[1],
+                                    [(k, "%.1e" % a, "%.1e" % b_) for a, b_, k in rows[:6]]))
+    print("   losses (GPU, arbiter, CPU oracle):", {k: (round(float(losses[k].detach().sum()), 6), round(arb_l[k], 6),
+                                                        round(ref_l[k], 6)) for k in arb_l})
+    assert len(rows) >= 60 and not bad, bad
+    assert whole_ok, whole
 
 
 def test_training_step_waymo_scale(dev):
@@ -287,129 +275,190 @@ def test_training_step_waymo_scale(dev):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16sp", pytest.param("bf16sp-fwd", marks=pytest.mark.slow),
-                                       pytest.param("bf16sp-bwd", marks=pytest.mark.slow)])
-def test_training_step_k21_vs_oracle(dev, precision):
-    """BASELINE configs[2], parity ON THE WORKLOAD bench.py MEASURES: car_cfg on its full grid, batch 2 of K21 frames
-    (21 500 points each, 32 245 voxels), 8 boxes per frame, the weights bench.py trains -- forward_train + backward on the
-    HIP kernels, batch built by the product's own device_batch (fp32; bf16 = BEV convs on the bf16 MFMA; bf16sp = the 64-channel
-    sparse convs on it as well, the opt-in mode), against the CPU oracle's step read from
-    tests/golden/train_k21_ref.npz (tests/golden/make_golden_train_k21.py; imported here for the shared seeded inputs).
-    fp32: six loss terms 1e-3 relative; gradients: the stored layers TAKEN TOGETHER 2e-3 relative L2 (measured 6.6e-4), each
-    stored tensor 2e-2 (measured 6.4e-3), every parameter's norm 5e-3 (1.8e-3) and seeded projection 2e-2 (7.2e-3).  The
-    per-tensor bar is this workload's own fp32 floor, not a kernel tolerance: tests/analysis/train_order_sensitivity.py runs the CPU
-    ORACLE against its own stored golden with nothing changed but the order in which its 4-channel input layer adds the 27
-    offset terms -- forward activations move by <= 5e-5 on values of 40, FOUR of 3.9 M ReLU decisions flip (|z| < 1e-6),
-    and the BatchNorm-parameter gradients of the first sparse blocks (small residuals of cancelling sums over 30 k rows)
-    move by 6.4e-3 (descending order) / 8.8e-3 (three interleaved partial sums), the same tensors in the same ranking as
-    the GPU's deviation (down1.1.bias 6.4e-3, conv1.1.bias 5.3e-3, conv0.1.bias 5.0e-3, ...).  With the round-1 kernel on
-    the input layer the GPU happened to land on the golden's side of those decisions (7.7e-4); the round-4 input-layer
-    kernel (k ascending, one fmaf chain) lands on the other (tests/test_train_order_sensitivity_cpu.py holds the oracle-
-    vs-oracle number on CPU).  bf16 (BEV convs on the bf16
-    MFMA, what the bench line runs): the six loss terms 3 % (measured 0.3 %), and the gradient of the SELECTION-FREE part of
-    the objective (all terms but the rescoring head's loss_cls) -- stored layers taken together 1.2e-1 relative L2 with
-    cosine >= 0.99 (measured 7.8e-2), every parameter's gradient norm within 25 % (measured 17 %).  These are the numbers
-    of THIS workload, not of the kernels: the bf16 kernels equal float64 on the rounded operands to 5e-7
-    (tests/test_gpu_bf16.py) and the same step on two sparser clouds holds 6e-3 (test_training_step_vs_oracle[bf16]);
-    with 32 k voxels and 70 k masked anchors per frame the rpn-path gradient reaches the sparse trunk through eight
-    train-mode BatchNorm backward passes (each subtracts the projections of dy on 1 and x-hat: cancellation) and the
-    0.4 % operand rounding of the BEV convs comes out as 20-37 % on the first sparse blocks' BatchNorm parameters.
-    Why not the full sum in bf16: bf16 moves the classification scores by ~1e-2, far beyond any threshold margin, ~2000
-    guided candidates sit near the 0.11 threshold on this workload, so the candidate SET differs and with it, discretely,
-    the gradient of loss_cls into everything upstream (measured: 19 % on the full sum)."""
+def _k21_golden():
     import importlib.util
     import os
-    from sassd import train, autograd as AG
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     spec = importlib.util.spec_from_file_location("make_golden_train_k21", os.path.join(gdir, "make_golden_train_k21.py"))
     MG = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(MG)
-    G = np.load(os.path.join(gdir, "train_k21_ref.npz"))
+    return MG, np.load(os.path.join(gdir, "train_k21_ref.npz"))
+
+
+def _k21_step(dev, precision, force_sel=None, hook=None):
+    """forward_train + backward of the bench's training workload on the HIP kernels -> (model, losses, golden module, golden)"""
+    from sassd import train, autograd as AG
+    MG, G = _k21_golden()
     model, c, w, clouds, gts = MG.build()
     model = model.to(dev).train()
     model.train_cfg.rpn.anchor_thr = float(G["anchor_thr"])
     cal = w["cal"]
     anchors = dict(Car=torch.from_numpy(w["anchors"]).to(dev))
     anchors_bv = dict(Car=torch.from_numpy(w["anchors_bv"]).to(dev))
-    sparse_bf16 = precision.startswith("bf16sp")         # bf16sp: the 64-channel sparse convs on the bf16 MFMA as well
-    sparse_mode = {"bf16sp": "bf16", "bf16sp-fwd": "bf16-fwd", "bf16sp-bwd": "bf16-bwd"}.get(precision, "fp32")
-    precision = "bf16" if sparse_bf16 else precision     # (-fwd / -bwd: one half only; SASSD_FULL_TESTS=1, printed, same bars)
     AG.set_bev_precision(precision)
-    AG.set_sparse_precision(sparse_mode)
     try:
         batch = train.device_batch([torch.from_numpy(p).to(dev) for p in clouds], [torch.from_numpy(g).to(dev) for g in gts],
                                    [np.array(["Car"] * len(g)) for g in gts], ["Car"], anchors, anchors_bv, cal["voxel_size"],
                                    cal["pc_range"], max_points=cal["max_points"], max_voxels=cal["max_voxels"], model=model)
         assert sum(v.shape[0] for v in batch["voxels"]) == int(G["n_voxels"]) == 32245
         assert int(sum(m.sum() for m in batch["anchors_mask"]["Car"])) == int(G["n_masked"])
-        losses = model(**batch)
-        total = sum(v.sum() for k, v in losses.items() if precision == "fp32" or k != "loss_cls")
+        with H.GuidedSelectionTap(force=force_sel) as tap:
+            losses = model(**batch)
+        total = sum(v.sum() for v in losses.values())
+        if hook is not None:
+            hook("backward")
         total.backward()
         torch.cuda.synchronize()
     finally:
         AG.set_bev_precision("fp32")
-        AG.set_sparse_precision("fp32")
+    return model, losses, tap, MG, G
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_step_k21_vs_oracle(dev, precision):
+    """BASELINE configs[2], parity ON THE WORKLOAD bench.py MEASURES: car_cfg on its full grid, batch 2 of K21 frames
+    (21 500 points each, 32 245 voxels), 8 boxes per frame, the weights bench.py trains -- forward_train + backward on the
+    HIP kernels, batch built by the product's own device_batch -- against the CPU oracle's step stored in
+    tests/golden/train_k21_ref.npz (tests/golden/make_golden_train_k21.py; imported here for the shared seeded inputs).
+
+    Round 5 -- what the GPU is compared WITH.  The golden holds four evaluations of the step on one candidate set: the
+    fp32 oracle, its FLOAT64 arbiter, and the rounded-operand step (dense-conv operands rounded to bf16 exactly where the
+    HIP kernels round them) in fp32 and float64.
+      fp32: the GPU runs at the golden's threshold-safe guided-anchor threshold and must select the golden's candidates
+        itself; six loss terms 1e-4 relative to the arbiter; every stored tensor ||g_gpu - g64|| <= 3 x ||g_cpu32 - g64||
+        (floor 2e-4 of its norm), the stored layers together 2 x; every parameter's norm and seeded projection within the
+        same multiple of its stored distance ||g_cpu32 - g64||.  (Round 4 held 2e-2 per tensor against the fp32 oracle: two
+        fp32 summation orders disagree by 6.4e-3 on this workload -- tests/test_train_order_sensitivity_cpu.py -- and a
+        bar against one of them says nothing about which is right.)
+      bf16 (BEV convs on the bf16 MFMA, what the bench line runs): the FULL objective, loss_cls included -- the golden's
+        candidate set is forced onto the GPU step (bf16 moves ~2000 scores near the threshold by more than any margin; the
+        selection kernel itself is held by the fp32 case) -- against the rounded-operand float64 step, same multiples of
+        the distance between the two rounded CPU evaluations (floors 2e-3 / 1e-3).  That distance is NOT small: rounding
+        is discontinuous, activations that differ in the last fp32 bits round a few operands to different bf16 neighbours,
+        and those 2^-8 jumps feed the next layer's roundings -- the two CPU evaluations of the rounded step are about as
+        far apart as the rounded step is from the unrounded one (tests/test_train_arbiter_cpu.py asserts it from this
+        fixture; tests/analysis/train_arbiter_study.py reproduces it on a small workload).  A whole-step comparison of a
+        bf16 step can therefore not be tight for ANY implementation; what pins the bf16 step tightly is
+        test_bf16_step_launches_vs_rounded_reference below (every bf16 launch of this very step, on its live operands,
+        1e-5 against the rounded-operand product on the CPU)."""
+    tag, ftag = ("f64/", "") if precision == "fp32" else ("b64/", "b32/")
+    MG, G = _k21_golden()
+    force = [G["sel0"], G["sel1"]] if precision == "bf16" else None
+    model, losses, tap, MG, G = _k21_step(dev, precision, force)
+    if precision == "fp32":
+        for b in range(2):
+            assert np.array_equal(tap.own[b], G["sel%d" % b]), "sample %d: the GPU selected other guided anchors" % b
+    else:
+        moved = [len(np.setxor1d(tap.own[b], G["sel%d" % b])) for b in range(2)]
+        print("bf16: the kernel's own selection differs from the golden's in %s of %s candidates (golden set forced)"
+              % (moved, [len(G["sel0"]), len(G["sel1"])]))
     got_l = {k: float(v.detach().sum()) for k, v in losses.items()}
-    ref_l = dict(zip([str(k) for k in G["loss_names"]], G["losses"]))
-    assert set(got_l) == set(ref_l) and len(ref_l) == 6
-    lbar = 1e-3 if precision == "fp32" else 3e-2
-    gp, g8p = ("grad:", "grad8:") if precision == "fp32" else ("gradx:", "gradx8:")
-    gnames, gnorms = (G["grad_names"], G["grad_norms"]) if precision == "fp32" else (G["gradx_names"], G["gradx_norms"])
-    gprojs = G["grad_projs"] if precision == "fp32" else [None] * len(gnames)
-    for k, v in ref_l.items():
-        assert v != 0 and abs(got_l[k] - v) <= lbar * max(1.0, abs(v)), (k, got_l[k], v)
+    names = [str(k) for k in G["loss_names"]]
+    arb_l, flo_l = dict(zip(names, G[tag + "losses"])), dict(zip(names, G[ftag + "losses"]))
+    assert set(got_l) == set(arb_l) and len(arb_l) == 6
+    for k, v in arb_l.items():
+        bar = 1e-4 * max(1.0, abs(v)) if precision == "fp32" else max(3 * abs(flo_l[k] - v), 2e-3 * max(1.0, abs(v)))
+        assert v != 0 and abs(got_l[k] - v) <= bar, (k, got_l[k], v, flo_l[k], bar)
     params = dict(model.named_parameters())
-    worst, worst_n, worst_p, num, den, dot, gg = {}, {}, {}, 0.0, 0.0, 0.0, 0.0
+    # stored layers, elementwise
+    got, arb, flo = {}, {}, {}
     for k in G.files:
-        if k.startswith(gp) or k.startswith(g8p):
-            name = k.split(":", 1)[1]
+        if k.startswith(tag + "grad:") or k.startswith(tag + "grad8:"):
+            kind, name = k[len(tag):].split(":", 1)
             g = params[name].grad
-            if g is None:                                # (a rescoring-head parameter under the reduced objective)
-                continue
-            g = g[:8] if k.startswith(g8p) else g
-            ref = torch.from_numpy(G[k])
-            if float(ref.norm()) > 1e-7:
-                worst[name] = _rel(g, ref)
-                gdc = g.detach().cpu().double()
-                num += float((gdc - ref.double()).pow(2).sum())
-                den += float(ref.double().pow(2).sum())
-                dot += float((gdc * ref.double()).sum())
-                gg += float(gdc.pow(2).sum())
-    for name, norm, proj in zip(gnames, gnorms, gprojs):
+            assert g is not None, name
+            got[name] = g[:8] if kind == "grad8" else g
+            arb[name] = torch.from_numpy(G[k])
+            flo[name] = torch.from_numpy(G[ftag + kind + ":" + name])
+    fl = dict(rel_floor=2e-4, whole_floor=5e-5) if precision == "fp32" else dict(rel_floor=2e-3, whole_floor=1e-3)
+    bad, whole, whole_ok, rows = H.arbiter_report(got, arb, flo, **fl)
+    # every parameter: norm and seeded projection against the arbiter's, in multiples of the stored distance
+    dist = dict(zip([str(n) for n in G[ftag + "grad_names"]], G[ftag + "grad_dist"]))
+    worst_n, worst_p, bad_np = {}, {}, {}
+    for name, norm, proj in zip(G[tag + "grad_names"], G[tag + "grad_norms"], G[tag + "grad_projs"]):
         name = str(name)
-        g = params[name].grad
-        if norm < 1e-7 or (g is None and precision != "fp32"):
+        if norm < 1e-7:
             continue
+        g = params[name].grad
         assert g is not None, name
         gd = g.detach().double().cpu().reshape(-1)
-        worst_n[name] = abs(float(gd.norm()) - norm) / norm
-        worst_p[name] = 0.0 if proj is None else abs(float(torch.dot(gd, MG.projection(name, gd.numel()))) - proj) / norm
-    allrel = (num / den) ** 0.5
-    cosine = dot / max((den * gg) ** 0.5, 1e-30)
-    print("K21 x 2 training step (%s%s) vs oracle: stored-layer gradient cosine %.5f; losses" % (
-        precision, " + bf16 sparse MFMA (%s)" % sparse_mode if sparse_bf16 else "", cosine),
-          {k: (round(got_l[k], 5), round(float(v), 5)) for k, v in ref_l.items()},
-          "| stored-layer gradients: worst rel L2 %.2e over %d tensors, taken together %.2e | all %d parameters: worst norm "
-          "error %.2e, worst projection error %.2e" % (max(worst.values()), len(worst), allrel, len(worst_n),
-                                                       max(worst_n.values()), max(worst_p.values())))
-    print("largest stored-layer errors:", sorted(((round(v, 4), k) for k, v in worst.items()), reverse=True)[:10])
-    print("largest norm errors:", sorted(((round(v, 4), k) for k, v in worst_n.items()), reverse=True)[:10])
-    assert len(worst) >= 40 and len(worst_n) >= 70
-    if precision == "fp32":
-        assert allrel < 2e-3 and cosine > 0.999999, (allrel, cosine)
-        bad = {k: v for k, v in worst.items() if not v < 2e-2}
-        assert not bad, bad
-        assert max(worst_n.values()) < 5e-3, {k: v for k, v in worst_n.items() if v >= 5e-3}
-        assert max(worst_p.values()) < 2e-2, {k: v for k, v in worst_p.items() if v >= 2e-2}
-    elif not sparse_bf16:
-        assert allrel < 1.2e-1 and cosine > 0.99, (allrel, cosine)
-        assert max(worst_n.values()) < 0.25, {k: v for k, v in worst_n.items() if v >= 0.25}
-    else:
-        # the opt-in mode (bench.py --sparse-precision bf16; +4.6 % samples/s): rounding the operands of the 64-channel
-        # sparse convs as well roughly doubles the gradient noise of this workload -- measured 1.44e-1 together, cosine
-        # 0.9897, norms 12 %; that is why it is not the default
-        assert allrel < 2e-1 and cosine > 0.98, (allrel, cosine)
-        assert max(worst_n.values()) < 0.25, {k: v for k, v in worst_n.items() if v >= 0.25}
+        slack = max(3 * dist[name], fl["rel_floor"] * norm)
+        en = abs(float(gd.norm()) - norm)
+        # an error e with ||e|| <= slack, seen through a seeded unit-variance direction r: dot(e, r) ~ N(0, ||e||^2) -> 4 sigma
+        ep = abs(float(torch.dot(gd, MG.projection(name, gd.numel()))) - proj)
+        worst_n[name], worst_p[name] = en / norm, ep / norm
+        if en > slack or ep > 4 * slack:
+            bad_np[name] = (en / norm, ep / norm, slack / norm)
+    print("K21 x 2 training step (%s) vs the %s float64 arbiter: losses (GPU, arbiter, CPU fp32)" % (
+        precision, "rounded-operand" if precision == "bf16" else "fp32 oracle's"),
+        {k: (round(got_l[k], 6), round(float(v), 6), round(float(flo_l[k]), 6)) for k, v in arb_l.items()},
+        "| stored layers together: GPU %.2e / CPU oracle %.2e | worst stored tensors (GPU, CPU oracle): %s | all %d parameters: "
+        "worst norm error %.2e, worst projection error %.2e" % (whole[0], whole[1], [(k, "%.1e" % a, "%.1e" % b_) for a, b_, k in rows[:8]],
+                                                                len(worst_n), max(worst_n.values()), max(worst_p.values())))
+    assert len(rows) >= 40 and len(worst_n) >= 70
+    assert not bad, bad
+    assert whole_ok, whole
+    assert not bad_np, bad_np
+
+
+def test_bf16_step_launches_vs_rounded_reference(dev):
+    """The TIGHT pin of the bf16 training step (BASELINE configs[2]; the configuration the bench's `train` record measures):
+    every dense-convolution launch of the K21 x 2 step under set_bev_precision("bf16") -- forward, data gradient and weight
+    gradient of the eight BEVNet layers, the fused RPN head and the two rescoring-head layers -- is replayed ON ITS LIVE
+    OPERANDS (the tensors the step itself produced on the GPU) by torch-CPU convolutions over operands rounded to bf16 with
+    torch.bfloat16 where oracle.train_ref.bf16_conv_rule says the HIP kernel rounds, and must agree to 1e-5 relative L2 (fp32
+    CPU sums; the kernels measure 5e-7 against float64 in tests/test_gpu_bf16.py).  Everything between those launches is the
+    code of the fp32 step, which test_training_step_k21_vs_oracle[fp32] holds against the float64 arbiter: together the two
+    tests pin the bf16 step launch by launch, which no whole-step comparison can (see there)."""
+    from oracle import train_ref
+    from sassd import autograd as AG
+    log = []
+    fwd0, bwd0 = AG.Conv2dFn.forward, AG.Conv2dFn.backward
+
+    def fwd(ctx, x, weight, bias, packed, wino, wino4=None):
+        y = fwd0(ctx, x, weight, bias, packed, wino, wino4)
+        log.append(("fwd", x.detach(), weight.detach(), None if bias is None else bias.detach(), y.detach()))
+        return y
+
+    def bwd(ctx, dy):
+        out = bwd0(ctx, dy)
+        x, weight = ctx.saved_tensors
+        log.append(("bwd", x.detach(), weight.detach(), dy.detach(), out[0], out[1]))
+        return out
+
+    AG.Conv2dFn.forward, AG.Conv2dFn.backward = staticmethod(fwd), staticmethod(bwd)
+    try:
+        _k21_step(dev, "bf16")
+    finally:
+        AG.Conv2dFn.forward, AG.Conv2dFn.backward = staticmethod(fwd0), staticmethod(bwd0)
+    nf = sum(1 for e in log if e[0] == "fwd")
+    assert nf >= 11 and len(log) == 2 * nf, (nf, len(log))
+    rb = train_ref.round_bf16
+    worst, rounded = {}, [0, 0, 0]
+    for e in log:
+        x, w = e[1].cpu(), e[2].cpu()
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        rf, rd, rw = train_ref.bf16_conv_rule(cin, cout, ks, x.shape[3])
+        tagk = "%dx%d %d->%d" % (ks, ks, cin, cout)
+        if e[0] == "fwd":
+            ref = F.conv2d(rb(x) if rf else x, rb(w) if rf else w, None if e[3] is None else e[3].cpu(), 1, ks // 2)
+            worst[("forward", tagk)] = max(worst.get(("forward", tagk), 0.0), _rel(e[4], ref))
+            rounded[0] += rf
+        else:
+            dy = e[3].cpu()
+            if e[4] is not None:
+                ref = torch.nn.grad.conv2d_input(x.shape, rb(w) if rd else w, rb(dy) if rd else dy, padding=ks // 2)
+                worst[("data gradient", tagk)] = max(worst.get(("data gradient", tagk), 0.0), _rel(e[4], ref))
+                rounded[1] += rd
+            ref = torch.nn.grad.conv2d_weight(rb(x) if rw else x, w.shape, rb(dy) if rw else dy, padding=ks // 2)
+            worst[("weight gradient", tagk)] = max(worst.get(("weight gradient", tagk), 0.0), _rel(e[5], ref))
+            rounded[2] += rw
+    print("bf16 step, every dense-conv launch on its live operands vs the rounded-operand CPU product (%d forward / %d data-"
+          "gradient / %d weight-gradient launches on the bf16 MFMA of %d layers): %s"
+          % (rounded[0], rounded[1], rounded[2], nf, {"%s %s" % k: "%.1e" % v for k, v in sorted(worst.items())}))
+    assert rounded[0] >= 7 and rounded[1] >= 7 and rounded[2] >= 11, rounded
+    bad = {k: v for k, v in worst.items() if not v < 1e-5}
+    assert not bad, bad
 
 
 def test_training_step_waymo_vs_oracle(dev):

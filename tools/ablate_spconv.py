@@ -58,8 +58,7 @@ print("pairs", work["pairs"], "bytes_gs %.1f MB" % (work["bytes_gs"] / 1e6))
 
 # round 4: the balanced kernel (spconv_gq.h) next to the round-3 kernel; the gather / weight-load ablation bits are gone
 # (a load under a branch makes the compiler drain vmcnt(0) in front of every tile -- the very thing being measured)
-MODES = [("r3", 10 << 16), ("gq4x8w", 7 << 16), ("gq4x4w", 8 << 16), ("gq16x4w", 9 << 16), ("gq16x8w", 6 << 16),
-         ("c4x4w", 13 << 16), ("c16x4w", 14 << 16), ("default", 0)]
+MODES = [("r3", 10 << 16), ("gs4w", 1 << 16), ("gs8w", 5 << 16), ("gq4x4w", 8 << 16), ("gq16x4w", 9 << 16), ("default", 0)]
 layers = []
 lvl = 0
 for kind, cin, cout, key, wp, scale, shift in plan.sp:

@@ -82,6 +82,10 @@ class SparseConvFn(Function):
     # submanifold layers take their data gradient on the FORWARD rulebook (no transposed table, no memset): for a
     # submanifold table nbr[j][k] = i  <=>  nbr[i][26-k] = j, hence dx[i] = sum_k dy[nbr[i][k]] . W[26-k]^T -- the forward
     # kernel with the offset-reversed transposed weight image (identity tested on the oracle, tests/test_oracle_cpu.py).
+    # The identity needs UNIQUE voxel coordinates (two rows on one cell make the hash last-writer-wins and the table
+    # asymmetric); the voxelizer and the strided-conv emit produce unique coordinates by construction, and spconv itself
+    # leaves duplicate indices undefined -- a caller feeding hand-made indices with duplicates through the facade must set
+    # SASSD_SUBM_FWD_TABLE=0 (the transposed table is exact for any table).
     # False: the transposed-table formulation for every layer (A/B, tests).
     subm_on_forward_table = os.environ.get("SASSD_SUBM_FWD_TABLE", "1") != "0"
 

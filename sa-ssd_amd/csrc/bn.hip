@@ -4,11 +4,13 @@
 // (mmdet/models/necks/cmn.py:147-173 through spconv.SparseSequential): in training mode torch runs them as
 // collect-statistics + transform + clamp (forward) and threshold + reduce + elementwise (backward), six launches per
 // layer over a 1-9 MB tensor, i.e. launch latency.  Here: three short launches each way.
-//   forward   bn_stats_kernel      per-channel sum / sum of squares in double -> one partial pair per block
-//             bn_finalize_kernel   ONE block adds the <= 256 block partials in a fixed order (deterministic; no
-//                                  inter-workgroup hand-off inside a launch): mean / invstd, running statistics (unbiased
-//                                  variance, like torch).  (Round 2 let every block of the apply launch redo this
-//                                  reduction -- 256 KB of partials per block: 18 us per launch instead of 6.)
+//   forward   bn_stats_kernel      per-channel sum / sum of squares (16-byte loads, <= 16 elements in fp32, then double)
+//                                  -> one partial pair per block and channel
+//             bn_finalize_kernel   one block PER CHANNEL adds the <= 1024 block partials in a fixed order (deterministic):
+//                                  mean / invstd, running statistics (unbiased variance, like torch).  (Round 2 let every
+//                                  block of the apply launch redo this reduction -- 256 KB of partials per block: 18 us
+//                                  per launch instead of 6; rounds 2-4 used ONE block for all channels: 8.8 us of
+//                                  dependent-load latency.)
 //             bn_apply_relu_kernel y = max(0, (x - mean) * (invstd * gamma) + beta)
 //   backward  bn_bwd_reduce_kernel dz = dy * (z > 0) with z recomputed from x exactly as the forward computed it;
 //                                  partials of sum dz, sum dz * xhat
@@ -30,52 +32,70 @@ struct BnFwdArgs {
     float momentum, eps;
 };
 
-// 256 threads = (256 / C) row lanes x C channels
+// block-wide sum of two doubles (256 threads, fixed xor-shuffle tree + the four wave results in wave order); valid in thread 0
+__device__ __forceinline__ void bn_block_sum2(double &a, double &b, double (*red)[4])
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = a; red[1][w] = b; }
+    __syncthreads();
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
+// 256 threads = (1024 / C) row lanes x C / 4 channel quads: one 16-byte load per thread and row (round 5; rounds 2-4 loaded
+// 4 bytes per thread and converted every element to double: 7.1 us at 36 k x 64).  A thread adds <= 16 elements per channel
+// in fp32 before it widens (like bn2d_stats_kernel); the row lanes of a channel are added in lane order.
 __global__ void __launch_bounds__(256) bn_stats_kernel(BnFwdArgs P)
 {
-    __shared__ double red[2][256];
-    const int C = P.C, rl = 256 / C;
-    const int c = threadIdx.x % C, r = threadIdx.x / C;
+    __shared__ double red[2][4][256];
+    const int C = P.C, C4 = C >> 2, rl = 256 / C4;
+    const int c4 = threadIdx.x % C4, r = threadIdx.x / C4;
     const int r0 = blockIdx.x * P.rows_per_block, r1 = min(r0 + P.rows_per_block, P.n);
-    double s = 0.0, q = 0.0;
-    if (r < rl)
-        for (int row = r0 + r; row < r1; row += rl) {
-            const double v = (double)P.x[(size_t)row * C + c];
-            s += v;
-            q += v * v;
+    double ds[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x4 fs = {0.f, 0.f, 0.f, 0.f}, fq = fs;
+    int cnt = 0;
+    for (int row = r0 + r; row < r1; row += rl) {
+        const f32x4 v = ((const f32x4 *)P.x)[(size_t)row * C4 + c4];
+        fs += v;
+        fq += v * v;
+        if (++cnt == 16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ds[j] += (double)fs[j]; dq[j] += (double)fq[j]; }
+            fs = fq = (f32x4){0.f, 0.f, 0.f, 0.f};
+            cnt = 0;
         }
-    red[0][threadIdx.x] = s;
-    red[1][threadIdx.x] = q;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][j][threadIdx.x] = ds[j] + (double)fs[j];
+        red[1][j][threadIdx.x] = dq[j] + (double)fq[j];
+    }
     __syncthreads();
     if (threadIdx.x < C) {
+        const int q = threadIdx.x >> 2, j = threadIdx.x & 3;
         double ss = 0.0, qq = 0.0;
-        for (int k = 0; k < rl; ++k) { ss += red[0][k * C + threadIdx.x]; qq += red[1][k * C + threadIdx.x]; }
+        for (int k = 0; k < rl; ++k) { ss += red[0][j][k * C4 + q]; qq += red[1][j][k * C4 + q]; }
         P.part[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = ss;
         P.part[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = qq;
     }
 }
 
-// sums of the block partials for every channel, identical in every block: thread (r, c) adds the partials of blocks
-// r, r + rl, ... in order, the rl partial sums are combined in order of r
-template <int NT>
-__device__ __forceinline__ void bn_reduce_partials(const double *part, int nb, int C, double (*red)[NT], double *out0,
-                                                   double *out1)
+// sums of the block partials of ONE channel (block c of the finalize launches; 256 threads): thread t adds the partials of
+// blocks t, t + 256, ... in order, then the fixed block tree.  (Rounds 2-4: one 1024-thread block for all channels walked
+// <= 1024 / (1024 / C) dependent loads per thread -- 8.8 us of load latency per call; C blocks: one to four loads.)
+__device__ __forceinline__ void bn_reduce_channel(const double *part, int nb, int C, int c, double (*red)[4], double &a, double &b)
 {
-    const int rl = NT / C, c = threadIdx.x % C, r = threadIdx.x / C;
-    double a = 0.0, b = 0.0;
-    for (int k = r; k < nb; k += rl) {
+    a = 0.0; b = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256) {
         a += part[((size_t)k * 2 + 0) * C + c];
         b += part[((size_t)k * 2 + 1) * C + c];
     }
-    red[0][threadIdx.x] = a;
-    red[1][threadIdx.x] = b;
-    __syncthreads();
-    if (threadIdx.x < C) {
-        double sa = 0.0, sb = 0.0;
-        for (int k = 0; k < rl; ++k) { sa += red[0][k * C + threadIdx.x]; sb += red[1][k * C + threadIdx.x]; }
-        *out0 = sa;
-        *out1 = sb;
-    }
+    bn_block_sum2(a, b, red);
 }
 
 struct BnApplyArgs {
@@ -87,22 +107,22 @@ struct BnApplyArgs {
     float momentum, eps;
 };
 
-// (1024 threads: the <= 1024 block partials of a channel are added by 1024 / C thread groups, 15 -> 4 us per call)
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(BnApplyArgs P)
+__global__ void __launch_bounds__(256) bn_finalize_kernel(BnApplyArgs P)
 {
-    __shared__ double red[2][1024];
-    double ss = 0.0, qq = 0.0;
-    bn_reduce_partials<1024>(P.part, P.nb, P.C, red, &ss, &qq);
-    if (threadIdx.x < P.C) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x;
+    double ss, qq;
+    bn_reduce_channel(P.part, P.nb, P.C, c, red, ss, qq);
+    if (threadIdx.x == 0) {
         const double mean = ss / P.n;
         double var = qq / P.n - mean * mean;
         if (var < 0.0) var = 0.0;
-        P.mean[threadIdx.x] = (float)mean;
-        P.invstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)P.eps));
+        P.mean[c] = (float)mean;
+        P.invstd[c] = (float)(1.0 / sqrt(var + (double)P.eps));
         if (P.rmean) {
             const double unb = P.n > 1 ? var * P.n / (P.n - 1) : var;
-            P.rmean[threadIdx.x] = (float)((1.0 - P.momentum) * P.rmean[threadIdx.x] + P.momentum * mean);
-            P.rvar[threadIdx.x] = (float)((1.0 - P.momentum) * P.rvar[threadIdx.x] + P.momentum * unb);
+            P.rmean[c] = (float)((1.0 - P.momentum) * P.rmean[c] + P.momentum * mean);
+            P.rvar[c] = (float)((1.0 - P.momentum) * P.rvar[c] + P.momentum * unb);
         }
     }
 }
@@ -141,41 +161,58 @@ struct BnBwdArgs {
 
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(BnBwdArgs P)
 {
-    __shared__ double red[2][256];
-    const int C = P.C, rl = 256 / C;
-    const int c = threadIdx.x % C, r = threadIdx.x / C;
+    __shared__ double red[2][4][256];
+    const int C = P.C, C4 = C >> 2, rl = 256 / C4;
+    const int c4 = threadIdx.x % C4, r = threadIdx.x / C4;
     const int r0 = blockIdx.x * P.rows_per_block, r1 = min(r0 + P.rows_per_block, P.n);
-    double sb = 0.0, sg = 0.0;
-    {
-        const float m = P.mean[c], is = P.invstd[c], g = P.gamma[c], b = P.beta[c];
-        for (int row = r0 + r; row < r1; row += rl) {
-            const float xv = P.x[(size_t)row * C + c];
-            const float xh = (xv - m) * is;
-            const float z = fmaf(xv - m, is * g, b);         // exactly the forward's z: the mask is y > 0
-            const float dz = z > 0.f ? P.dy[(size_t)row * C + c] : 0.f;
-            sb += (double)dz;
-            sg += (double)dz * (double)xh;
+    float m[4], is[4], g[4], bt[4];                 // (scalar loads: gamma / beta are views into the flat parameter buffer,
+#pragma unroll                                      //  at any 4-byte offset)
+    for (int j = 0; j < 4; ++j) {
+        m[j] = P.mean[c4 * 4 + j]; is[j] = P.invstd[c4 * 4 + j]; g[j] = P.gamma[c4 * 4 + j]; bt[j] = P.beta[c4 * 4 + j];
+    }
+    double db[4] = {0.0, 0.0, 0.0, 0.0}, dg[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x4 fb = {0.f, 0.f, 0.f, 0.f}, fg = fb;
+    int cnt = 0;
+    for (int row = r0 + r; row < r1; row += rl) {
+        const f32x4 xv = ((const f32x4 *)P.x)[(size_t)row * C4 + c4], d = ((const f32x4 *)P.dy)[(size_t)row * C4 + c4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (xv[j] - m[j]) * is[j];
+            const float z = fmaf(xv[j] - m[j], is[j] * g[j], bt[j]);     // exactly the forward's z: the mask is y > 0
+            const float dz = z > 0.f ? d[j] : 0.f;
+            fb[j] += dz;
+            fg[j] += dz * xh;
+        }
+        if (++cnt == 16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { db[j] += (double)fb[j]; dg[j] += (double)fg[j]; }
+            fb = fg = (f32x4){0.f, 0.f, 0.f, 0.f};
+            cnt = 0;
         }
     }
-    red[0][threadIdx.x] = sb;
-    red[1][threadIdx.x] = sg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][j][threadIdx.x] = db[j] + (double)fb[j];
+        red[1][j][threadIdx.x] = dg[j] + (double)fg[j];
+    }
     __syncthreads();
     if (threadIdx.x < C) {
+        const int q = threadIdx.x >> 2, j = threadIdx.x & 3;
         double a = 0.0, b = 0.0;
-        for (int k = 0; k < rl; ++k) { a += red[0][k * C + threadIdx.x]; b += red[1][k * C + threadIdx.x]; }
+        for (int k = 0; k < rl; ++k) { a += red[0][j][k * C4 + q]; b += red[1][j][k * C4 + q]; }
         P.part[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a;
         P.part[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
     }
 }
 
-__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(BnBwdArgs P)
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(BnBwdArgs P)
 {
-    __shared__ double red[2][1024];
-    double a = 0.0, b = 0.0;
-    bn_reduce_partials<1024>(P.part, P.nb, P.C, red, &a, &b);
-    if (threadIdx.x < P.C) {
-        P.dbeta[threadIdx.x] = (float)a;
-        P.dgamma[threadIdx.x] = (float)b;
+    __shared__ double red[2][4];
+    double a, b;
+    bn_reduce_channel(P.part, P.nb, P.C, blockIdx.x, red, a, b);
+    if (threadIdx.x == 0) {
+        P.dbeta[blockIdx.x] = (float)a;
+        P.dgamma[blockIdx.x] = (float)b;
     }
 }
 
@@ -211,8 +248,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(BnBwdArgs P)
 
 int bn_blocks(int n, int C, int *rows_per_block)
 {
-    const int rl = 256 / C;
-    int nb = cdiv(n, 16 * rl);                       // >= 16 row iterations per block
+    const int rl = 1024 / C;                         // rows one block covers per iteration (a 16-byte load per thread)
+    int it = n / (512 * rl);                         // ~512 blocks (two per CU) ...
+    it = it < 2 ? 2 : (it > 16 ? 16 : it);           // ... of 2 .. 16 row iterations
+    int nb = cdiv(n, it * rl);
     nb = nb < 1 ? 1 : (nb > kBnMaxBlocks ? kBnMaxBlocks : nb);
     *rows_per_block = cdiv(n, nb);
     return cdiv(n, *rows_per_block);
@@ -252,7 +291,7 @@ extern "C" int sassd_bn_relu_fwd(const float *x, int n, int C, const float *gamm
     Q.x = x; Q.n = n; Q.C = C; Q.nb = P.nb; Q.part = (const double *)workspace; Q.gamma = gamma; Q.beta = beta; Q.y = y;
     Q.mean = save_mean; Q.invstd = save_invstd; Q.rmean = running_mean; Q.rvar = running_var;
     Q.momentum = momentum; Q.eps = eps;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, s, Q);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, Q);
     hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(bn_apply_blocks(n, C)), dim3(256), 0, s, Q);
     return sassd_launch_status();
 }
@@ -273,7 +312,7 @@ extern "C" int sassd_bn_relu_bwd(const float *x, const float *dy, int n, int C, 
     P.part = (double *)workspace;
     P.dx = dx; P.dgamma = dgamma; P.dbeta = dbeta;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(P.nb), dim3(256), 0, s, P);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, P);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, P);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(n, C)), dim3(256), 0, s, P);
     return sassd_launch_status();
 }

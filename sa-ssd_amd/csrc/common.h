@@ -43,6 +43,30 @@ static inline int sassd_dyn_lds(const void *fn, size_t bytes, std::atomic<unsign
     return SASSD_OK;
 }
 
+// Two byte-pattern fills in ONE launch (a workspace that needs an all-ones hash table next to zeroed counters took two
+// hipMemsetAsync calls = two __amd_rocclr_fillBufferAligned launches per call: 6 per inference frame in the round-4 trace).
+// Both regions 16-byte aligned with sizes that are multiples of 16 (every workspace segment is 256-byte aligned).
+static __global__ void sassd_fill2_kernel(uint4 *a, size_t na16, unsigned pa, uint4 *b, size_t nb16, unsigned pb)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const uint4 va = make_uint4(pa, pa, pa, pa), vb = make_uint4(pb, pb, pb, pb);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na16 + nb16; i += stride) {
+        if (i < na16) a[i] = va;
+        else b[i - na16] = vb;
+    }
+}
+static inline int sassd_fill2(void *a, size_t abytes, unsigned char pa, void *b, size_t bbytes, unsigned char pb, hipStream_t s)
+{
+    if (((uintptr_t)a | (uintptr_t)b | abytes | bbytes) & 15) return SASSD_EINVAL;
+    const size_t n16 = (abytes + bbytes) / 16;
+    if (n16 == 0) return SASSD_OK;
+    size_t blocks = (n16 + 4 * 256 - 1) / (4 * 256);             // <= 4 stores per thread
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sassd_fill2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4 *)a, abytes / 16, 0x01010101u * pa,
+                       (uint4 *)b, bbytes / 16, 0x01010101u * pb);
+    return SASSD_OK;
+}
+
 // Compute units of the current device (cached per device; persistent kernels launch one workgroup per CU).
 static inline int sassd_num_cus(int *out)
 {

@@ -540,9 +540,8 @@ extern "C" int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32
     }
     for (int l = level_begin; l < level_end; ++l) {
         if (l == 0) {
-            if ((rc = sassd_hip(hipMemsetAsync(w, 0xFF, L.keys_end, stream)))) return rc;
-            if (L.zero_end > L.zero_begin &&
-                (rc = sassd_hip(hipMemsetAsync(w + L.zero_begin, 0, L.zero_end - L.zero_begin, stream)))) return rc;
+            if ((rc = sassd_fill2(w, L.keys_end, 0xFF, w + L.zero_begin,
+                                  L.zero_end > L.zero_begin ? L.zero_end - L.zero_begin : 0, 0x00, stream))) return rc;
             hipLaunchKernelGGL(hash_build_kernel, dim3(cdiv(caps[0], 256)), dim3(256), 0, stream, indices[0],
                                n_ptrs[0], caps[0], L.dims[0][0], L.dims[0][1], L.dims[0][2], look[0].hv, status);
         } else {

@@ -843,8 +843,20 @@ int launch_wgrad(const float *x, const float *dy, const int32_t *nbr, const int3
         static std::atomic<unsigned long long> attr_done{0};
         // the opt-in is made once per device with the largest size any capacity can ask for (128 KB); a device that
         // refuses it still runs every capacity whose lists fit the 64 KB no kernel has to ask for
-        int rc = sassd_dyn_lds((const void *)spconv_wgrad_offset_kernel<CIN, COUT>, (size_t)8 * 2 * 2048 * sizeof(int),
-                               attr_done);
+        // (a refusal leaves HIP's sticky last-error set -- cleared here, or sassd_launch_status() would report
+        // the kernel that then launches fine as failed -- and is remembered per device, so it is asked once, not per call)
+        static std::atomic<unsigned long long> attr_refused{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return SASSD_EHIP;
+        const unsigned long long dbit = 1ull << (dev & 63);
+        int rc = SASSD_EHIP;
+        if (!(attr_refused.load(std::memory_order_acquire) & dbit)) {
+            rc = sassd_dyn_lds((const void *)spconv_wgrad_offset_kernel<CIN, COUT>, (size_t)8 * 2 * 2048 * sizeof(int), attr_done);
+            if (rc) {
+                (void)hipGetLastError();
+                attr_refused.fetch_or(dbit, std::memory_order_release);
+            }
+        }
         if (rc && lds > 64 * 1024) return rc;
         hipLaunchKernelGGL((spconv_wgrad_offset_kernel<CIN, COUT>), dim3(cdiv(cap, wg_rows)), dim3(512), lds, stream, x, dy,
                            nbr, n_ptr, cap, part, wg_rows);

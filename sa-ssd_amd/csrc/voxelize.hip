@@ -275,8 +275,7 @@ static int voxelize_impl(const float *points, int n_points, const int32_t *n_poi
     ws.scal = (int *)(w + off[5]);
 
     int rc;
-    if ((rc = sassd_hip(hipMemsetAsync(ws.keys, 0xFF, (size_t)hcap * 4, stream)))) return rc;
-    if ((rc = sassd_hip(hipMemsetAsync(ws.slots, 0x7F, (size_t)hcap * max_points * 4, stream)))) return rc;
+    if ((rc = sassd_fill2(ws.keys, (size_t)hcap * 4, 0xFF, ws.slots, (size_t)hcap * max_points * 4, 0x7F, stream))) return rc;
     const int nblk = cdiv(n_points > 0 ? n_points : 1, kPtsPerBlock);
     if (n_points > 0)
         hipLaunchKernelGGL(vox_insert_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, stream, points, P, ws, status);

@@ -236,10 +236,7 @@ class InferencePlan:
         B = self.B
         if self.pyr is not None:
             for lvl in range(4):
-                self.pyr.build(lvl, lvl + 1)            # level 0: memsets + hash; l >= 1: ordered emit of level l; tables
-                self.rb_ev["subm%d" % lvl].record()
-                if lvl > 0:
-                    self.rb_ev["down%d" % (lvl - 1)].record()
+                self._rulebook_level(lvl)
             return
         self.tables[0].build(self.idx[0], self.n[0], self.shapes[0], B, self.status)
         for lvl in range(4):
@@ -253,36 +250,77 @@ class InferencePlan:
                 self.rb_ev["down%d" % lvl].record()
                 self.tables[lvl + 1].build(self.idx[lvl + 1], self.n[lvl + 1], self.shapes[lvl + 1], B, self.status)
 
+    def _rulebook_level(self, lvl):
+        """level `lvl` of the fused pyramid on the CURRENT stream: the level's submanifold table (`subm<lvl>`) and, for lvl > 0,
+        the strided table into it (`down<lvl-1>`) + its coordinates; fires their events."""
+        self.pyr.build(lvl, lvl + 1)                    # level 0: clears + hash; l >= 1: ordered emit of level l; tables
+        self.rb_ev["subm%d" % lvl].record()
+        if lvl > 0:
+            self.rb_ev["down%d" % (lvl - 1)].record()
+
     def backbone(self, keep_middle=False, anchors_mask=None, densify=True, masks=True):
+        """7 rulebooks + 14 sparse convs (+ densify).  Two streams: coordinate-only work (rulebook pyramid, anchors_mask) on the
+        side stream, features on the main stream.  ISSUE ORDER = DEPENDENCY ORDER (round 5): a cross-stream wait covers
+        everything its source queue holds when the wait is issued -- the round-4 order (all 11 pyramid launches, then the 14
+        convs) made the first conv start after the LAST pyramid kernel, in eager launches and inside the hipGraph alike
+        (profiles/r05_sparse_timeline_*.txt: pyramid 0-108 us, first conv at 110 us).  Now level l+1 of the pyramid is issued
+        right after the first conv of level l, and the main stream waits for each rulebook event once: the convs of a level
+        run while the next level's rulebooks are built."""
         main = torch.cuda.current_stream(self.dev)
         e0 = self._ev() if self.prof is not None else None
+        staged = self.overlap and self.pyr is not None       # pyramid levels issued on demand, one level ahead of the convs
+        issued = -1                                          # highest pyramid level issued so far
+
+        def issue_levels(upto):
+            nonlocal issued
+            with torch.cuda.stream(self.side):
+                while issued < min(upto, 3):
+                    issued += 1
+                    self._rulebook_level(issued)
+                if issued == 3 and not self._masks_issued:
+                    self._masks_issued = True
+                    if masks:
+                        self.anchor_masks(anchors_mask)     # also coordinate-only work
+                    self.mask_ev.record()
+
         if self.overlap:
             self.side.wait_stream(main)                 # voxel coordinates are ready
-            with torch.cuda.stream(self.side):
-                self.rulebooks()
-                if masks:
-                    self.anchor_masks(anchors_mask)     # also coordinate-only work
-                self.mask_ev.record()
+            self._masks_issued = False
+            if staged:
+                issue_levels(0)
+            else:
+                with torch.cuda.stream(self.side):
+                    self.rulebooks()
+                    if masks:
+                        self.anchor_masks(anchors_mask)
+                    self.mask_ev.record()
         else:
             self.rulebooks()
         x = self.mean
         lvl = 0
         cur = 0
+        waited = set()
         for li, (kind, cin, cout, key, wp, scale, shift) in enumerate(self.sp):
             y = self.feat[cur]
-            if key is not None and self.overlap:
-                main.wait_event(self.rb_ev[key])
-            if kind == "subm":
-                K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y)
-            elif kind == "down":
+            if kind == "down":
                 lvl += 1
+            if key is not None and self.overlap and key not in waited:
+                if staged:
+                    issue_levels(lvl)                   # (already issued one level ahead, except at the very start)
+                main.wait_event(self.rb_ev[key])
+                waited.add(key)
+            if kind == "subm" or kind == "down":
                 K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y)
             else:
                 K.spconv_fwd(x, None, self.n[lvl], self.caps[lvl], wp, 1, cin, cout, scale, shift, True, y)
+            if staged and kind == "subm" and issued == lvl:
+                issue_levels(lvl + 1)                   # behind the level's first submanifold conv: overlaps the rest of it
             if keep_middle:
                 self.middle[li] = (y.clone(), lvl, cout)
             x = y
             cur ^= 1
+        if staged:
+            issue_levels(3)
         self.sp_out = x
         self._seg("sparse", e0)
         if not densify:

@@ -1,4 +1,6 @@
 """Shared test inputs: seeded synthetic frames and random network parameters (same on CPU oracle and GPU)."""
+import os
+
 import numpy as np
 import torch
 
@@ -281,3 +283,13 @@ def arbiter_report(got, arb, floor32, factor=3.0, rel_floor=2e-4, whole_factor=2
     whole = ((ng / den) ** 0.5, (nc / den) ** 0.5)
     whole_ok = whole[0] <= max(whole_factor * whole[1], whole_floor)
     return bad, whole, whole_ok, rows
+
+
+def dump_rows(title, rows):
+    """SASSD_PARITY_DUMP=<file>: append the full per-tensor table of an arbiter comparison (calibration runs on the GPU box)"""
+    path = os.environ.get("SASSD_PARITY_DUMP")
+    if path:
+        with open(path, "a") as f:
+            f.write("## %s\n" % title)
+            for eg, ec, k in rows:
+                f.write("%.3e %.3e %6.1f %s\n" % (eg, ec, eg / max(ec, 1e-30), k))

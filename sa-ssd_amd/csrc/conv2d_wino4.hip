@@ -330,8 +330,8 @@ struct W4Gemm {
 // The fp32 MFMA runs at 1/16 of the bf16 MFMA's rate.  An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8
 // significand bits, split by truncation: a1 = top 16 bits of a, a2 = top 16 bits of a - a1, a3 = a - a1 - a2, every
 // subtraction exact), and a product of two bf16 values is exact in fp32.  v_mfma_f32_32x32x16_bf16 gives every lane 8
-// K-slots: lane (row, k-half) fills them with ONE channel's pieces,
-//     A side (a1, a1, a1, a2, a2, a2, a3, a3)   B side (w1, w2, w3, w1, w2, w3, w1, w2),
+// K-slots: lane (row, k-half) fills them with ONE channel's pieces -- eight of the nine piece products, every pair except
+// a3 w3 (the exact slot order is the one split_a / split_b below implement and document) --
 // so that one instruction (32 cycles for two channels; the fp32 form needs 64) accumulates a w - a3 w3, i.e. the fp32
 // product to 2^-30, in fp32 -- the operands stay fp32 in HBM and LDS, the fragment reads are those of the fp32 kernel, and
 // the split costs 8 VALU instructions per fragment value (two masks, two subtractions, four byte permutes) that run

@@ -18,6 +18,8 @@ Stages / reference lines:
   rescore + NMS        ssd_rotate_head.py:487-533                       sassd_rescore_nms
 """
 import numpy as np
+import os
+
 import torch
 
 from . import kernels as K
@@ -186,6 +188,7 @@ class InferencePlan:
         # coordinate-only work (rulebooks, anchors_mask) runs on a side stream, overlapping the feature path
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.pyramid_issue = os.environ.get("SASSD_PYRAMID_ISSUE", "front")     # see backbone()
         self.rb_ev = {k: torch.cuda.Event() for k in self.nbr}
         self.mask_ev = torch.cuda.Event()
         self.prof = None           # set to {} to collect (name, start_event, end_event) tuples per frame
@@ -268,7 +271,8 @@ class InferencePlan:
         run while the next level's rulebooks are built."""
         main = torch.cuda.current_stream(self.dev)
         e0 = self._ev() if self.prof is not None else None
-        staged = self.overlap and self.pyr is not None       # pyramid levels issued on demand, one level ahead of the convs
+        # pyramid levels issued on demand, one level ahead of the convs ("ahead"), or all four in front of the convs ("front")
+        staged = self.overlap and self.pyr is not None and self.pyramid_issue == "ahead"
         issued = -1                                          # highest pyramid level issued so far
 
         def issue_levels(upto):

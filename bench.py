@@ -59,6 +59,7 @@ from sassd import synth  # noqa: E402
 from sassd.pipeline import InferencePlan  # noqa: E402
 
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PROFILE_TAG = "r05"                # profiles/<tag>_*: the PMC records of this round (tools/gpu_profiles_r5.sh, collect_profiles.py)
 PEAK_BF16_MFMA_TF = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 SPLIT_SLOTS = 8                   # bf16 multiplies the split GEMM spends per fp32 product (8 of the 9 piece products)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured float4 copy)
@@ -282,7 +283,7 @@ def _train_measure(args, dev, rank, world, config, precision, steps, warmup, bat
     sps = steps * B * world / dt
     traffic, at = (None, None)
     if bf16_conv and B == 2 and config == "car":
-        rec, at = stamped_traffic("r04_bf16_conv_hbm_traffic.json")
+        rec, at = stamped_traffic(PROFILE_TAG + "_bf16_conv_hbm_traffic.json")
         traffic = rec["traffic_bytes_per_launch"] if rec else None
     roof = dict(bound="mfma", kernel=kname, achieved=round(flops / kms / 1e9, 1), peak=peak, unit="TFLOP/s",
                 frac=round(flops / kms / 1e9 / peak, 4), ms_per_launch=round(kms, 4), traffic=traffic,
@@ -597,15 +598,15 @@ def main():
     # the kernel sources this library was built from (`traffic_measured_at` says which)
     traffic = traffic_at = sp_traffic = sp_traffic_at = None
     if B == 1 and args.config == "car":
-        rec, traffic_at = stamped_traffic("r04_wino4_gemm_hbm_traffic.json")
+        rec, traffic_at = stamped_traffic(PROFILE_TAG + "_wino4_gemm_hbm_traffic.json")
         traffic = rec["traffic_bytes_per_launch"] if rec else None
     if B == w["batch"]:                  # fabric-side bytes of one sparse pass: 2 x FETCH + WRITE
-        t, sp_traffic_at = stamped_traffic("r04_sparse_%s_hbm_traffic.json" % args.config)
+        t, sp_traffic_at = stamped_traffic(PROFILE_TAG + "_sparse_%s_hbm_traffic.json" % args.config)
         if t:
             sp_traffic = int((2 * t["FETCH_SIZE_kb_per_pass_raw"] + t["WRITE_SIZE_kb_per_pass_raw"]) * 1024)
     # issue / wait / MFMA-busy fractions of the sparse-conv kernels from the stamped SQ-counter passes (profiles/)
     sp_counters, sp_counters_at = None, None
-    st, sp_counters_at = stamped_traffic("r04_stall_breakdown.json")
+    st, sp_counters_at = stamped_traffic(PROFILE_TAG + "_stall_breakdown.json")
     if st:
         sp_counters = {k: dict(v["fraction_of_wave_cycles"], mfma_busy_fraction=v.get("mfma_busy_fraction"))
                        for k, v in st["kernels"].items() if k.startswith("spconv") and k.endswith("@" + args.config)} or None

@@ -52,6 +52,15 @@ def wgrad_overlap():
     return _WGRAD["on"]
 
 
+def wgrad_fence():
+    """Called in front of a data-gradient launch: the main stream waits for the weight gradient still running on the side
+    stream (the previous layer's), so that the two MFMA-bound kernels of the backward pass never share the chip -- what is
+    left beside a weight gradient is the NEXT layer's BatchNorm backward (HBM- / latency-bound)."""
+    if _WGRAD["on"] and _WGRAD["dirty"]:
+        for dev, side in _WGRAD["stream"].items():
+            torch.cuda.current_stream(dev).wait_stream(side)
+
+
 def wgrad_join():
     """The current stream waits for every weight gradient launched on the side stream so far."""
     if _WGRAD["dirty"]:
@@ -177,17 +186,8 @@ class SparseConvFn(Function):
         else:
             dyc = torch.zeros(1, cout, dtype=torch.float32, device=dev)
         dx = dw = None
-        if ctx.needs_input_grad[1]:                     # first: on the side stream it then runs beside the data gradient
-            with _wgrad_scope(x, dyc):
-                if nbr is None and n_in > 0 and (cin, cout) in _SP_PAIRS:
-                    # 1x1x1 layer: X^T dY through the sparse weight-gradient kernel over an identity table (centre offset only)
-                    dw = K.spconv_bwd_weight(x, dyc, _ident_nbr(n_in, dev), _n_ptr(n_in, dev), n_in, cin, cout)[13:14]
-                elif nbr is None:
-                    dw = (x.t() @ dyc[:n_in]).view(1, cin, cout)
-                else:
-                    xc = x if n_in > 0 else torch.zeros(1, cin, device=dev)
-                    dw = K.spconv_bwd_weight(xc, dyc, nbr, _n_ptr(n_out, dev), nbr.shape[0], cin, cout)
         if ctx.needs_input_grad[0]:
+            wgrad_fence()
             if cin < 16:
                 raise NotImplementedError("sparse data gradient needs Cin >= 16 (the 4-channel input layer has none)")
             on_fwd = ctx.subm and SparseConvFn.subm_on_forward_table and n_in > 0
@@ -206,6 +206,16 @@ class SparseConvFn(Function):
                     nbr_t = K.rulebook_transpose(nbr, _n_ptr(n_out, dev), nbr.shape[0], max(n_in, 1))
                     nbr._sassd_transposed = ((n_out, n_in), nbr_t)
                 dx = K.spconv_bwd_data(dyc, nbr_t, _n_ptr(n_in, dev), max(n_in, 1), wt, 27, cin, cout)[:n_in]
+        if ctx.needs_input_grad[1]:                     # (side stream: behind the data gradient, beside what follows it)
+            with _wgrad_scope(x, dyc):
+                if nbr is None and n_in > 0 and (cin, cout) in _SP_PAIRS:
+                    # 1x1x1 layer: X^T dY through the sparse weight-gradient kernel over an identity table (centre offset only)
+                    dw = K.spconv_bwd_weight(x, dyc, _ident_nbr(n_in, dev), _n_ptr(n_in, dev), n_in, cin, cout)[13:14]
+                elif nbr is None:
+                    dw = (x.t() @ dyc[:n_in]).view(1, cin, cout)
+                else:
+                    xc = x if n_in > 0 else torch.zeros(1, cin, device=dev)
+                    dw = K.spconv_bwd_weight(xc, dyc, nbr, _n_ptr(n_out, dev), nbr.shape[0], cin, cout)
         return dx, dw, None, None, None, None
 
 
@@ -311,10 +321,8 @@ class Conv2dFn(Function):
         dy = dy.contiguous()
         ks = weight.shape[2]
         dx = dw = db = None
-        if ctx.needs_input_grad[1]:                     # first: on the side stream it then runs beside the data gradient
-            with _wgrad_scope(x, dy):
-                dw = K.conv2d_bwd_weight(x, dy, ks, bf16=ctx.bf16)
         if ctx.needs_input_grad[0]:
+            wgrad_fence()
             cout, cin = weight.shape[0], weight.shape[1]
             if ctx.bf16 and ks == 3 and K.conv2d_bf16_supported(cout, cin, dy.shape[2], dy.shape[3]):
                 dx = K.conv2d_bf16_fwd(dy, _bf16_pack(weight, True), cin)
@@ -323,6 +331,9 @@ class Conv2dFn(Function):
                 dx = _conv_any(dy, pk["wt"], ks, pk.get("packed"), pk.get("wino"), None, pk.get("wino4"))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
+        if ctx.needs_input_grad[1]:                     # (side stream: behind the data gradient, beside what follows it)
+            with _wgrad_scope(x, dy):
+                dw = K.conv2d_bwd_weight(x, dy, ks, bf16=ctx.bf16)
         return dx, dw, db, None, None, None
 
 

@@ -18,7 +18,6 @@ Stages / reference lines:
   rescore + NMS        ssd_rotate_head.py:487-533                       sassd_rescore_nms
 """
 import numpy as np
-import os
 
 import torch
 
@@ -188,7 +187,6 @@ class InferencePlan:
         # coordinate-only work (rulebooks, anchors_mask) runs on a side stream, overlapping the feature path
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(device=dev) if self.overlap else None
-        self.pyramid_issue = os.environ.get("SASSD_PYRAMID_ISSUE", "front")     # see backbone()
         self.rb_ev = {k: torch.cuda.Event() for k in self.nbr}
         self.mask_ev = torch.cuda.Event()
         self.prof = None           # set to {} to collect (name, start_event, end_event) tuples per frame
@@ -263,41 +261,19 @@ class InferencePlan:
 
     def backbone(self, keep_middle=False, anchors_mask=None, densify=True, masks=True):
         """7 rulebooks + 14 sparse convs (+ densify).  Two streams: coordinate-only work (rulebook pyramid, anchors_mask) on the
-        side stream, features on the main stream.  ISSUE ORDER = DEPENDENCY ORDER (round 5): a cross-stream wait covers
-        everything its source queue holds when the wait is issued -- the round-4 order (all 11 pyramid launches, then the 14
-        convs) made the first conv start after the LAST pyramid kernel, in eager launches and inside the hipGraph alike
-        (profiles/r05_sparse_timeline_*.txt: pyramid 0-108 us, first conv at 110 us).  Now level l+1 of the pyramid is issued
-        right after the first conv of level l, and the main stream waits for each rulebook event once: the convs of a level
-        run while the next level's rulebooks are built."""
+        side stream, features on the main stream, which waits for each rulebook event once.  (Round 5 measured the alternative
+        issue order -- pyramid level l+1 issued behind the first conv of level l, so that a conv never waits for more of the
+        pyramid than it needs: 703 against 748 frames/s and 0.365 against 0.347 ms for the segment's graph on one box,
+        profiles/r05_pyramid_issue_order.txt.  The pyramid in front it is.)"""
         main = torch.cuda.current_stream(self.dev)
         e0 = self._ev() if self.prof is not None else None
-        # pyramid levels issued on demand, one level ahead of the convs ("ahead"), or all four in front of the convs ("front")
-        staged = self.overlap and self.pyr is not None and self.pyramid_issue == "ahead"
-        issued = -1                                          # highest pyramid level issued so far
-
-        def issue_levels(upto):
-            nonlocal issued
-            with torch.cuda.stream(self.side):
-                while issued < min(upto, 3):
-                    issued += 1
-                    self._rulebook_level(issued)
-                if issued == 3 and not self._masks_issued:
-                    self._masks_issued = True
-                    if masks:
-                        self.anchor_masks(anchors_mask)     # also coordinate-only work
-                    self.mask_ev.record()
-
         if self.overlap:
             self.side.wait_stream(main)                 # voxel coordinates are ready
-            self._masks_issued = False
-            if staged:
-                issue_levels(0)
-            else:
-                with torch.cuda.stream(self.side):
-                    self.rulebooks()
-                    if masks:
-                        self.anchor_masks(anchors_mask)
-                    self.mask_ev.record()
+            with torch.cuda.stream(self.side):
+                self.rulebooks()
+                if masks:
+                    self.anchor_masks(anchors_mask)     # also coordinate-only work
+                self.mask_ev.record()
         else:
             self.rulebooks()
         x = self.mean
@@ -309,22 +285,16 @@ class InferencePlan:
             if kind == "down":
                 lvl += 1
             if key is not None and self.overlap and key not in waited:
-                if staged:
-                    issue_levels(lvl)                   # (already issued one level ahead, except at the very start)
                 main.wait_event(self.rb_ev[key])
                 waited.add(key)
             if kind == "subm" or kind == "down":
                 K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y)
             else:
                 K.spconv_fwd(x, None, self.n[lvl], self.caps[lvl], wp, 1, cin, cout, scale, shift, True, y)
-            if staged and kind == "subm" and issued == lvl:
-                issue_levels(lvl + 1)                   # behind the level's first submanifold conv: overlaps the rest of it
             if keep_middle:
                 self.middle[li] = (y.clone(), lvl, cout)
             x = y
             cur ^= 1
-        if staged:
-            issue_levels(3)
         self.sp_out = x
         self._seg("sparse", e0)
         if not densify:

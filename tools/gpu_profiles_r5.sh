@@ -8,7 +8,7 @@ mkdir -p gpurun_out/prof; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/prof
 if [ "$1" != "notests" ]; then
   SASSD_FULL_TESTS=1 timeout 1500 python -m pytest tests -q -m gpu -s > $O/full_tests.log 2>&1; echo "full gpu tests rc=$?"
   ( echo "# SASSD_FULL_TESTS=1 python -m pytest tests -q -m gpu -s on csrc $(python -c 'import sassd; from sassd import _C; print(_C.csrc_hash())'), commit $(cat .git_head 2>/dev/null)";
-    grep -a "passed\|failed\| error\|vs float64 arbiter\|vs the .* arbiter\|bf16 step, every\|side stream\|max abs errors\|waymo-scale training step" $O/full_tests.log | cut -c1-2500 ) > $O/full_tests_tail.txt
+    grep -a "passed\|failed\| error\|vs float64 arbiter\|vs the .* arbiter\|bf16 step, every\|max abs errors\|waymo-scale training step" $O/full_tests.log | cut -c1-2500 ) > $O/full_tests_tail.txt
   tail -3 $O/full_tests_tail.txt | cut -c1-300
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 fi
@@ -43,7 +43,6 @@ timeout 900 python bench.py > $O/bench_default.log 2>&1; echo "bench default rc=
 trace bench_inflight3 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train
 trace bench_train python $R/bench.py --mode train --steps 10 --warmup 4
 timeout 600 python bench.py --mode train --steps 40 --warmup 8 > $O/bench_train_bf16.log 2>&1; echo "train bf16 rc=$?"
-timeout 600 python bench.py --mode train --steps 40 --warmup 8 --serial-wgrad > $O/bench_train_serial_wgrad.log 2>&1; echo "train serial-wgrad rc=$?"
 timeout 600 python bench.py --mode train --steps 40 --warmup 8 --force-ddp > $O/bench_train_forceddp.log 2>&1; echo "train force-ddp rc=$?"
 timeout 600 python bench.py --mode train --precision fp32 --steps 30 --warmup 6 > $O/bench_train_fp32.log 2>&1; echo "train fp32 rc=$?"
 timeout 600 python bench.py --mode train --config waymo --steps 12 --warmup 4 > $O/bench_train_waymo.log 2>&1; echo "train waymo rc=$?"
@@ -52,4 +51,4 @@ timeout 300 python bench.py --config waymo --steps 20 --warmup 5 --no-cpu-baseli
 timeout 300 python tools/run_bf16_conv.py --ablate > $O/bf16_conv_timing.json 2>/dev/null; echo "bf16 timing rc=$?"
 timeout 400 python tools/ablate_spconv.py --config car --ablate 2>&1 | grep -v "^/opt" > $O/spconv_layers_car.txt; echo "layers car rc=$?"
 python tools/collect_profiles.py r05 >> $O/collect.log 2>&1; echo "collect rc=$?"
-grep -o '"traffic_measured_at": [^,]*' $O/bench_default.log | head -3; grep -o '"value": [0-9.]*' $O/bench_default.log $O/bench_train_bf16.log $O/bench_train_serial_wgrad.log $O/bench_multi.log $O/bench_waymo.log $O/bench_train_waymo.log $O/bench_train_fp32.log
+grep -o '"traffic_measured_at": [^,]*' $O/bench_default.log | head -3; grep -o '"value": [0-9.]*' $O/bench_default.log $O/bench_train_bf16.log $O/bench_multi.log $O/bench_waymo.log $O/bench_train_waymo.log $O/bench_train_fp32.log

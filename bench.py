@@ -81,8 +81,11 @@ def build_model(seed=0, dev=None, config="car"):
     return model, w
 
 
-def cpu_baseline(model, w, warm=3, runs=20, budget_s=60.0):
-    """BASELINE.md section 4 protocol on the CPU oracle (imported HERE only: the checker, timed as the baseline)."""
+def cpu_baseline(model, w, warm=3, runs=20, budget_s=60.0, gpu_plan=None):
+    """BASELINE.md section 4 protocol on the CPU oracle (imported HERE only: the checker, timed as the baseline).
+    gpu_plan: the first frame is also run through the HIP pipeline and the two feature maps are compared -- `parity` in the
+    record (the oracle used as the checker it is: voxel rows bit-equal, sparse / BEV feature error relative to the map's
+    maximum; the parity TESTS hold the bars, this prints where the line's own build stands against them)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
     from oracle import clib, nets as onets
@@ -106,6 +109,16 @@ def cpu_baseline(model, w, warm=3, runs=20, budget_s=60.0):
         x, conv6 = onets.bevnet_forward(onets.densify(x3, idx3, shape3, 1), bev)
         box, cls, dirp = onets.ssd_head_forward(x, head, 1)
         t3 = time.perf_counter()
+        if i == 0 and gpu_plan is not None:
+            dev = gpu_plan.dev
+            gpu_plan.run_from_points([torch.from_numpy(pts).to(dev)])
+            torch.cuda.synchronize()
+            n0, n3 = int(gpu_plan.n[0].item()), int(gpu_plan.n[3].item())
+            parity = dict(frame="synth.k21(100)", voxel_rows_bit_equal=bool(np.array_equal(gpu_plan.idx[0][:n0].cpu().numpy(), coors)),
+                          level3_rows_bit_equal=bool(np.array_equal(gpu_plan.idx[3][:n3].cpu().numpy(), idx3)),
+                          sparse_feature_err_over_max=float((gpu_plan.sp_out[:n3].cpu() - x3).abs().max() / x3.abs().max()),
+                          bev_feature_err_over_max=float((gpu_plan.x.cpu() - x).abs().max() / x.abs().max()),
+                          bars="sparse 1e-4, BEV 2e-4 (tests/test_gpu_pipeline.py)")
         mask = onets.anchors_mask(c, bv, cal["voxel_size"], cal["pc_range"], cal["grid_xyz"], 1)[None]
         guided = onets.guided_anchors(box, cls, dirp, torch.from_numpy(an).view(1, -1, 7), torch.from_numpy(mask), 1, 0.1)
         logits, _ = onets.pswarp_forward(conv6, ps, [g[0] for g in guided])
@@ -117,7 +130,8 @@ def cpu_baseline(model, w, warm=3, runs=20, budget_s=60.0):
             total.append((t4 - t0) * 1e3)
         i += 1
     med = float(np.median(total))
-    return dict(value=round(1e3 / med, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
+    extra = {} if gpu_plan is None else dict(parity=parity)
+    return dict(extra, value=round(1e3 / med, 4), unit="frames/s", cores=torch.get_num_threads(), kind="port",
                 ms_per_frame_median=round(med, 1), ms_p10=round(float(np.percentile(total, 10)), 1),
                 ms_p90=round(float(np.percentile(total, 90)), 1),
                 stage_ms_median={k: round(float(np.median(v)), 2) for k, v in stages.items()},
@@ -626,7 +640,8 @@ def main():
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": round(exec_tf * mfma_mult, 2), "peak": mfma_peak, "unit": "TFLOP/s",
                      "frac": round(exec_tf * mfma_mult / mfma_peak, 4),
-                     "fp32_product_tflops": round(exec_tf, 2),
+                     "fp32_product_tflops": round(exec_tf, 2),          # the like-for-like figure across rounds
+                     "algorithmic_tflops": round(conv_flops / (kernel_ms * 1e-3) / 1e12, 2),   # SURVEY 8(d) direct-conv flops / launch
                      "frac_of_fp32_mfma_peak": round(exec_tf / PEAK_F32_MFMA_TF, 4),
                      "ms_per_launch": round(kernel_ms, 4), "executed_flops_per_launch": exec_flops,
                      "layer": {"ms": round(conv_iso, 4), "direct_conv_flops": conv_flops,
@@ -677,7 +692,7 @@ def main():
         finally:
             watchdog.cancel()
     if world == 1 and headline and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model, w)
+        out["cpu_baseline"] = cpu_baseline(model, w, gpu_plan=iso_plan)
     print(json.dumps(out))
 
 

@@ -327,7 +327,10 @@ def _train_measure(args, dev, rank, world, config, precision, steps, warmup, bat
                    "parallelism": "ddp x%d (flat-gradient RCCL all-reduce in 4 buckets / step%s)" %
                                   (world, "; one-rank communicator forced" if (sync.on and world == 1) else "")},
         "roofline": roof,
-        "final_loss": round(float(loss), 4), "loss_terms": {k: round(float(v), 4) for k, v in terms.items()}}
+        "final_loss": round(float(loss), 4), "loss_terms": {k: round(float(v), 4) for k, v in terms.items()},
+        "final_loss_note": "after %d steps of a one-cycle schedule laid out for %d (warm-up + up to five trials): a sanity value "
+                           "(finite, six non-zero terms), not comparable across --steps or with rounds 1-3, whose schedule "
+                           "was sized for one trial" % (warmup + len(trials_dt) * steps, 5 * steps + warmup)}
 
 
 def main_train(args):

@@ -118,7 +118,7 @@ def cpu_baseline(model, w, warm=3, runs=20, budget_s=60.0, gpu_plan=None):
                           level3_rows_bit_equal=bool(np.array_equal(gpu_plan.idx[3][:n3].cpu().numpy(), idx3)),
                           sparse_feature_err_over_max=float((gpu_plan.sp_out[:n3].cpu() - x3).abs().max() / x3.abs().max()),
                           bev_feature_err_over_max=float((gpu_plan.x.cpu() - x).abs().max() / x.abs().max()),
-                          bars="sparse 1e-4, BEV 2e-4 (tests/test_gpu_pipeline.py)")
+                          bars="sparse 1e-5, BEV 2e-5 of the maximum (tests/test_gpu_pipeline.py)")
         mask = onets.anchors_mask(c, bv, cal["voxel_size"], cal["pc_range"], cal["grid_xyz"], 1)[None]
         guided = onets.guided_anchors(box, cls, dirp, torch.from_numpy(an).view(1, -1, 7), torch.from_numpy(mask), 1, 0.1)
         logits, _ = onets.pswarp_forward(conv6, ps, [g[0] for g in guided])

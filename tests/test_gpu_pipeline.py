@@ -100,15 +100,20 @@ def test_pipeline_vs_oracle(dev, frames, seed, score_thr):
     n3 = int(plan.n[3].item())
     assert n3 == len(ref["idx3"]) and np.array_equal(plan.idx[3][:n3].cpu().numpy(), ref["idx3"])
     sp = plan.sp_out[:n3].cpu()
+    # (features: bars RELATIVE to the map's maximum, ~85 for this model.  Round 5 tightened them 10 x -- sparse 1e-5, BEV 2e-5 of
+    # the maximum; measured 1.1e-6 / 2.1e-6 -- and prints the relative figure: rounds 1-4 printed only the absolute error, whose
+    # 1.9e-4 read as if it sat on the old 2e-4 bar)
     e = (sp - ref["x3"]).abs().max().item()
-    assert e < 1e-4 * max(1.0, ref["x3"].abs().max().item()), e
-    errs = {"sparse_features": e}
+    m3 = max(1.0, ref["x3"].abs().max().item())
+    assert e < 1e-5 * m3, (e, m3)
+    errs = {"sparse_features": e, "sparse_features/max": e / m3}
     # -- dense BEV stack
     for name, got in (("conv6", plan.conv6), ("x", plan.x)):
         r = ref[name]
         e = (got.cpu() - r).abs().max().item()
         errs["bev_" + name] = e
-        assert e < 2e-4 * max(1.0, r.abs().max().item()), (name, e)
+        errs["bev_" + name + "/max"] = e / max(1.0, r.abs().max().item())
+        assert e < 2e-5 * max(1.0, r.abs().max().item()), (name, e, r.abs().max().item())
     # -- anchors mask exact
     assert np.array_equal(plan.mask.cpu().numpy().astype(bool), ref["masks"])
     res = plan.results()
@@ -229,11 +234,14 @@ def test_waymo_scale_frame(dev, batch):
     assert np.array_equal(plan.mean[:n0].cpu().numpy(), ref["feats"])
     assert n3 == len(ref["idx3"]) and np.array_equal(plan.idx[3][:n3].cpu().numpy(), ref["idx3"])
     e = (plan.sp_out[:n3].cpu() - ref["x3"]).abs().max().item()
-    assert e < 1e-4 * max(1.0, ref["x3"].abs().max().item()), e
-    errs = {"sparse_features": e}
+    m3 = max(1.0, ref["x3"].abs().max().item())
+    assert e < 1e-5 * m3, (e, m3)
+    errs = {"sparse_features": e, "sparse_features/max": e / m3}
     e = (plan.x.cpu() - ref["x"]).abs().max().item()
+    mx = max(1.0, ref["x"].abs().max().item())
     errs["bev_x"] = e
-    assert e < 2e-4 * max(1.0, ref["x"].abs().max().item()), e
+    errs["bev_x/max"] = e / mx
+    assert e < 2e-5 * mx, (e, mx)
     assert np.array_equal(plan.mask.cpu().numpy().astype(bool), ref["masks"])
     res = plan.results()
     ndet = sum(_check_sample("waymo", plan, res, ref, b, errs, unbounded=True) for b in range(batch))

@@ -306,6 +306,68 @@ def test_submanifold_data_gradient_on_forward_rulebook(dev, cin, cout):
     assert (got[True][1] - wr.grad).abs().max().item() < 2e-4 * max(1.0, wr.grad.abs().max().item())
 
 
+def _f64_sparse_conv(x, nbr, w):
+    """float64 gather / mm / index_add over a gather table (the oracle's sparse conv restated in double)"""
+    nbt = torch.from_numpy(nbr).long()
+    y = torch.zeros(len(nbr), w.shape[2], dtype=torch.float64)
+    for k in range(w.shape[0]):
+        o = torch.nonzero(nbt[:, k] >= 0).view(-1)
+        if o.numel():
+            y = y.index_add(0, o, x[nbt[o, k]] @ w[k])
+    return y
+
+
+def test_sparse_layers_k21x2_vs_float64(dev):
+    """Kernel-level guard under the whole-step bars: EVERY sparse layer shape of the network on the rulebooks of the
+    bench's training workload (two K21 frames: 32 k / 37 k / 29 k / 27 k rows), through the DEFAULT dispatch -- forward, data
+    gradient (forward-table form for the submanifold layers, transposed table for the strided ones) and weight gradient --
+    against a float64 gather / matmul reference: 1e-5 relative L2 each (fp32 sums of <= 27 x 64 products; measured ~1e-6).  A
+    dropped pair in a split offset or a wrong unit boundary in the balanced partition is a 1e-2 error here; the whole-step
+    tests alone would only see it as "fp32 noise"."""
+    from sassd.autograd import SparseConvFn
+    idx = _level0("k21", 0, 2)
+    shape = (40, 1600, 1408)
+    levels = []                                           # (rows idx, subm table, strided table into the level, input rows)
+    n_prev = None
+    nbr_down = None
+    for lvl in range(4):
+        if lvl > 0:
+            n_prev = len(idx)
+            idx, nbr_down, shape = orb.conv_rulebook(idx, shape, 2)
+        _, nbr_s = orb.subm_rulebook(idx, shape)
+        levels.append((nbr_s, nbr_down, n_prev))
+    layers = [(0, "subm", 4, 16), (0, "subm", 16, 16), (1, "down", 16, 32), (1, "subm", 32, 32), (2, "down", 32, 64),
+              (2, "subm", 64, 64), (3, "down", 64, 64), (3, "subm", 64, 64), (3, "1x1", 64, 64)]
+    worst = {}
+    for lvl, kind, cin, cout in layers:
+        nbr_s, nbr_d, n_in_down = levels[lvl]
+        nbr = nbr_s if kind == "subm" else (nbr_d if kind == "down" else None)
+        n_out = len(nbr_s)
+        n_in = n_in_down if kind == "down" else n_out
+        g = torch.Generator().manual_seed(100 * cin + cout + lvl)
+        K_ = 1 if kind == "1x1" else 27
+        x = torch.randn(n_in, cin, generator=g)
+        w = torch.randn(K_, cin, cout, generator=g) * (0.5 / (cin ** 0.5))
+        dy = torch.randn(n_out, cout, generator=g)
+        xr, wr = x.double().requires_grad_(cin >= 16), w.double().requires_grad_(True)
+        ref = (xr @ wr[0]) if nbr is None else _f64_sparse_conv(xr, nbr, wr)
+        ref.backward(dy.double())
+        xd, wd = x.to(dev).requires_grad_(cin >= 16), w.to(dev).requires_grad_(True)
+        nb = None if nbr is None else torch.from_numpy(nbr).to(dev)
+        y = SparseConvFn.apply(xd, wd, nb, n_out, K.spconv_pack_weight(wd.detach()), kind == "subm")
+        y.backward(dy.to(dev))
+        torch.cuda.synchronize()
+        tag = "%s %d->%d @ %d rows" % (kind, cin, cout, n_out)
+
+        def rel(a, b):
+            return float((a.detach().double().cpu() - b).norm() / b.norm())
+        worst[tag] = (rel(y, ref.detach()), rel(xd.grad, xr.grad) if cin >= 16 else 0.0, rel(wd.grad, wr.grad))
+    print("sparse layers on the K21 x 2 rulebooks vs float64 (forward, data gradient, weight gradient):",
+          {k: tuple("%.1e" % e for e in v) for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not max(v) < 1e-5}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("legacy", [False, True])
 def test_spconv_input_layer_kernel(dev, legacy):
     """The 4-channel input layer (cmn.py:197, SubMConv3d(4, 16, 3)) on the row-per-16-threads kernel (and on the

@@ -58,7 +58,25 @@ def _ident_nbr(n, dev):
     return t[:n]
 
 
-_sp_t_packs = {}
+class _PackCache(dict):
+    """Packed-weight images keyed by the source weight's (address, shape, ...) and validated by its generation
+    (kernels.weight_key: version counter, address, device, global generation).  A FRESH tensor can land on the address of a
+    dead one with the same shape, version 0 and the same global generation -- its key and generation then equal the dead
+    tensor's and the lookup would return the dead tensor's image (round 5: the sparse data gradient of the third 64 -> 64 layer
+    a test created was computed with the first one's transposed weights; models built through build_detector bump the
+    generation, hand-made layers and tests do not).  So an entry PINS the tensor it was packed from: while the entry exists
+    that storage cannot be freed, hence no other tensor can sit on its address.  Bounded (the oldest entries go first; a
+    dropped entry only costs a re-pack)."""
+    MAX = 256
+
+    def put(self, key, gen, pack, source):
+        if key not in self and len(self) >= self.MAX:
+            for k in list(self)[:self.MAX // 4]:
+                del self[k]
+        self[key] = (gen, pack, source)
+
+
+_sp_t_packs = _PackCache()
 
 
 def _spconv_t_pack(weight, reverse=False):
@@ -72,7 +90,7 @@ def _spconv_t_pack(weight, reverse=False):
         return hit[1]
     w = weight.detach()
     pack = K.spconv_pack_weight_t((w.flip(0) if reverse else w).contiguous())
-    _sp_t_packs[key] = (gen, pack)
+    _sp_t_packs.put(key, gen, pack, weight)
     return pack
 
 
@@ -159,7 +177,7 @@ def _conv_any(x, weight, ks, packed=None, wino=None, shift=None, wino4=None):
 # channel pairs the sparse kernels are instantiated for (csrc/spconv.hip SP_DISPATCH); anything else takes the GEMM
 _SP_PAIRS = {(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (32, 16), (64, 32)}
 
-_dgrad_packs = {}
+_dgrad_packs = _PackCache()
 _dgrad_direct = {}
 
 
@@ -194,11 +212,11 @@ def _dgrad_pack(weight, h, w):
         pack = dict(packed=K.conv2d_pack_weight(wt))
     pack["wt"] = wt
     if cache:
-        _dgrad_packs[key] = (gen, pack)
+        _dgrad_packs.put(key, gen, pack, weight)
     return pack
 
 
-_bf16_packs = {}
+_bf16_packs = _PackCache()
 
 
 def _bf16_pack(weight, transposed):
@@ -215,7 +233,7 @@ def _bf16_pack(weight, transposed):
         w = w.transpose(0, 1).flip(2, 3)
     pack = K.conv2d_bf16_pack_weight(w.contiguous())
     if cache:
-        _bf16_packs[key] = (gen, pack)
+        _bf16_packs.put(key, gen, pack, weight)
     return pack
 
 

@@ -139,7 +139,7 @@ class PackPlan:
                     key = key + ((True,) if rev else ())
 
                     def inst_t(view, m=m, key=key):
-                        AG._sp_t_packs[key] = (K.weight_key(m.weight), view)
+                        AG._sp_t_packs[key] = (K.weight_key(m.weight), view, m.weight)
                     add_f32(K.spconv_pack_weight_t(wi.flip(0).contiguous() if rev else wi), inst_t)
             elif isinstance(m, _HipConv2d) and m.weight.requires_grad:
                 cout, cin, ks = m.out_channels, m.in_channels, m.kernel_size[0]
@@ -149,13 +149,13 @@ class PackPlan:
                 if ks == 3 and bf16:
                     if cout % 32 == 0:
                         def inst_b(view, m=m, wkey=wkey):
-                            AG._bf16_packs[wkey + (False,)] = (K.weight_key(m.weight), view)
+                            AG._bf16_packs[wkey + (False,)] = (K.weight_key(m.weight), view, m.weight)
                         add(bf_maps, self._bf, bf16_map(off, cout, cin, False), inst_b)
                     else:
                         direct_fwd = True
                     if cin % 32 == 0:
                         def inst_bt(view, m=m, wkey=wkey):
-                            AG._bf16_packs[wkey + (True,)] = (K.weight_key(m.weight), view)
+                            AG._bf16_packs[wkey + (True,)] = (K.weight_key(m.weight), view, m.weight)
                         add(bf_maps, self._bf, bf16_map(off, cout, cin, True), inst_bt)
                 if direct_fwd:
                     def inst_d(view, m=m):

@@ -306,6 +306,36 @@ def test_submanifold_data_gradient_on_forward_rulebook(dev, cin, cout):
     assert (got[True][1] - wr.grad).abs().max().item() < 2e-4 * max(1.0, wr.grad.abs().max().item())
 
 
+def test_packed_weight_cache_and_address_reuse(dev):
+    """Round-5 regression: the transposed-pack cache of the sparse data gradient is keyed by the weight's address + shape and
+    validated by (version, address, device, generation).  A fresh weight on the address of a freed one has the SAME key and
+    generation -- before the cache pinned its source tensors, the second layer below was differentiated with the first
+    layer's weights (relative error 1.4-2.5 in the float64 guard when the suite ran in one process).  Four same-shape layers
+    are created, used and dropped in turn; every data gradient must match its own float64 reference."""
+    from sassd.autograd import SparseConvFn
+    import gc
+    idx = _level0("small", 4)
+    _, nbr = orb.subm_rulebook(idx, (40, 1600, 1408))
+    n = len(nbr)
+    nb = torch.from_numpy(nbr).to(dev)
+    seen = []
+    for trial in range(4):
+        g = torch.Generator().manual_seed(50 + trial)
+        x = torch.randn(n, 16, generator=g)
+        w = torch.randn(27, 16, 16, generator=g) * 0.2
+        dy = torch.randn(n, 16, generator=g)
+        xr, wr = x.double().requires_grad_(True), w.double()
+        _f64_sparse_conv(xr, nbr, wr).backward(dy.double())
+        xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        seen.append(wd.data_ptr())
+        SparseConvFn.apply(xd, wd, nb, n, K.spconv_pack_weight(wd.detach()), True).backward(dy.to(dev))
+        torch.cuda.synchronize()
+        err = float((xd.grad.double().cpu() - xr.grad).norm() / xr.grad.norm())
+        assert err < 1e-5, (trial, err, seen)
+        del xd, wd
+        gc.collect()
+
+
 def _f64_sparse_conv(x, nbr, w):
     """float64 gather / mm / index_add over a gather table (the oracle's sparse conv restated in double)"""
     nbt = torch.from_numpy(nbr).long()

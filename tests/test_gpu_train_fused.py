@@ -224,9 +224,10 @@ def test_pack_plan_matches_individual_packs(dev):
                 if m.in_channels >= 16:
                     # submanifold layers differentiate on the forward rulebook: offset-reversed transposed image
                     rev = isinstance(m, SP.SubMConv3d) and k == 27 and AG.SparseConvFn.subm_on_forward_table
-                    gen, pk = AG._sp_t_packs[(m.weight.data_ptr(), (k, m.in_channels, m.out_channels)) + ((True,) if rev else ())]
+                    gen, pk, src = AG._sp_t_packs[(m.weight.data_ptr(), (k, m.in_channels, m.out_channels)) + ((True,) if rev else ())]
                     ref = K.spconv_pack_weight_t(w.flip(0).contiguous() if rev else w)
                     assert gen == K.weight_key(m.weight) and torch.equal(pk, ref); checked["spt"] += 1
+                    assert src is m.weight                   # (the entry pins the tensor it was packed from)
             elif isinstance(m, _HipConv2d):
                 w = m.weight.detach()
                 key = (w.data_ptr(), tuple(w.shape))
@@ -239,13 +240,15 @@ def test_pack_plan_matches_individual_packs(dev):
                     checked["direct"] += 1; checked["dgrad"] += 1
                 else:
                     if m.out_channels % 32 == 0:
-                        gen, pk = AG._bf16_packs[key + (False,)]
+                        gen, pk, src = AG._bf16_packs[key + (False,)]
+                        assert src is m.weight
                         assert gen == K.weight_key(m.weight) and torch.equal(pk, K.conv2d_bf16_pack_weight(w.contiguous()))
                         checked["bf"] += 1
                     else:
                         assert torch.equal(m._pk, K.conv2d_pack_weight(w.contiguous())); checked["direct"] += 1
                     if m.in_channels % 32 == 0:
-                        gen, pk = AG._bf16_packs[key + (True,)]
+                        gen, pk, src = AG._bf16_packs[key + (True,)]
+                        assert src is m.weight
                         wt = w.transpose(0, 1).flip(2, 3).contiguous()
                         assert gen == K.weight_key(m.weight) and torch.equal(pk, K.conv2d_bf16_pack_weight(wt))
                         checked["bft"] += 1

@@ -34,7 +34,7 @@ from sassd import synth  # noqa: E402
 _spec = importlib.util.spec_from_file_location("make_golden_waymo_train", os.path.join(HERE, "make_golden_waymo_train.py"))
 MGW = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(MGW)
-projection, FULL, SLICED = MGW.projection, MGW.FULL, MGW.SLICED
+projection, FULL, SLICED, stored, pack = MGW.projection, MGW.FULL, MGW.SLICED, MGW.stored, MGW.pack
 B, NGT = 2, 8
 
 
@@ -65,40 +65,6 @@ def step_args(model, c, w, clouds, gts):
     an = np.broadcast_to(w["anchors"][None], (B,) + w["anchors"].shape).copy()
     shape = tuple(model.neck.sparse_shape) if hasattr(model.neck, "sparse_shape") else (41, 1600, 1408)
     return (sd, feats, coors, B, shape, gts, types, ["Car"], {"Car": an}, {"Car": m}, {"Car": (a.pos_iou_thr, a.neg_iou_thr)}), m
-
-
-def stored(k, g):
-    """-> (key prefix, array) of the slice of gradient `k` the fixture keeps elementwise, or None"""
-    if k in FULL or ".bn" in k or k.split(".")[-2].isdigit() and g.dim() == 1:
-        return "grad:", g.numpy().astype(np.float32)
-    if k in SLICED:
-        return "grad8:", g[:8].numpy().astype(np.float32)
-    return None
-
-
-def pack(tag, losses, grads, arbiter=None):
-    """one variant of the step under the key prefix `tag` ("" = the fp32 oracle): loss terms, stored-layer gradients
-    (float32 storage: 6e-8 relative, three orders below anything compared), norm + seeded projection of EVERY parameter's
-    gradient, and -- when `arbiter` (the float64 gradients of the same arithmetic) is given -- every parameter's distance
-    to it, ||g - g_arbiter||: the floor the GPU bars of tests/test_gpu_train.py are multiples of."""
-    out = {tag + "losses": np.array([losses[k] for k in sorted(losses)], np.float64)}
-    names, norms, projs, dn = [], [], [], []
-    for k, g in grads.items():
-        if g is None:
-            continue
-        gd = g.double().reshape(-1)
-        names.append(k)
-        norms.append(float(gd.norm()))
-        projs.append(float(torch.dot(gd, projection(k, gd.numel()))))
-        if arbiter is not None:
-            dn.append(float((gd - arbiter[k].double().reshape(-1)).norm()))
-        st = stored(k, g)
-        if st is not None:
-            out[tag + st[0] + k] = st[1]
-    out.update({tag + "grad_names": np.array(names), tag + "grad_norms": np.array(norms), tag + "grad_projs": np.array(projs)})
-    if arbiter is not None:
-        out[tag + "grad_dist"] = np.array(dn)
-    return out
 
 
 def main():

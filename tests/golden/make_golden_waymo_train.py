@@ -4,7 +4,9 @@
 oracle/train_ref.py::train_step (torch-CPU autograd over oracle rulebooks; ~2.5 minutes on 8 cores -- too slow to run
 inside the GPU test, hence this fixture).  Stored: the six loss terms, the threshold-safe guided-anchor threshold, label /
 candidate counts, the full gradient of a subset of layers (first / last sparse convs, every BatchNorm, the heads, the aux
-linears, a slice of the big BEV convs), and for EVERY parameter its gradient norm and a seeded random projection.
+linears, a slice of the big BEV convs), and for EVERY parameter its gradient norm and a seeded random projection -- for the
+fp32 oracle (keys without prefix) and, since round 5, for its float64 arbiter ("f64/"), plus every parameter's distance
+||g_fp32 - g_float64|| ("grad_dist") that the GPU bars are stated in multiples of.
 
     python tests/golden/make_golden_waymo_train.py        # writes tests/golden/waymo_train_ref.npz
 
@@ -70,6 +72,39 @@ def hash_name(name):
     return h
 
 
+def stored(k, g):
+    """-> (key prefix, array) of the slice of gradient `k` a training fixture keeps elementwise, or None"""
+    if k in FULL or ".bn" in k or k.split(".")[-2].isdigit() and g.dim() == 1:
+        return "grad:", g.numpy().astype(np.float32)
+    if k in SLICED:
+        return "grad8:", g[:8].numpy().astype(np.float32)
+    return None
+
+
+def pack(tag, losses, grads, arbiter=None):
+    """one variant of a step under the key prefix `tag` ("" = the fp32 oracle): loss terms, stored-layer gradients (float32
+    storage), norm + seeded projection of EVERY parameter's gradient, and -- when `arbiter` (the float64 gradients of the same
+    arithmetic) is given -- every parameter's distance to it (`grad_dist`)."""
+    out = {tag + "losses": np.array([losses[k] for k in sorted(losses)], np.float64)}
+    names, norms, projs, dn = [], [], [], []
+    for k, g in grads.items():
+        if g is None:
+            continue
+        gd = g.double().reshape(-1)
+        names.append(k)
+        norms.append(float(gd.norm()))
+        projs.append(float(torch.dot(gd, projection(k, gd.numel()))))
+        if arbiter is not None:
+            dn.append(float((gd - arbiter[k].double().reshape(-1)).norm()))
+        st = stored(k, g)
+        if st is not None:
+            out[tag + st[0] + k] = st[1]
+    out.update({tag + "grad_names": np.array(names), tag + "grad_norms": np.array(norms), tag + "grad_projs": np.array(projs)})
+    if arbiter is not None:
+        out[tag + "grad_dist"] = np.array(dn)
+    return out
+
+
 def main():
     import helpers as H
     from oracle import clib, nets as onets, train_ref
@@ -92,21 +127,15 @@ def main():
         losses, grads, ex = train_ref.train_step(*args, anchor_thr=thr, **kw)
     out = dict(anchor_thr=np.float64(thr), n_voxels=np.int64(len(co)), n_masked=np.int64(m.sum()),
                n_pos=np.int64((ex["labels"] > 0).sum()), n_ext_pos=np.int64((ex["ext_labels"] > 0).sum()),
-               n_guided=np.int64(len(ex["guided"][0])), loss_names=np.array(sorted(losses)),
-               losses=np.array([losses[k] for k in sorted(losses)], np.float64))
-    names, norms, projs = [], [], []
-    for k, g in grads.items():
-        if g is None:
-            continue
-        gd = g.double().reshape(-1)
-        names.append(k)
-        norms.append(float(gd.norm()))
-        projs.append(float(torch.dot(gd, projection(k, gd.numel()))))
-        if k in FULL or ".bn" in k or k.split(".")[-2].isdigit() and g.dim() == 1:
-            out["grad:" + k] = g.numpy().astype(np.float32)
-        elif k in SLICED:
-            out["grad8:" + k] = g[:8].numpy().astype(np.float32)
-    out.update(grad_names=np.array(names), grad_norms=np.array(norms), grad_projs=np.array(projs))
+               n_guided=np.int64(len(ex["guided"][0])), loss_names=np.array(sorted(losses)))
+    # round 5: the float64 arbiter of the same step on the same candidate set ("f64/" keys) and every parameter's distance
+    # ||g_fp32 - g_float64|| ("grad_dist"): the GPU bars of test_training_step_waymo_vs_oracle are multiples of it
+    import time
+    t0 = time.time()
+    l64, g64, _ = train_ref.train_step(*args, anchor_thr=thr, guided_sel=ex["guided_sel"], dtype=torch.float64, **kw)
+    print("float64 step: %.0f s" % (time.time() - t0), flush=True)
+    out.update(pack("", losses, grads, g64))
+    out.update(pack("f64/", l64, g64))
     path = os.path.join(HERE, "waymo_train_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", {k: round(v, 5) for k, v in losses.items()},

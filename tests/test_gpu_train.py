@@ -475,14 +475,13 @@ def test_bf16_step_launches_vs_rounded_reference(dev):
 def test_training_step_waymo_vs_oracle(dev):
     """BASELINE configs[4] as a TRAINING config, parity: one 180 000-point frame (79 302 voxels, grid 40 x 1504 x 1504, BEV
     188 x 188) through forward_train + backward on the HIP kernels -- the batch built by the product's own device_batch
-    (HIP voxelizer, anchor mask, rulebooks) -- against the CPU oracle's step on the same model / frame / boxes, read
-    from tests/golden/waymo_train_ref.npz (the oracle needs ~2.5 CPU-minutes for this frame;
-    tests/golden/make_golden_waymo_train.py made the file and is imported here for the shared seeded inputs).
-    Bars: the six loss terms 1e-3 relative (as for car_cfg; measured equal to 5 digits); gradients 5e-3 relative L2 --
-    elementwise for the stored layers (first / last sparse convs, every BatchNorm, heads, aux linears, a slice of four BEV
-    convs), through the norm and a seeded random projection for every other parameter.  (car_cfg holds 2e-3 and
-    measures < 6e-4; at this scale the auxiliary loss terms are 192 and 44 -- their gradients, scattered back with float
-    atomics over 5x the rows, dominate the first sparse layers, which measure 2-4e-3.)"""
+    (HIP voxelizer, anchor mask, rulebooks) -- against the CPU oracle's step on the same model / frame / boxes, read from
+    tests/golden/waymo_train_ref.npz (the oracle needs minutes for this frame; tests/golden/make_golden_waymo_train.py made
+    the file and is imported here for the shared seeded inputs).
+    Round 5: the golden holds the fp32 oracle AND its float64 arbiter; the bars are those of the K21 workload -- six loss
+    terms 1e-4 relative to the arbiter; every stored tensor ||g_gpu - g64|| <= max(3 x ||g_cpu32 - g64||, 5e-3 ||g64||), the
+    stored layers together 3 x; every parameter's norm and seeded projection within the same multiple of its stored distance.
+    (Rounds 3-4: fixed 5e-3 bars against the fp32 oracle and 2.5e-2 on the projections.)"""
     import importlib.util
     import os
     from sassd import train
@@ -505,41 +504,51 @@ def test_training_step_waymo_vs_oracle(dev):
     total.backward()
     torch.cuda.synchronize()
     got_l = {k: float(v.detach().sum()) for k, v in losses.items()}
-    ref_l = dict(zip([str(k) for k in G["loss_names"]], G["losses"]))
-    assert set(got_l) == set(ref_l) and len(ref_l) == 6
-    for k, v in ref_l.items():
-        assert v != 0 and abs(got_l[k] - v) <= 1e-3 * max(1.0, abs(v)), (k, got_l[k], v)
+    names = [str(k) for k in G["loss_names"]]
+    arb_l, flo_l = dict(zip(names, G["f64/losses"])), dict(zip(names, G["losses"]))
+    assert set(got_l) == set(arb_l) and len(arb_l) == 6
+    for k, v in arb_l.items():
+        assert v != 0 and abs(got_l[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got_l[k], v, flo_l[k])
     params = dict(model.named_parameters())
-    worst, worst_n, worst_p = {}, {}, {}
+    got, arb, flo = {}, {}, {}
     for k in G.files:
-        if k.startswith("grad:") or k.startswith("grad8:"):
-            name = k.split(":", 1)[1]
+        if k.startswith("f64/grad:") or k.startswith("f64/grad8:"):
+            kind, name = k[4:].split(":", 1)
             g = params[name].grad
-            g = g[:8] if k.startswith("grad8:") else g
-            ref = torch.from_numpy(G[k])
-            if float(ref.norm()) > 1e-7:
-                worst[name] = _rel(g, ref)
-    for name, norm, proj in zip(G["grad_names"], G["grad_norms"], G["grad_projs"]):
+            assert g is not None, name
+            got[name] = g[:8] if kind == "grad8" else g
+            arb[name] = torch.from_numpy(G[k])
+            flo[name] = torch.from_numpy(G[kind + ":" + name])
+    # (whole-model floor 5e-3 like the per-tensor one: at this scale the auxiliary terms are 192 and 44, their gradients --
+    # scattered back with float atomics over 5 x the rows -- dominate the first sparse layers AND the whole-model norm, and the
+    # CPU oracle's own distance to float64 is only 1.4e-5 here, so a multiple of it would be a bar on atomic-add order)
+    fl = dict(rel_floor=5e-3, whole_factor=3.0, whole_floor=5e-3)
+    bad, whole, whole_ok, rows = H.arbiter_report(got, arb, flo, **fl)
+    H.dump_rows("waymo golden fp32", rows)
+    dist = dict(zip([str(n) for n in G["grad_names"]], G["grad_dist"]))
+    worst_n, worst_p, bad_np = {}, {}, {}
+    for name, norm, proj in zip(G["f64/grad_names"], G["f64/grad_norms"], G["f64/grad_projs"]):
         name = str(name)
-        g = params[name].grad
-        assert g is not None, name
         if norm < 1e-7:
             continue
+        g = params[name].grad
+        assert g is not None, name
         gd = g.detach().double().cpu().reshape(-1)
-        worst_n[name] = abs(float(gd.norm()) - norm) / norm
-        # error e with ||e|| <= 2e-3 ||g||, independent of the seeded direction r (unit variance): dot(e, r) ~ N(0, ||e||^2)
-        worst_p[name] = abs(float(torch.dot(gd, MG.projection(name, gd.numel()))) - proj) / norm
-    print("waymo-scale training step vs oracle: losses", {k: (round(got_l[k], 5), round(float(v), 5)) for k, v in ref_l.items()},
-          "| stored-layer gradients: worst rel L2 %.2e over %d tensors | all %d parameters: worst norm error %.2e, worst "
-          "projection error %.2e" % (max(worst.values()), len(worst), len(worst_n), max(worst_n.values()),
-                                     max(worst_p.values())))
-    bad = {k: v for k, v in worst.items() if not v < 5e-3}
-    assert len(worst) >= 40 and not bad, bad
-    assert len(worst_n) >= 75 and max(worst_n.values()) < 5e-3, {k: v for k, v in worst_n.items() if v >= 5e-3}
-    assert max(worst_p.values()) < 5 * 5e-3, {k: v for k, v in worst_p.items() if v >= 2.5e-2}
-
-
-# ---- evaluation with the overlap matrices on the GPU (kept last in the last -m gpu file) --------------
+        slack = max(3 * dist[name], fl["rel_floor"] * norm)
+        en = abs(float(gd.norm()) - norm)
+        ep = abs(float(torch.dot(gd, MG.projection(name, gd.numel()))) - proj)      # dot(e, r) ~ N(0, ||e||^2): 4 sigma
+        worst_n[name], worst_p[name] = en / norm, ep / norm
+        if en > slack or ep > 4 * slack:
+            bad_np[name] = (en / norm, ep / norm, slack / norm)
+    print("waymo-scale training step vs the float64 arbiter: losses (GPU, arbiter, CPU fp32)",
+          {k: (round(got_l[k], 5), round(float(v), 5), round(float(flo_l[k]), 5)) for k, v in arb_l.items()},
+          "| stored layers together: GPU %.2e / CPU oracle %.2e | worst stored tensors (GPU, CPU oracle): %s | all %d parameters: "
+          "worst norm error %.2e, worst projection error %.2e" % (whole[0], whole[1], [(k, "%.1e" % a, "%.1e" % b_) for a, b_, k in rows[:6]],
+                                                                len(worst_n), max(worst_n.values()), max(worst_p.values())))
+    assert len(rows) >= 40 and len(worst_n) >= 75
+    assert not bad, bad
+    assert whole_ok, whole
+    assert not bad_np, bad_np
 
 def test_kitti_eval_on_gpu(dev):
     """get_official_eval_result with the rotated BEV / 3-D overlaps computed by sassd_rotate_iou_eval (HIP): the report

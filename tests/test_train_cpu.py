@@ -252,6 +252,12 @@ def test_waymo_train_golden_is_complete():
     assert len(G["grad_names"]) == len(G["grad_norms"]) == len(G["grad_projs"]) >= 75
     stored = [k for k in G.files if k.startswith("grad:") or k.startswith("grad8:")]
     assert len(stored) >= 40 and all(np.isfinite(G[k]).all() for k in stored)
+    # round 5: the float64 arbiter of the same step rides along, with every parameter's distance to it
+    assert all(("f64/" + k) in G.files for k in stored) and len(G["grad_dist"]) == len(G["grad_names"]) == len(G["f64/grad_names"])
+    assert (np.abs(G["losses"] - G["f64/losses"]) <= 1e-5 * np.abs(G["f64/losses"])).all()
+    num = sum(float(((G[k].astype(np.float64) - G["f64/" + k]) ** 2).sum()) for k in stored)
+    den = sum(float((G["f64/" + k].astype(np.float64) ** 2).sum()) for k in stored)
+    assert 1e-6 < (num / den) ** 0.5 < 3e-3, (num / den) ** 0.5      # the fp32 floor of this workload
 
 
 def test_deferred_bn_batch_counters_land_in_any_state_dict():

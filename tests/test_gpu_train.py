@@ -519,10 +519,8 @@ def test_training_step_waymo_vs_oracle(dev):
             got[name] = g[:8] if kind == "grad8" else g
             arb[name] = torch.from_numpy(G[k])
             flo[name] = torch.from_numpy(G[kind + ":" + name])
-    # (whole-model floor 5e-3 like the per-tensor one: at this scale the auxiliary terms are 192 and 44, their gradients --
-    # scattered back with float atomics over 5 x the rows -- dominate the first sparse layers AND the whole-model norm, and the
-    # CPU oracle's own distance to float64 is only 1.4e-5 here, so a multiple of it would be a bar on atomic-add order)
-    fl = dict(rel_floor=5e-3, whole_factor=3.0, whole_floor=5e-3)
+    # (measured: stored layers together GPU 4.0e-5 / CPU oracle 1.4e-5; worst tensor extra_conv.1.bias 2.2e-3 / 8.1e-4)
+    fl = dict(rel_floor=5e-3, whole_factor=3.0, whole_floor=5e-4)
     bad, whole, whole_ok, rows = H.arbiter_report(got, arb, flo, **fl)
     H.dump_rows("waymo golden fp32", rows)
     dist = dict(zip([str(n) for n in G["grad_names"]], G["grad_dist"]))

@@ -66,6 +66,39 @@ def _const_i32(dev, values):
     return _CONSTS_I32[key]
 
 
+_CONSTS_F32 = {}
+
+
+def _const_f32(dev, values):
+    key = (str(dev), tuple(float(v) for v in values))
+    if key not in _CONSTS_F32:
+        if len(_CONSTS_F32) > 4096:
+            _CONSTS_F32.clear()
+        _CONSTS_F32[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
+    return _CONSTS_F32[key]
+
+
+_ARANGE_I32 = {}
+
+
+def _arange_i32(dev, n):
+    """cached torch.arange(n, int32) (read-only): the padded-row masks of a step compare it with the device counts"""
+    key = (str(dev), int(n))
+    if key not in _ARANGE_I32:
+        if len(_ARANGE_I32) > 64:
+            _ARANGE_I32.clear()
+        _ARANGE_I32[key] = torch.arange(int(n), device=dev, dtype=torch.int32)
+    return _ARANGE_I32[key]
+
+
+def _scaled_terms(sums, scales):
+    """Loss sums [n] x per-term constants -> n loss tensors of shape [1] in TWO launches each way (one multiply by a cached constant
+    vector; unbind forward = views, backward = one stack).  `sums[i:i+1] / b * w` per term was two to three elementwise
+    launches forward and a division, a multiplication and a slice backward (zeros + copy) per term backward: ~25 of the
+    training step's small torch launches (round 5)."""
+    return tuple(t.view(1) for t in (sums * _const_f32(sums.device, scales)).unbind(0))      # ([1] each, like the module path)
+
+
 _GT_CAT = [None, None]
 
 
@@ -324,7 +357,8 @@ class SpMiddleFHD(nn.Module):
         sums = AuxHeadFn.apply(middle[0].features, middle[1].features, middle[2].features, self.point_fc.weight,
                                self.point_cls.weight, self.point_reg.weight, nn_idx, nn_d2, label, target, npos)
         n = len(gt_bboxes)
-        return dict(aux_loss_cls=sums[0:1] / n, aux_loss_reg=sums[1:2] / n)
+        cls_term, reg_term = _scaled_terms(sums, (1.0 / n, 1.0 / n))
+        return dict(aux_loss_cls=cls_term, aux_loss_reg=reg_term)
 
     def aux_loss(self, points, point_cls, point_reg, gt_bboxes):
         """cmn.py:74-104."""
@@ -481,9 +515,10 @@ class SSDRotateHead(nn.Module):
                                cls_preds.view(b, -1, self._num_class),
                                dir_cls_preds.view(b, -1, 2) if self._use_direction_classifier else None,
                                labels.view(b, -1), targets.view(b, -1, self._box_code_size), all_anchors, num_pos)
-        out = dict(rpn_loc_loss=sums[0:1] / b * 2, rpn_cls_loss=sums[1:2] / b)
+        terms = _scaled_terms(sums, (2.0 / b, 1.0 / b, 0.2 / b)[:int(sums.shape[0])])
+        out = dict(rpn_loc_loss=terms[0], rpn_cls_loss=terms[1])
         if self._use_direction_classifier:
-            out['rpn_dir_loss'] = sums[2:3] / b * .2
+            out['rpn_dir_loss'] = terms[2]
         return out
 
     def loss(self, box_preds, cls_preds, dir_cls_preds, gt_bboxes, gt_labels, gt_types, anchors, anchors_mask, cfg):
@@ -707,7 +742,7 @@ class PSWarpHead(nn.Module):
         targets = torch.empty(b, capk, 7, dtype=torch.float32, device=dev)
         num_pos = torch.empty(b, dtype=torch.int32, device=dev)
         boxes = guided.detach().float().contiguous()
-        row_ok = (torch.arange(capk, device=dev, dtype=torch.int32)[None, :] < counts[:, None]).view(torch.uint8)
+        row_ok = (_arange_i32(dev, capk)[None, :] < counts[:, None]).view(torch.uint8)
         if cfg.assigner.similarity_fn != 'RotateIou3dSimilarity':
             raise NotImplementedError("padded rescoring loss: RotateIou3dSimilarity only")
         offs, o = [0], 0

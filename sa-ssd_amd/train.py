@@ -556,9 +556,10 @@ def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, 
     voxels = torch.empty(cap0, max_points, ndim, dtype=torch.float32, device=dev)
     coors4 = torch.empty(cap0, 4, dtype=torch.int32, device=dev)
     nump = torch.empty(cap0, dtype=torch.int32, device=dev)
-    row_off = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-    vnum = torch.zeros(B, dtype=torch.int32, device=dev)
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    # one zero fill for every small device counter of the batch: [row offsets B+1 | voxel counts B | level row counts 3 | status 1]
+    # (the last four are contiguous: host sync 2 reads them as one slice, without a cat)
+    small = torch.zeros(2 * B + 5, dtype=torch.int32, device=dev)
+    row_off, vnum, n_dev, status = small[:B + 1], small[B + 1:2 * B + 1], small[2 * B + 1:2 * B + 4], small[2 * B + 4:]
     for b, p in enumerate(points):
         K.voxelize(p, vs, cr, max_points, max_voxels, batch_idx=b, coors_cols=4, want_voxels=True, want_mean=False,
                    out=dict(voxels=voxels, coors=coors4, num_points=nump, voxel_num=vnum[b:b + 1]),
@@ -591,17 +592,16 @@ def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, 
             for _ in range(3):
                 caps.append(max(min(8 * caps[-1], max(n0 * factor, n0 + 16384)), 1))
             idx = [coors4[:max(n0, 1)]] + [torch.empty(c, 4, dtype=torch.int32, device=dev) for c in caps[1:]]
-            n_dev = torch.zeros(3, dtype=torch.int32, device=dev)
             n_ptrs = [row_off[B:B + 1]] + [n_dev[i:i + 1] for i in range(3)]
             nbr_s = [torch.empty(c, 27, dtype=torch.int32, device=dev) for c in caps]
             nbr_d = [None] + [torch.empty(c, 27, dtype=torch.int32, device=dev) for c in caps[1:]]
             pyr = K.RulebookPyramid(idx, n_ptrs, caps, shape0, B, nbr_s, nbr_d, status)
             pyr.build()
-            return idx, nbr_s, nbr_d, pyr, torch.cat([n_dev, status]).cpu().numpy()   # host sync 2: row counts + flags
+            return idx, nbr_s, nbr_d, pyr, small[2 * B + 1:].cpu().numpy()            # host sync 2: row counts + flags
 
         idx, nbr_s, nbr_d, pyr, tail = build_pyramid(level_cap_factor)
         if int(tail[3]) != 0 and level_cap_factor < 8:
-            status.zero_()                                 # capacity overflow: once more with the worst-case bound
+            small[2 * B + 1:].zero_()                      # capacity overflow: once more with the worst-case bound
             idx, nbr_s, nbr_d, pyr, tail = build_pyramid(8)
         if int(tail[3]) != 0:
             raise RuntimeError("device_batch: status 0x%x (voxel / rulebook capacity overflow: raise max_voxels)"

@@ -580,10 +580,10 @@ class SSDRotateHead(nn.Module):
         gather.  -> (guided [B, Gmax+cap, 7], counts [B] int32)."""
         b = box_preds.shape[0]
         dev = box_preds.device
-        if isinstance(anchors, dict):
-            anchors = torch.cat(list(anchors.values()), 1)
+        if isinstance(anchors, dict):               # (one class: the tensor itself -- a cat of one tensor is a copy)
+            anchors = torch.cat(list(anchors.values()), 1) if len(anchors) > 1 else next(iter(anchors.values()))
         if isinstance(anchors_mask, dict):
-            anchors_mask = torch.cat(list(anchors_mask.values()), 1)
+            anchors_mask = torch.cat(list(anchors_mask.values()), 1) if len(anchors_mask) > 1 else next(iter(anchors_mask.values()))
         a = anchors.view(b, -1, 7).shape[1]
         cap = min(int(cap), a) if cap else a        # default: every anchor fits (padding rows cost next to nothing)
         mask = anchors_mask.view(b, -1)
@@ -651,10 +651,10 @@ class SSDRotateHead(nn.Module):
         """ssd_rotate_head.py:316-388, module-level torch path used by training (gradients flow into box_preds;
         ground-truth boxes are prepended).  Inference uses the fused sassd_decode_filter kernel instead."""
         b = box_preds.shape[0]
-        if isinstance(anchors, dict):
-            anchors = torch.cat(list(anchors.values()), 1)
+        if isinstance(anchors, dict):               # (one class: the tensor itself -- a cat of one tensor is a copy)
+            anchors = torch.cat(list(anchors.values()), 1) if len(anchors) > 1 else next(iter(anchors.values()))
         if isinstance(anchors_mask, dict):
-            anchors_mask = torch.cat(list(anchors_mask.values()), 1)
+            anchors_mask = torch.cat(list(anchors_mask.values()), 1) if len(anchors_mask) > 1 else next(iter(anchors_mask.values()))
         batch_box = T.second_box_decode(box_preds.view(b, -1, self._box_code_size), anchors.view(b, -1, 7))
         batch_mask = anchors_mask.view(b, -1).bool()
         batch_cls = cls_preds.view(b, -1, self._num_class)

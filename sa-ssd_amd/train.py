@@ -527,6 +527,20 @@ def load_params_from_file(model, filename, to_cpu=False):
     return _copy_model_state(model, ck['model_state'])
 
 
+_ANCHORS_B = {}
+
+
+def _batched_anchors(an, B):
+    """[A, 7] anchors -> contiguous [B, A, 7], cached per (anchor tensor, B): anchors are constants of a training run"""
+    key = (an.data_ptr(), an._version, tuple(an.shape), int(B))
+    hit = _ANCHORS_B.get(key)
+    if hit is None:
+        if len(_ANCHORS_B) > 16:
+            _ANCHORS_B.clear()
+        hit = _ANCHORS_B[key] = (an, an.unsqueeze(0).repeat(B, 1, 1).contiguous())    # (pins `an`: its address stays its own)
+    return hit[1]
+
+
 def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, voxel_size, pc_range,
                  max_points=5, max_voxels=20000, area_threshold=1, model=None, level_cap_factor=2):
     """What KittiLiDAR.prepare_train_img + collate produce (kitti.py:212-262,333-343), built on the device from raw
@@ -577,11 +591,16 @@ def device_batch(points, gt_bboxes, gt_types, class_names, anchors, anchors_bv, 
         kw["num_points"].append(nump[lo:hi])
         for c in class_names:
             kw["anchors"][c].append(anchors[c])
-            kw["anchors_mask"][c].append(masks[c][b].bool())
+            kw["anchors_mask"][c].append(masks[c][b].view(torch.bool))     # (the kernel writes 0 / 1 bytes: a view, no launch)
         names = list(class_names)
         lab = [names.index(t) + 1 if t in names else 0 for t in gt_types[b]]
         kw["gt_labels"].append(torch.tensor(lab, dtype=torch.int64, device=dev))
-    kw["sassd_merged"] = dict(voxels=voxels[:n0], num_points=nump[:n0], coordinates=coors4[:n0])
+    # the batch as merge_second_batch would build it, without its launches: voxel buffers are already one tensor; the anchors
+    # of every sample are the same tensor (one cached [B, A, 7] copy per anchor set instead of a stack per step); the masks
+    # are already [B, A]
+    kw["sassd_merged"] = dict(voxels=voxels[:n0], num_points=nump[:n0], coordinates=coors4[:n0],
+                              anchors={c: _batched_anchors(anchors[c], B) for c in class_names},
+                              anchors_mask={c: masks[c].view(torch.bool) for c in class_names})
     if model is not None:
         shape0 = [int(v) for v in model.neck.sparse_shape]
 

@@ -417,8 +417,8 @@ def test_bf16_step_launches_vs_rounded_reference(dev):
     every dense-convolution launch of the K21 x 2 step under set_bev_precision("bf16") -- forward, data gradient and weight
     gradient of the eight BEVNet layers, the fused RPN head and the two rescoring-head layers -- is replayed ON ITS LIVE
     OPERANDS (the tensors the step itself produced on the GPU) by torch-CPU convolutions over operands rounded to bf16 with
-    torch.bfloat16 where oracle.train_ref.bf16_conv_rule says the HIP kernel rounds, and must agree to 1e-5 relative L2 (fp32
-    CPU sums; the kernels measure 5e-7 against float64 in tests/test_gpu_bf16.py).  Everything between those launches is the
+    torch.bfloat16 where oracle.train_ref.bf16_conv_rule says the HIP kernel rounds, and must agree to 1e-5 relative L2 (weight
+    gradients 2e-5; fp32 CPU sums; the kernels measure 5e-7 against float64 in tests/test_gpu_bf16.py).  Everything between those launches is the
     code of the fp32 step, which test_training_step_k21_vs_oracle[fp32] holds against the float64 arbiter: together the two
     tests pin the bf16 step launch by launch, which no whole-step comparison can (see there)."""
     from oracle import train_ref
@@ -468,7 +468,10 @@ def test_bf16_step_launches_vs_rounded_reference(dev):
           "gradient / %d weight-gradient launches on the bf16 MFMA of %d layers): %s"
           % (rounded[0], rounded[1], rounded[2], nf, {"%s %s" % k: "%.1e" % v for k, v in sorted(worst.items())}))
     assert rounded[0] >= 7 and rounded[1] >= 7 and rounded[2] >= 11, rounded
-    bad = {k: v for k, v in worst.items() if not v < 1e-5}
+    # forward / data gradient 1e-5 (measured <= 3.5e-7).  Weight gradient 2e-5: its CPU reference sums 70 400 products per
+    # element in fp32 (oneDNN's blocking depends on the host's core count) -- the measured 5.8e-6 on the 256 -> 256 layers is that
+    # reference's own rounding, the kernel is 5e-7 from float64 on such operands (tests/test_gpu_bf16.py)
+    bad = {k: v for k, v in worst.items() if not v < (2e-5 if k[0] == "weight gradient" else 1e-5)}
     assert not bad, bad
 
 

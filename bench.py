@@ -65,6 +65,7 @@ SPLIT_SLOTS = 8                   # bf16 multiplies the split GEMM spends per fp
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured float4 copy)
 MEASURED_HBM_GBS = 6290.0
 PUBLISHED_FPS = 25.0              # /root/reference/readme.md:2 "can run at 25 FPS" 
+PYRAMID_DEFAULT = "levels"        # rulebook pyramid form of the plans: "levels" (fill + 2 launches per level) | "persistent"
 
 
 def build_model(seed=0, dev=None, config="car"):
@@ -341,7 +342,7 @@ def main_train(args):
     dev = torch.device("cuda", local_rank)
     if args.spconv_cfg:
         from sassd import kernels as K0
-        K0.debug_set_spconv(args.spconv_cfg << 16)
+        K0.DEFAULT_CFG["spconv"] = K0.spconv_cfg(args.spconv_cfg)     # host-side default of the binding, passed per call
     out = train_measure(args, dev, rank, world, "waymo" if args.config == "waymo" else "car", args.precision,
                         args.steps, args.warmup, args.batch if args.batch > 1 else 0, args.frames,
                         False if args.torch_bn else None)
@@ -373,6 +374,67 @@ def timed_graph_ms(plan, batch, reps=30):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
+
+
+def infer_extra(dev, config, steps=60, warmup=10, inflight=3, pyramid_persistent=False):
+    """configs[3] / configs[4] (inference side) as a compact record of the DEFAULT line (`infer_multi`, `infer_waymo`), so that
+    the driver's run measures them too: the same measurement as the headline -- `steps` hipGraph replays of the whole frame
+    batch, `inflight` plans on separate streams, bracketed by synchronize, median of three trials -- plus the sparse segment
+    (rulebooks + 14 sparse convs as its own hipGraph) against the HBM roofline."""
+    model, w = build_model(0, dev, config)
+    B, S = w["batch"], max(1, inflight)
+    sd = model.state_dict()
+    plans = [InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["anchors_bv"], device=dev,
+                           pyramid_persistent=pyramid_persistent, **w["plan"]) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    clouds = [torch.from_numpy(w["frame"](i)).to(dev) for i in range(max(8, B))]
+
+    def batch_of(i):
+        return [clouds[(i * B + j) % len(clouds)] for j in range(B)]
+    for pl, st in zip(plans, streams):
+        with torch.cuda.stream(st):
+            pl.capture(w["points_cap"])
+    torch.cuda.synchronize()
+
+    def step(i):
+        with torch.cuda.stream(streams[i % S]):
+            plans[i % S].run_graph(batch_of(i))
+    for i in range(max(warmup, S)):
+        step(i)
+    torch.cuda.synchronize()
+    for pl in plans:
+        assert int(pl.status.item()) == 0, "pipeline status 0x%x" % int(pl.status.item())
+    dts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
+    plan = plans[0]
+    ndet, ncand = int(plan.det["counts"].sum().item()), int(plan.df["counts"].sum().item())
+    with torch.cuda.stream(streams[0]):
+        plan.run_from_points(batch_of(0))
+        torch.cuda.synchronize()
+        work = plan.sparse_work()
+        plan.capture(w["points_cap"], stages=("sparse",))
+        plan.stage_inputs(batch_of(0))
+        sp_ms = timed_graph_ms(plan, None, reps=20)
+    sp_gbs = (work["bytes_gs"] + work["rulebook_bytes"]) / (sp_ms * 1e-3) / 1e9
+    del plans, plan
+    torch.cuda.empty_cache()
+    return {"metric": "%s inference frames/sec" % config, "value": round(steps * B / dt, 3), "unit": "frames/s",
+            "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup, "trials": 3,
+            "config": {"workload": "%s, batch=%d, random-init SA-SSD weights, points resident in HBM" % (w["desc"], B),
+                       "frames_per_step_per_gpu": B, "frames_in_flight": S},
+            "roofline_sparse": {"bound": "hbm", "ms": round(sp_ms, 4), "achieved": round(sp_gbs, 1), "unit": "GB/s",
+                                "frac": round(sp_gbs / PEAK_HBM_GBS, 4),
+                                "frac_of_measured_copy_peak": round(sp_gbs / MEASURED_HBM_GBS, 4),
+                                "bytes_gs": work["bytes_gs"], "bytes_min": work["bytes_min"],
+                                "rulebook_bytes": work["rulebook_bytes"], "rows": work["n"]},
+            "detections_last_frame": ndet, "guided_anchor_candidates_last_frame": ncand}
 
 
 def main():
@@ -408,6 +470,10 @@ def main():
                     "bf16 MFMA over split operands (default), 1 = the fp32 MFMA (the default of rounds 2-3)")
     ap.add_argument("--eager", action="store_true", help="issue the ~80 launches per frame from the host instead of "
                     "replaying the captured hipGraph (A/B)")
+    ap.add_argument("--pyramid", choices=("levels", "persistent"), default=PYRAMID_DEFAULT, help="rulebook pyramid: two "
+                    "launches per level, or ONE persistent launch with in-launch grid barriers (A/B)")
+    ap.add_argument("--no-extra", action="store_true", help="default (car) run: skip the `infer_multi` / `infer_waymo` / "
+                    "`train_waymo` records (BASELINE configs[3] / [4]) that follow the headline measurement")
     args = ap.parse_args()
     env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if args.gpus > 1 and env_world == 0:
@@ -423,19 +489,16 @@ def main():
     torch.cuda.set_device(local_rank)                                         # reduction (and the DDP exchange) use it
     dev = torch.device("cuda", local_rank)
 
-    if args.spconv_cfg:
-        from sassd import kernels as K0
-        K0.debug_set_spconv(args.spconv_cfg << 16)
-    if args.wino4_cfg:
-        from sassd import kernels as K0
-        K0.debug_set_wino4(args.wino4_cfg, 0)
+    from sassd import kernels as K0
+    plan_cfg = dict(spconv_cfg=K0.spconv_cfg(args.spconv_cfg), wino4_cfg=K0.wino4_cfg(args.wino4_cfg))   # per-call words
     model, w = build_model(0, dev, args.config)
     B = args.batch if args.batch > 0 else w["batch"]
     S = max(1, args.inflight)
     sd = model.state_dict()
 
     def new_plan():
-        return InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["anchors_bv"], device=dev, **w["plan"])
+        return InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["anchors_bv"], device=dev,
+                             pyramid_persistent=args.pyramid == "persistent", **plan_cfg, **w["plan"])
 
     plans = [new_plan() for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
@@ -520,12 +583,18 @@ def main():
     work = iso_plan.sparse_work()                              # of the last frame processed
 
     # the sparse segment (7 rulebooks + 14 sparse convs) as its own hipGraph
-    sp_ms = None
+    sp_ms = sp_convs_ms = sp_pyr_ms = None
     if not args.eager:
         with torch.cuda.stream(streams[0]):
             iso_plan.capture(w["points_cap"], stages=("sparse",))
             iso_plan.stage_inputs(batch_of(29))
             sp_ms = timed_graph_ms(iso_plan, None)
+            # the two halves of the segment on their own (the floor model of DESIGN section 8: the convs on the rulebooks the
+            # previous replay left behind; the pyramid alone)
+            iso_plan.capture(w["points_cap"], stages=("sparse_convs",))
+            sp_convs_ms = timed_graph_ms(iso_plan, None)
+            iso_plan.capture(w["points_cap"], stages=("pyramid",))
+            sp_pyr_ms = timed_graph_ms(iso_plan, None)
             iso_plan.capture(w["points_cap"], stages=("voxelize", "backbone", "tail"))
             frame_ms = timed_graph_ms(iso_plan, batch_of(29))
     # the launches of an F(4x4) layer timed separately on the LIVE buffers the last frame left behind (real activations:
@@ -540,29 +609,28 @@ def main():
         chained = any(iso_plan.chain)
 
         def timed_part(flags, call):
-            K.debug_set_wino4(args.wino4_cfg, flags)
+            word = K.wino4_cfg(args.wino4_cfg, flags)
             for _ in range(3):
-                call()
+                call(word)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):
-                call()
+                call(word)
             e1.record()
             torch.cuda.synchronize()
-            K.debug_set_wino4(args.wino4_cfg, 0)
             return e0.elapsed_time(e1) / 20
         with torch.cuda.stream(streams[0]):
             prev = (scale, shift, True)
             # debug bits: 16 skip input transform, 32 skip GEMM, 64 skip output transform, 128 skip fused transform
-            w4_parts["gemm"] = timed_part(128 | 16, lambda: K.conv2d_wino4_chain(
-                None, prev, wp, 256, cout, cm, B, H_, W_, scale, shift, True, None, ws))
+            w4_parts["gemm"] = timed_part(128 | 16, lambda c: K.conv2d_wino4_chain(
+                None, prev, wp, 256, cout, cm, B, H_, W_, scale, shift, True, None, ws, cfg=c))
             if chained:
-                w4_parts["outin_fused"] = timed_part(32, lambda: K.conv2d_wino4_chain(
-                    None, prev, wp, 256, cout, cm, B, H_, W_, scale, shift, True, None, ws))
-            w4_parts["out"] = timed_part(128 | 32, lambda: K.conv2d_wino4_chain(
-                None, prev, wp, 256, cout, cm, B, H_, W_, scale, shift, True, iso_plan.act[1], ws))
-            w4_parts["in"] = timed_part(32, lambda: K.conv2d_wino4_chain(
-                iso_plan.dense, None, wp0, iso_plan.bev_cin[0], cout, cm, B, H_, W_, scale, shift, True, None, ws))
+                w4_parts["outin_fused"] = timed_part(32, lambda c: K.conv2d_wino4_chain(
+                    None, prev, wp, 256, cout, cm, B, H_, W_, scale, shift, True, None, ws, cfg=c))
+            w4_parts["out"] = timed_part(128 | 32, lambda c: K.conv2d_wino4_chain(
+                None, prev, wp, 256, cout, cm, B, H_, W_, scale, shift, True, iso_plan.act[1], ws, cfg=c))
+            w4_parts["in"] = timed_part(32, lambda c: K.conv2d_wino4_chain(
+                iso_plan.dense, None, wp0, iso_plan.bev_cin[0], cout, cm, B, H_, W_, scale, shift, True, None, ws, cfg=c))
     headline = args.config == "car" and B == 1
     # ---- the training half of BASELINE.json's metric (configs[2]: car_cfg, batch 2 / GPU, bf16, DDP): every rank takes
     # part (gradient all-reduce over RCCL at N > 1); the record rides in the same JSON line as `train` ------------------
@@ -635,6 +703,7 @@ def main():
         "vs_baseline": round(fps / world / PUBLISHED_FPS, 3) if headline else None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s, batch=%d, random-init SA-SSD weights, points resident in HBM" % (w["desc"], B),
                    "frames_per_step_per_gpu": B, "frames_in_flight": S, "spconv_cfg": args.spconv_cfg,
+                   "rulebook_pyramid": args.pyramid,
                    "launch": "eager host launches" if args.eager else "one hipGraph replay per frame",
                    "parallelism": "frame-sharded x%d, no collective" % world,
                    "vs_baseline_ref": "reference readme.md:2 '25 FPS' (hardware unstated), per-GPU fps / 25"},
@@ -669,6 +738,8 @@ def main():
                             "bytes_gs": work["bytes_gs"], "bytes_min": work["bytes_min"],
                             "rulebook_bytes": work["rulebook_bytes"], "flops": work["flops"],
                             "ms": round(sp_ms, 4), "ms_eager_isolated": round(iso_ms["sparse"], 4), "rows": work["n"],
+                            "ms_convs_only": None if sp_convs_ms is None else round(sp_convs_ms, 4),
+                            "ms_pyramid_only": None if sp_pyr_ms is None else round(sp_pyr_ms, 4),
                             "counters": sp_counters, "counters_measured_at": sp_counters_at,
                             "counters_unit": "per sparse-conv kernel: fractions of its wave-cycles parked (SQ_WAIT_ANY), issue-"
                                              "stalled (SQ_WAIT_INST_ANY), issuing (SQ_ACTIVE_INST_ANY); mfma_busy_fraction = "
@@ -694,6 +765,20 @@ def main():
             out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             watchdog.cancel()
+    # ---- BASELINE configs[3] / [4] in the same line (N = 1 only: no collective, rank 0): short runs of the same measurement
+    if world == 1 and headline and not args.no_extra and not args.eager:
+        del plans, plan
+        torch.cuda.empty_cache()
+        for key, fn in (("infer_multi", lambda: infer_extra(dev, "multi", 60, 10, S, args.pyramid == "persistent")),
+                        ("infer_waymo", lambda: infer_extra(dev, "waymo", 40, 8, S, args.pyramid == "persistent")),
+                        ("train_waymo", lambda: train_measure(args, dev, rank, world, "waymo", "bf16", 12, 4, frames=8))):
+            t0 = time.perf_counter()
+            try:
+                out[key] = fn()
+            except Exception as e:                               # the headline line is still valid without it
+                out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out[key]["wall_s"] = round(time.perf_counter() - t0, 1)
+            torch.cuda.empty_cache()
     if world == 1 and headline and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, w, gpu_plan=iso_plan)
     print(json.dumps(out))

@@ -34,6 +34,7 @@ extern "C" {
 #define SASSD_ST_VOXEL_OVERFLOW   1   /* more rows than an output capacity      */
 #define SASSD_ST_HASH_FULL        2   /* hash table probe exhausted             */
 #define SASSD_ST_BOX_OVERFLOW     4   /* more candidate boxes than capK / capD  */
+#define SASSD_ST_GRID_SYNC        8   /* an in-launch grid barrier timed out (persistent rulebook pyramid) */
 
 #define SASSD_MAX_POINTS_PER_VOXEL 64  /* max_points supported by sassd_voxelize (reference default: 35) */
 
@@ -41,15 +42,20 @@ const char *sassd_version(void);
 int sassd_last_hip_error(void);
 const char *sassd_last_hip_error_string(void);
 
-/* Debug / ablation switches of the sparse-conv forward kernels (tools/ablate_spconv.py); 0 in production.  Low 16 bits:
- * bit1 no LDS slab update, bit2 no MFMA, bit4 ticket offset assignment (round-3 kernel), bit5 every gather reads row 0,
- * bit6 one weight image for every offset (bits 5 / 6 keep the number of loads in flight unchanged: a load under a branch
- * changes the compiler's wait counts, the very thing being measured), bit8 register-stationary kernel everywhere.
- * Bits 16+: kernel / workgroup geometry -- 0 the per-shape, per-capacity default; 1 / 5 = spconv_gs_kernel on 4 / 8 waves,
- * 8 / 9 = the balanced kernel spconv_gq_kernel with 4x4x1 quads / 16x16x4 tiles (the four geometries the default picks
- * from), 10 = the round-3 default (1 or 5 by capacity) for every layer; any other value makes the launch return SASSD_EINVAL.  The environment variable SASSD_SPCONV_DEBUG (read once by the Python
- * binding at load time) sets the same word for an unmodified test / bench command. */
-void sassd_debug_set_spconv(int flags);
+/* Kernel selection is PER CALL (round 6; rounds 1-5 had process-wide sassd_debug_set_* switches, which a hipGraph capture
+ * could bake in by accident): the sparse-conv and Winograd entry points take an `int cfg`, 0 in production.
+ *   sparse conv (sassd_spconv_fwd / _bwd_data / _bwd_weight)   low 16 bits = ablation flags (tools/ablate_spconv.py): bit2 no
+ *     MFMA, bit5 every gather reads row 0 (weight gradient: the tile-per-wave formulation), bit6 one weight image for every
+ *     offset (bits 5 / 6 keep the number of loads in flight unchanged), bit8 the register-stationary kernel everywhere.
+ *     Bits 16+: workgroup geometry -- 0 the per-shape, per-capacity default; 1 / 5 = spconv_gs_kernel on 4 / 8 waves, 8 / 9 =
+ *     the balanced kernel spconv_gq_kernel with 4x4x1 quads / 16x16x4 tiles (the four the default picks from), 10 = the
+ *     round-3 default (1 or 5 by capacity) for every layer; any other value returns SASSD_EINVAL.
+ *   Winograd (sassd_conv2d_wino4_fwd / _chain, sassd_conv1x1_gemm_fwd)   bits 0-7 = GEMM geometry: 0 split operands on the
+ *     bf16 MFMA, 128 x 128 workgroups (default); 1 = the fp32 MFMA (v_mfma_f32_32x32x2_f32) at its picked width; 2..6 = fp32
+ *     MFMA with 32 cfg tile columns; 11..14 = split with other workgroup shapes.  Bits 8+: bit0 stage only the first chunk,
+ *     bit1 no MFMA (fp32 geometries), bit2 no split arithmetic, bits 4 / 5 / 6 / 7 skip the input transform / GEMM / output
+ *     transform / fused transform (per-kernel timing on live buffers, bench.py).  Chained calls must agree on the geometry.
+ * The Python binding reads SASSD_SPCONV_DEBUG / SASSD_WINO4_CFG once as the DEFAULT cfg its wrappers pass. */
 
 /* hipGraph capture of a launch sequence issued through this ABI (the reference has no counterpart: its frame is
  * ~10^2 host-issued launches with >= 6 host syncs).  begin -> any sassd_* calls on `stream` (streams
@@ -120,18 +126,24 @@ int sassd_rulebook_pairs(const int32_t *nbr, const int32_t *n_out_ptr, int cap_o
 
 /* Fused rulebook PYRAMID: all gather tables of a stack of `levels` resolutions (level l: SubMConv3d k=3 rulebook,
  * indice_key "subm<l>"; l-1 -> l: SparseConv3d(k=3,s=2,p=1) rulebook + output coordinates) -- the seven
- * get_indice_pairs calls of VxNet (cmn.py:147-173, 197-206) in 11 kernel launches instead of 30.
+ * get_indice_pairs calls of VxNet (cmn.py:147-173, 197-206) in one fill + 2 launches per level (9 for VxNet; the
+ * per-op chain above takes 30), or in one fill + ONE persistent launch (flags).
  *   indices[l]  [caps[l],4] i32 (b,z,y,x): level 0 is the input, levels >= 1 are written (ascending linear order)
  *   n_ptrs[l]   device int32 row counts: level 0 is the input, levels >= 1 are written
  *   D,H,W       spatial shape of level 0; level l+1 = (dim-1)/2+1 per axis
  *   nbr_subm[l] [caps[l],27] or NULL;  nbr_down[l] (l >= 1) [caps[l],27]: strided table from level l-1 into level l
  *   level_begin/level_end   build levels [begin, end) only (a caller that overlaps the tables with the convolutions
  *               issues one call per level and records an event after each); begin = 0 also resets the workspace.
+ *   flags       SASSD_PYRAMID_PERSISTENT: all phases in ONE launch separated by agent-scope grid barriers (needs
+ *               level_begin = 0, level_end = levels; bits 8..15 = workgroups per compute unit, 0 = default 2, max 4;
+ *               a barrier that times out sets SASSD_ST_GRID_SYNC).  Per call, no process-wide state.
+ *   workspace   16-byte aligned (cleared by 16-byte stores).
  * All pointer arrays are HOST arrays of device pointers. */
+#define SASSD_PYRAMID_PERSISTENT 1
 size_t sassd_rulebook_pyramid_workspace_bytes(int levels, const int *caps, int D, int H, int W, int batch_size);
 int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32_t *const *n_ptrs, const int *caps,
                            int D, int H, int W, int batch_size, int32_t *const *nbr_subm,
-                           int32_t *const *nbr_down, int level_begin, int level_end, int32_t *status,
+                           int32_t *const *nbr_down, int level_begin, int level_end, int flags, int32_t *status,
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -148,7 +160,7 @@ size_t sassd_spconv_packed_floats(int K, int Cin, int Cout);
 int sassd_spconv_pack_weight(const float *w, int K, int Cin, int Cout, float *packed, void *stream);
 int sassd_spconv_fwd(const float *x, const int32_t *nbr, const int32_t *n_out_ptr, int cap_out,
                      const float *w_packed, int K, int Cin, int Cout, const float *scale,
-                     const float *shift, int relu, float *y, void *stream);
+                     const float *shift, int relu, float *y, int cfg, void *stream);
 
 /* (a15) Sparse convolution backward (training; replaces spconv `indice_conv_backward_fp32`).
  *   sassd_rulebook_transpose   nbrT[i,k] = o  for every rulebook entry nbr[o,k] = i  (-1 elsewhere); nbrT [cap_in,27]
@@ -162,10 +174,10 @@ int sassd_rulebook_transpose(const int32_t *nbr, const int32_t *n_out_ptr, int c
                              int cap_in, void *stream);
 int sassd_spconv_pack_weight_t(const float *w, int K, int Cin, int Cout, float *packed, void *stream);
 int sassd_spconv_bwd_data(const float *dy, const int32_t *nbrT, const int32_t *n_in_ptr, int cap_in,
-                          const float *wT_packed, int K, int Cin, int Cout, float *dx, void *stream);
+                          const float *wT_packed, int K, int Cin, int Cout, float *dx, int cfg, void *stream);
 size_t sassd_spconv_bwd_weight_workspace_bytes(int cap_out, int K, int Cin, int Cout);
 int sassd_spconv_bwd_weight(const float *x, const float *dy, const int32_t *nbr, const int32_t *n_out_ptr,
-                            int cap_out, int K, int Cin, int Cout, float *dw, int accumulate,
+                            int cap_out, int K, int Cin, int Cout, float *dw, int accumulate, int cfg,
                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* (a8) SparseConvTensor.dense() + view (cmn.py:112-114): out [B, C*D, H, W] f32, zero filled here.
@@ -204,18 +216,11 @@ int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, const float *sc
  * cycles); tensors, packed weights and workspace stay fp32.  Needs Cin % 32 == 0, Cout % 256 == 0, H % 4 == 0,
  * W % 4 == 0 and a caller workspace (transformed input + product tensors, 36 planes each). */
 int sassd_conv2d_wino4_supported(int Cin, int Cout, int H, int W);
-/* GEMM geometry / ablation switches (tools/run_wino4.py, bench.py --wino4-cfg).  cfg 0 = split operands on the bf16 MFMA,
- * 128 x 128 workgroups (default); 1 = the fp32 MFMA (v_mfma_f32_32x32x2_f32) at its picked width -- the kernel of rounds 2-3,
- * kept for the A/B; 2..6 = fp32 MFMA with 32 cfg tile columns; 11..14 = split with other workgroup shapes.  dbg: bit 0
- * stage only the first chunk, bit 1 no MFMA (fp32 geometries), bit 2 no split arithmetic (split geometries), bits 4 / 5 /
- * 6 / 7 skip the input transform / GEMM / output transform / fused transform.  Process-wide, not thread-safe: set it
- * before building plans or capturing graphs. */
-void sassd_debug_set_wino4(int cfg, int dbg);
 size_t sassd_conv2d_wino4_packed_floats(int Cin, int Cout);
 int sassd_conv2d_wino4_pack_weight(const float *w /*[Cout,Cin,3,3]*/, int Cout, int Cin, float *packed, void *stream);
 size_t sassd_conv2d_wino4_workspace_bytes(int batch, int Cin, int Cout, int H, int W);
 int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, const float *scale, const float *shift, int relu,
-                           float *y, int batch, int Cin, int Cout, int H, int W, void *workspace,
+                           float *y, int batch, int Cin, int Cout, int H, int W, int cfg, void *workspace,
                            size_t workspace_bytes, void *stream);
 
 /* Chained 3x3 layers with the activation map between them kept in the transform domain: one call = one layer,
@@ -234,7 +239,7 @@ int sassd_conv2d_wino4_chain_supported(int Cin, int Cout, int H, int W);
 size_t sassd_conv2d_wino4_chain_workspace_bytes(int batch, int cmax, int H, int W);
 int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev_scale, const float *prev_shift,
                              int prev_relu, const float *w_packed, const float *scale, const float *shift, int relu,
-                             float *y, int batch, int Cin, int Cout, int cmax, int H, int W, void *workspace,
+                             float *y, int batch, int Cin, int Cout, int cmax, int H, int W, int cfg, void *workspace,
                              size_t workspace_bytes, void *stream);
 
 /* 1x1 convolution with >= 128 output channels (BEVNet conv7, cmn.py:262) as a plain fp32-MFMA GEMM over the NCHW
@@ -244,7 +249,7 @@ int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev
 int sassd_conv1x1_gemm_supported(int Cin, int Cout, int H, int W);
 int sassd_conv1x1_gemm_pack_weight(const float *w /*[Cout,Cin,1,1]*/, int Cout, int Cin, float *packed, void *stream);
 int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *scale, const float *shift, int relu,
-                           float *y, int batch, int Cin, int Cout, int H, int W, void *stream);
+                           float *y, int batch, int Cin, int Cout, int H, int W, int cfg, void *stream);
 
 /* BASELINE configs[2] (bf16 training): the 3x3 pad-1 BEV convolutions (cmn.py:240-262) with bf16 MFMA operands --
  * direct implicit GEMM on v_mfma_f32_32x32x16_bf16, fp32 accumulation, NCHW fp32 activations in and out, optional

@@ -47,20 +47,19 @@ _SIGS = {
     "sassd_rulebook_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "sassd_rulebook_pairs": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "sassd_rulebook_pyramid_workspace_bytes": (_SZ, [_I, _P, _I, _I, _I, _I]),
-    "sassd_rulebook_pyramid": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "sassd_rulebook_pyramid": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P, _SZ, _P]),
     "sassd_graph_begin": (_I, [_P]),
     "sassd_graph_end": (_I, [_P, _P]),
     "sassd_graph_launch": (_I, [_P, _P]),
     "sassd_graph_destroy": (_I, [_P]),
-    "sassd_debug_set_spconv": (None, [_I]),
     "sassd_spconv_packed_floats": (_SZ, [_I, _I, _I]),
     "sassd_spconv_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
-    "sassd_spconv_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P]),
+    "sassd_spconv_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _I, _P]),
     "sassd_rulebook_transpose": (_I, [_P, _P, _I, _P, _I, _P]),
     "sassd_spconv_pack_weight_t": (_I, [_P, _I, _I, _I, _P, _P]),
-    "sassd_spconv_bwd_data": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
+    "sassd_spconv_bwd_data": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _I, _P]),
     "sassd_spconv_bwd_weight_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
-    "sassd_spconv_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _SZ, _P]),
+    "sassd_spconv_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _SZ, _P]),
     "sassd_densify": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "sassd_conv2d_packed_floats": (_SZ, [_I, _I, _I]),
     "sassd_conv2d_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
@@ -90,14 +89,13 @@ _SIGS = {
     "sassd_conv2d_wino_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv2d_wino_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_wino4_supported": (_I, [_I, _I, _I, _I]),
-    "sassd_debug_set_wino4": (None, [_I, _I]),
     "sassd_conv2d_wino4_packed_floats": (_SZ, [_I, _I]),
     "sassd_conv2d_wino4_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv2d_wino4_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
-    "sassd_conv2d_wino4_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "sassd_conv2d_wino4_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_conv1x1_gemm_supported": (_I, [_I, _I, _I, _I]),
     "sassd_conv1x1_gemm_pack_weight": (_I, [_P, _I, _I, _P, _P]),
-    "sassd_conv1x1_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "sassd_conv1x1_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_bf16_supported": (_I, [_I, _I, _I, _I]),
     "sassd_debug_set_bf16": (None, [_I]),
     "sassd_conv2d_bf16_packed_elems": (_SZ, [_I, _I]),
@@ -139,7 +137,7 @@ _SIGS = {
     "sassd_focal_loss": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "sassd_conv2d_wino4_chain_supported": (_I, [_I, _I, _I, _I]),
     "sassd_conv2d_wino4_chain_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
-    "sassd_conv2d_wino4_chain": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "sassd_conv2d_wino4_chain": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_gather_pack": (_I, [_P, _P, _P, C.c_long, _I, _P]),
     "sassd_grad_sumsq": (_I, [_P, C.c_long, _P, _P]),
     "sassd_adam_step": (_I, [_P, _P, _P, _P, C.c_long, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P]),
@@ -161,14 +159,6 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
-        # debugging aid (A/B of kernel geometries under an unmodified test / bench command): SASSD_SPCONV_DEBUG=<int> is
-        # handed to sassd_debug_set_spconv once, at load time (0 / unset in production)
-        flags = os.environ.get("SASSD_SPCONV_DEBUG")
-        if flags:
-            l.sassd_debug_set_spconv(int(flags, 0))
-        cfg = os.environ.get("SASSD_WINO4_CFG")          # likewise: the Winograd GEMM geometry (1 = the fp32 MFMA)
-        if cfg:
-            l.sassd_debug_set_wino4(int(cfg, 0), 0)
     return _lib
 
 

@@ -558,17 +558,21 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
     }
 }
 
-int g_wino4_cfg = 0, g_wino4_dbg = 0;
+// `cfg` of the Winograd entry points (0 in production): bits 0-7 = GEMM geometry (w4_tile), bits 8.. = ablation / stage-skip
+// flags (listed at w4_dbg below).  Rounds 2-5 kept both in process-wide ints behind sassd_debug_set_wino4; a per-call word
+// cannot be baked into a hipGraph by accident.
+inline int w4_geo(int cfg) { return cfg & 0xff; }
+inline int w4_dbg(int cfg) { return cfg >> 8; }
 
 template <int WM, int WN, int NB, int KC, int SPLIT = 0>
-int launch_w4_gemm(W4Gemm P, hipStream_t stream)
+int launch_w4_gemm(W4Gemm P, int dbg, hipStream_t stream)
 {
     constexpr int BM = 64 * WM, BN = 32 * NB * WN;
     static_assert(BM == kBM, "the channel block is fixed: w4_pick_wn and the supported() checks price it");
     constexpr size_t stage_b = (size_t)2 * (BM + BN) * KC * 4, img_b = (size_t)WM * WN * 64 * 32 * NB * 4;
     constexpr size_t lds = stage_b > img_b ? stage_b : img_b;        // the epilogue image reuses the staging buffers
     if constexpr (SPLIT == 1)
-        if (g_wino4_dbg & 4) return launch_w4_gemm<WM, WN, NB, KC, 2>(P, stream);      // ablation instance
+        if (dbg & 4) return launch_w4_gemm<WM, WN, NB, KC, 2>(P, dbg, stream);      // ablation instance
     static std::atomic<unsigned long long> attr_done{0};
     const void *fn = (const void *)wino4_gemm_kernel<WM, WN, NB, KC, SPLIT>;
     int rc = sassd_dyn_lds(fn, lds, attr_done);
@@ -580,7 +584,7 @@ int launch_w4_gemm(W4Gemm P, hipStream_t stream)
     if (P.nseg > P.nnb) P.nseg = P.nnb;
     P.seglen = cdiv(P.nnb, P.nseg);
     P.pairs_per_xcd = cdiv(pairs * P.nseg, 8);
-    P.dbg = g_wino4_dbg;
+    P.dbg = dbg;
     hipLaunchKernelGGL((wino4_gemm_kernel<WM, WN, NB, KC, SPLIT>), dim3(8 * P.pairs_per_xcd * P.seglen), dim3(WM * WN * 64),
                        lds, stream, P);
     return sassd_launch_status();
@@ -610,16 +614,16 @@ inline int w4_pick_wn(int T, int Cout, int np = 36, bool exact = false)
 
 // Geometry of the Winograd GEMM launch.  Default: fp32 products on the bf16 MFMA over split operands, 128 channels x 128
 // tiles per workgroup, four waves of 64 x 64 (measured at 2200 tiles: 142 us per 256 -> 256 layer with its two transform
-// launches against 157 for the best fp32-MFMA geometry; 64 columns 160, 192 columns 170).  g_wino4_cfg: 0 = default, 1 = the
+// launches against 157 for the best fp32-MFMA geometry; 64 columns 160, 192 columns 170).  geometry (cfg bits 0-7): 0 = default, 1 = the
 // fp32 MFMA at its picked width (the round-3 default), 2..6 = the fp32 MFMA with 32 cfg columns, 11..13 = split with
 // 64 (cfg - 10) columns, 14 = split, 128 columns, 16-channel chunks.
 struct W4Tile {
     int split, wn, nb, kc;
     int bn() const { return 32 * nb * wn; }
 };
-inline W4Tile w4_tile(int T, int Cout)
+inline W4Tile w4_tile(int T, int Cout, int geo)
 {
-    const int c = g_wino4_cfg;
+    const int c = geo;
     if (c >= 2 && c <= 6) return W4Tile{0, c, 1, kKC};
     if (c >= 11 && c <= 13) return W4Tile{1, c - 10, 2, kKC};
     if (c == 14) return W4Tile{1, 2, 2, 16};
@@ -627,40 +631,37 @@ inline W4Tile w4_tile(int T, int Cout)
     return W4Tile{1, 2, 2, kKC};
 }
 
-inline int w4_tiles_padded(int B, int H, int W, int Cout)
+inline int w4_tiles_padded(int B, int H, int W, int Cout, int geo)
 {
     const int T = B * (H / 4) * (W / 4);
-    const int bn = w4_tile(T, Cout).bn();
+    const int bn = w4_tile(T, Cout, geo).bn();
     return cdiv(T, bn) * bn;
 }
 
-inline int w4_launch(const W4Tile t, const W4Gemm &P, hipStream_t stream)
+inline int w4_launch(const W4Tile t, const W4Gemm &P, int dbg, hipStream_t stream)
 {
     if (t.split) {
-        if (t.kc == 16) return launch_w4_gemm<2, 2, 2, 16, 1>(P, stream);
+        if (t.kc == 16) return launch_w4_gemm<2, 2, 2, 16, 1>(P, dbg, stream);
         switch (t.wn) {
-        case 1: return launch_w4_gemm<2, 1, 2, kKC, 1>(P, stream);
-        case 2: return launch_w4_gemm<2, 2, 2, kKC, 1>(P, stream);
-        default: return launch_w4_gemm<2, 3, 2, kKC, 1>(P, stream);
+        case 1: return launch_w4_gemm<2, 1, 2, kKC, 1>(P, dbg, stream);
+        case 2: return launch_w4_gemm<2, 2, 2, kKC, 1>(P, dbg, stream);
+        default: return launch_w4_gemm<2, 3, 2, kKC, 1>(P, dbg, stream);
         }
     }
     switch (t.wn) {                                                      // 128 channels x 32 WN tiles, 2 x WN waves of 64 x 32
-    case 2: return launch_w4_gemm<2, 2, 1, kKC>(P, stream);
-    case 3: return launch_w4_gemm<2, 3, 1, kKC>(P, stream);
-    case 4: return launch_w4_gemm<2, 4, 1, kKC>(P, stream);
-    case 5: return launch_w4_gemm<2, 5, 1, kKC>(P, stream);
-    default: return launch_w4_gemm<2, 6, 1, kKC>(P, stream);
+    case 2: return launch_w4_gemm<2, 2, 1, kKC>(P, dbg, stream);
+    case 3: return launch_w4_gemm<2, 3, 1, kKC>(P, dbg, stream);
+    case 4: return launch_w4_gemm<2, 4, 1, kKC>(P, dbg, stream);
+    case 5: return launch_w4_gemm<2, 5, 1, kKC>(P, dbg, stream);
+    default: return launch_w4_gemm<2, 6, 1, kKC>(P, dbg, stream);
     }
 }
 
 }  // namespace
 
-// ablation / geometry switches of the F(4x4) GEMM (tools/run_wino4.py): cfg as listed at w4_tile (0 = split operands on the
-// bf16 MFMA, 1 = the fp32 MFMA, ...); dbg bit0 stage only the first chunk, bit1 no MFMA (fp32-MFMA geometries), bit2 no
-// split arithmetic (split geometries), bits 4 / 5 / 6 skip the input transform / the GEMM / the output transform (per-kernel
-// timing on live buffers, bench.py)
-extern "C" void sassd_debug_set_wino4(int cfg, int dbg) { g_wino4_cfg = cfg; g_wino4_dbg = dbg; }
-
+// cfg bits 8.. (ablation, tools/run_wino4.py; per-kernel timing on live buffers, bench.py): bit0 stage only the first chunk,
+// bit1 no MFMA (fp32-MFMA geometries), bit2 no split arithmetic (split geometries), bits 4 / 5 / 6 / 7 skip the input transform /
+// the GEMM / the output transform / the fused output -> input transform
 extern "C" int sassd_conv2d_wino4_supported(int Cin, int Cout, int H, int W)
 {
     return (Cin >= kKC && Cin % kKC == 0 && Cout >= 256 && Cout % 256 == 0 && H >= 4 && H % 4 == 0 && W >= 4 && W % 4 == 0)
@@ -690,33 +691,34 @@ extern "C" size_t sassd_conv2d_wino4_workspace_bytes(int batch, int Cin, int Cou
 }
 
 extern "C" int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, const float *scale, const float *shift,
-                                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, void *workspace,
-                                      size_t workspace_bytes, void *stream_)
+                                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, int cfg,
+                                      void *workspace, size_t workspace_bytes, void *stream_)
 {
     if (!x || !w_packed || !y || !workspace || batch < 1 || !sassd_conv2d_wino4_supported(Cin, Cout, H, W))
         return SASSD_EINVAL;
+    const int geo = w4_geo(cfg), dbg = w4_dbg(cfg);
     if (((uintptr_t)y & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)workspace & 15)) return SASSD_EINVAL;
     if (workspace_bytes < sassd_conv2d_wino4_workspace_bytes(batch, Cin, Cout, H, W)) return SASSD_ENOSPC;
     hipStream_t stream = (hipStream_t)stream_;
     W4Geom G;
     G.B = batch; G.C = Cin; G.H = H; G.W = W; G.TH = H / 4; G.TW = W / 4; G.T = batch * G.TH * G.TW;
-    G.Tp = w4_tiles_padded(batch, H, W, Cout);
+    G.Tp = w4_tiles_padded(batch, H, W, Cout, geo);
     float *V = (float *)workspace;
     float *M = (float *)((char *)workspace + align_up(36 * (size_t)Cin * G.Tp * 4, 256));
     // the padding columns of V feed padding columns of M that the output transform never reads; they only have to be
     // finite-or-not-read: the GEMM's columns are independent, so stale values cannot leak into real tiles
-    if (!(g_wino4_dbg & 16))
+    if (!(dbg & 16))
         hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V);
     W4Gemm P;
     P.U = w_packed; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0;
     P.np = 36; P.Cin = Cin; P.Cout = Cout; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;
     P.su = (size_t)Cin * Cout; P.sv = (size_t)Cin * G.Tp; P.sm = (size_t)Cout * G.Tp;
     int rc = SASSD_OK;
-    if (!(g_wino4_dbg & 32)) rc = w4_launch(w4_tile(G.T, Cout), P, stream);
+    if (!(dbg & 32)) rc = w4_launch(w4_tile(G.T, Cout, geo), P, dbg, stream);
     if (rc) return rc;
     W4Geom Go = G;
     Go.C = Cout;
-    if (!(g_wino4_dbg & 64))
+    if (!(dbg & 64))
         hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
                            scale, shift, relu, y);
     return sassd_launch_status();
@@ -744,9 +746,10 @@ extern "C" size_t sassd_conv2d_wino4_chain_workspace_bytes(int batch, int cmax, 
 extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev_scale,
                                         const float *prev_shift, int prev_relu, const float *w_packed,
                                         const float *scale, const float *shift, int relu, float *y, int batch, int Cin,
-                                        int Cout, int cmax, int H, int W, void *workspace, size_t workspace_bytes,
-                                        void *stream_)
+                                        int Cout, int cmax, int H, int W, int cfg, void *workspace,
+                                        size_t workspace_bytes, void *stream_)
 {
+    const int geo = w4_geo(cfg), dbg = w4_dbg(cfg);
     if (!w_packed || !workspace || batch < 1 || !sassd_conv2d_wino4_supported(Cin, Cout, H, W) || cmax < Cin ||
         cmax < Cout || (!src_products && !x))
         return SASSD_EINVAL;
@@ -757,17 +760,17 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
     hipStream_t stream = (hipStream_t)stream_;
     W4Geom G;
     G.B = batch; G.C = Cin; G.H = H; G.W = W; G.TH = H / 4; G.TW = W / 4; G.T = batch * G.TH * G.TW;
-    G.Tp = w4_tiles_padded(batch, H, W, Cout);
+    G.Tp = w4_tiles_padded(batch, H, W, Cout, geo);
     // src_products: the previous call (its Cout = this Cin) left M [36][Cin][Tp'] with Tp' padded for ITS column-block
     // width.  The fused transform reads M and writes V with one plane stride: both layers must agree on it (ADVICE r03;
     // every chained SA-SSD layer is 256 -> 256, so they do) -- a mismatch is refused instead of read as garbage.
-    if (src_products && w4_tiles_padded(batch, H, W, Cin) != G.Tp) return SASSD_EINVAL;
+    if (src_products && w4_tiles_padded(batch, H, W, Cin, geo) != G.Tp) return SASSD_EINVAL;
     float *V = (float *)workspace;
     float *M = (float *)((char *)workspace + need / 2);
     if (!src_products) {
-        if (!(g_wino4_dbg & 16))
+        if (!(dbg & 16))
             hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V);
-    } else if (!(g_wino4_dbg & 128)) {
+    } else if (!(dbg & 128)) {
         // the previous call left M [36][Cin][Tp] (its Cout = this Cin, same tile geometry) in the workspace
         static std::atomic<unsigned long long> attr_done{0};
         const size_t lds = w4_plane_bytes(H, W);
@@ -781,9 +784,9 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
     P.np = 36; P.Cin = Cin; P.Cout = Cout; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;
     P.su = (size_t)Cin * Cout; P.sv = (size_t)Cin * G.Tp; P.sm = (size_t)Cout * G.Tp;
     int rc = SASSD_OK;
-    if (!(g_wino4_dbg & 32)) rc = w4_launch(w4_tile(G.T, Cout), P, stream);
+    if (!(dbg & 32)) rc = w4_launch(w4_tile(G.T, Cout, geo), P, dbg, stream);
     if (rc) return rc;
-    if (y && !(g_wino4_dbg & 64)) {
+    if (y && !(dbg & 64)) {
         W4Geom Go = G;
         Go.C = Cout;
         hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
@@ -819,9 +822,11 @@ extern "C" int sassd_conv1x1_gemm_pack_weight(const float *w, int Cout, int Cin,
 }
 
 extern "C" int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *scale, const float *shift,
-                                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, void *stream_)
+                                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, int cfg,
+                                      void *stream_)
 {
     if (!x || !w_packed || !y || batch < 1 || !sassd_conv1x1_gemm_supported(Cin, Cout, H, W)) return SASSD_EINVAL;
+    const int geo = w4_geo(cfg), dbg = w4_dbg(cfg);
     if (((uintptr_t)y & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)x & 15)) return SASSD_EINVAL;
     const int hw = H * W;
     W4Gemm P;
@@ -829,13 +834,13 @@ extern "C" int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, con
     P.np = batch; P.Cin = Cin; P.Cout = Cout; P.ldv = hw; P.ldm = hw; P.ncols = hw;
     P.su = 0; P.sv = (size_t)Cin * hw; P.sm = (size_t)Cout * hw;
     hipStream_t stream = (hipStream_t)stream_;
-    if (g_wino4_cfg != 1 && hw % 128 == 0) return launch_w4_gemm<2, 2, 2, kKC, 1>(P, stream);     // split operands, as above
+    if (geo != 1 && hw % 128 == 0) return launch_w4_gemm<2, 2, 2, kKC, 1>(P, dbg, stream);     // split operands, as above
     switch (w4_pick_wn(hw, Cout, batch, true)) {
-    case 2: return launch_w4_gemm<2, 2, 1, kKC>(P, stream);
-    case 3: return launch_w4_gemm<2, 3, 1, kKC>(P, stream);
-    case 4: return launch_w4_gemm<2, 4, 1, kKC>(P, stream);
-    case 5: return launch_w4_gemm<2, 5, 1, kKC>(P, stream);
-    case 6: return launch_w4_gemm<2, 6, 1, kKC>(P, stream);
+    case 2: return launch_w4_gemm<2, 2, 1, kKC>(P, dbg, stream);
+    case 3: return launch_w4_gemm<2, 3, 1, kKC>(P, dbg, stream);
+    case 4: return launch_w4_gemm<2, 4, 1, kKC>(P, dbg, stream);
+    case 5: return launch_w4_gemm<2, 5, 1, kKC>(P, dbg, stream);
+    case 6: return launch_w4_gemm<2, 6, 1, kKC>(P, dbg, stream);
     }
     return SASSD_EINVAL;
 }

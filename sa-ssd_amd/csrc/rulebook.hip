@@ -10,6 +10,7 @@
 //   * the rulebook is an output-stationary gather table nbr[row_out][27] (one coalesced 108-B record per row).
 // Algorithmic HBM bytes: subm 16*Nin + 8*P ; strided 16*Nin + 16*Nout + 8*P.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -190,51 +191,34 @@ inline bool lin_fits(int D, int H, int W, int B) { return (double)D * H * W * B 
 
 // ------------------------------------------------------------------------------------------------------------------
 // Fused rulebook pyramid: every gather table of a submanifold / strided-conv stack (level l: SubMConv3d rulebook;
-// l -> l+1: SparseConv3d(k3,s2,p1) rulebook + the output coordinates) in 2 + 3*(L-1) launches and two memsets
-// (11 kernel launches instead of 30 for the four VxNet levels of cmn.py:147-173).
+// l -> l+1: SparseConv3d(k3,s2,p1) rulebook + the output coordinates), cmn.py:147-173.
 //   coordinate -> row lookup   level 0 (voxelizer rows, first-touch order): the open-addressing hash.  Levels >= 1
 //                     are emitted in ascending linear order, so their occupancy BITMAP plus a per-word rank array is a
 //                     perfect index: row(c) = rank[c >> 5] + popcount(bitmap[c >> 5] below bit c) -- two independent
-//                     loads, no probing, no inserts (hash inserts from the emit kernel were a chain of dependent
-//                     atomic round trips per thread: 50-110 us per level).
-//   rb_level_kernel   one thread per (row of level l, (kz, ky)): three x-offsets at a time of the subm table of level l
-//                     and of the strided table INTO level l (lookup in level l-1; the three cells share a bitmap word 15
-//                     times out of 16) and -- threads g < 8 -- the marks of the row's <= 8 strided outputs in the bitmap
-//                     of level l+1.  All three only read finished structures.
-//   rb_count_kernel   set bits per 256-word bitmap block + per 64-block super-block.
-//   rb_emit_kernel    ordered compaction of the bitmap: every workgroup sums the (super-)counters before it (a few
-//                     hundred L2-resident ints; no single-workgroup scan pass and no inter-workgroup waiting -- a
-//                     chained single-pass scan with tagged words measured 70-150 us here), writes the rank array and
-//                     emits its coordinates in ascending linear order: one word per thread, the word's first cell
-//                     decomposed once, its <= 32 set bits walked with carries.
+//                     loads, no probing, no inserts.
+// Phases (one launch each; a phase only reads what earlier phases finished):
+//   A0     hash insert of level 0's rows  ||  marks of level 1's occupied cells
+//   C(l)   l >= 1: the marks of level l -> bitmap words + set bits per 256-word block and 64-block super-block
+//          (|| at l = 1: the submanifold table of level 0, which needs the hash only)
+//   E(l)   ordered emit of level l: every block sums the (super-)counters before it (a few hundred L2-resident ints, no
+//          single-workgroup scan, no waiting), writes the rank array, the coordinates in ascending linear order, the row count
+//   T(l)   one thread per (row, (kz, ky)): three x-offsets at a time of the submanifold table of level l and of the strided
+//          table INTO level l (the three cells share a bitmap word 15 times out of 16)  ||  marks of level l+1
+// Round 6: the marks are PLAIN BYTE STORES into a byte-per-cell map (all writers of a cell store the same 1: no atomic).
+// Rounds 2-5 marked bits with atomicOr: 54-146 k device-scope atomics per level were 8-15 us of each level's 12-20 us kernel
+// (the level without marks took 4.5 us); the byte map costs its clear + one read (13.5 MB per KITTI frame, ~ 6 us at HBM
+// speed, inside the one fill launch and C(l)).  A first round-6 form that fused E(l) with the tables of the rows each block
+// emits (2 launches per level) measured 3.4x SLOWER: occupied cells cluster, so a few blocks carried hundreds of rows x 27
+// dependent lookups (profiles/r06_pyramid_forms.txt); the row-parallel T(l) stays.
+// flags bit 0: ONE persistent launch that walks the phases with agent-scope grid barriers (release fence -> arrival counters
+// sharded by blockIdx % 8 -> generation word -> acquire fence; MI355X_MICROARCH.md, inter-workgroup visibility) instead of
+// one launch per phase -- built for the A/B the round-5 verdict asked for; slower than the launches (same file).
 // ------------------------------------------------------------------------------------------------------------------
 struct Lookup {
     const unsigned *bitmap;    // nullptr -> hash
     const int *rank;
     HashView hv;
     int cap;                   // rows past the level's capacity do not exist
-};
-
-__device__ __forceinline__ int lookup_row(const Lookup &L, unsigned key)
-{
-    if (L.bitmap) {
-        const unsigned w = L.bitmap[key >> 5], b = 1u << (key & 31);
-        if (!(w & b)) return -1;
-        const int r = L.rank[key >> 5] + __popc(w & (b - 1));
-        return r < L.cap ? r : -1;
-    }
-    return hash2_lookup(L.hv.ent, L.hv.mask, key);
-}
-
-struct LevelArgs {
-    const int32_t *idx; const int32_t *n_ptr; int cap; int D, H, W;
-    Lookup cur;                // this level's index (complete)
-    int32_t *nbr_subm;         // [cap,27] or nullptr
-    Lookup prev;               // previous (finer) level's index
-    int pD, pH, pW;            // previous level's dims
-    int32_t *nbr_down;         // [cap,27] strided table into this level, or nullptr
-    unsigned *bitmap_next;     // marks of level l+1's outputs, or nullptr
-    int OD, OH, OW;
 };
 
 // three lookups along x (keys base + x0 .. base + x0 + 2, columns outside [0, W) = no voxel) in one go: with the bitmap
@@ -273,110 +257,242 @@ __device__ __forceinline__ void lookup3(const Lookup &L, unsigned base, int x0, 
     }
 }
 
-// one thread per (row of level l, (kz, ky)): the three x-offsets of the subm table of level l and of the strided table
-// INTO level l, and -- threads g < 8 -- the marks of the row's <= 8 strided outputs in the bitmap of level l+1
-__global__ void __launch_bounds__(256) rb_level_kernel(LevelArgs A)
-{
-    const int n = min(*A.n_ptr, A.cap);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * 9) return;
-    const int row = t / 9, g = t - row * 9;
-    const int4 c = ((const int4 *)A.idx)[row];
-    const int kz = g / 3, ky = g - kz * 3;
-    if (A.nbr_subm) {
-        const int z = c.y + kz - 1, y = c.z + ky - 1;
-        int r[3] = {-1, -1, -1};
-        if (z >= 0 && z < A.D && y >= 0 && y < A.H)
-            lookup3(A.cur, (((unsigned)c.x * A.D + z) * A.H + y) * A.W, c.w - 1, A.W, r);
-        if (g == 4) r[1] = row;                              // the centre offset (k = 13) is the row itself
-        int32_t *dst = A.nbr_subm + (size_t)row * 27 + g * 3;
-        dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2];
-    }
-    if (A.nbr_down) {
-        const int z = 2 * c.y - 1 + kz, y = 2 * c.z - 1 + ky;
-        int r[3] = {-1, -1, -1};
-        if (z >= 0 && z < A.pD && y >= 0 && y < A.pH)
-            lookup3(A.prev, (((unsigned)c.x * A.pD + z) * A.pH + y) * A.pW, 2 * c.w - 1, A.pW, r);
-        int32_t *dst = A.nbr_down + (size_t)row * 27 + g * 3;
-        dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2];
-    }
-    if (A.bitmap_next && g < 8) {
-        int oz[2], oy[2], ox[2];
-        const int nz = axis_outs(c.y, A.OD, oz), ny = axis_outs(c.z, A.OH, oy), nx = axis_outs(c.w, A.OW, ox);
-        const int a = g & 1, b = (g >> 1) & 1, e = g >> 2;
-        if (a < nz && b < ny && e < nx) {
-            const unsigned lin = (((unsigned)c.x * A.OD + oz[a]) * A.OH + oy[b]) * A.OW + ox[e];
-            atomicOr(&A.bitmap_next[lin >> 5], 1u << (lin & 31));
-        }
-    }
-}
-
-constexpr int kEmitWords = 256;          // bitmap words per workgroup of the pyramid's count / emit kernels (1 / thread)
+constexpr int kEmitWords = 256;          // bitmap words per virtual block of the count / emit phases (1 / thread)
 constexpr int kSupShift = 6;             // super-counter = 64 blocks
-
-__global__ void __launch_bounds__(256) rb_count_kernel(const unsigned *__restrict__ bitmap, int nwords,
-                                                       int *__restrict__ bcnt, int *__restrict__ sup)
-{
-    __shared__ int wsum[17];
-    const int i = blockIdx.x * kEmitWords + threadIdx.x;
-    const int s = i < nwords ? __popc(bitmap[i]) : 0;
-    int tot;
-    block_exclusive_scan(s, wsum, &tot);
-    if (threadIdx.x == 0) {
-        bcnt[blockIdx.x] = tot;
-        if (tot) atomicAdd(&sup[blockIdx.x >> kSupShift], tot);
-    }
-}
-
-__global__ void __launch_bounds__(256) rb_emit_kernel(const unsigned *__restrict__ bitmap, int nwords, int nblk,
-                                                      const int *__restrict__ bcnt, const int *__restrict__ sup,
-                                                      int *__restrict__ rank, int OD, int OH, int OW, int cap_out,
-                                                      int32_t *__restrict__ out_idx, int32_t *n_out_ptr,
-                                                      int32_t *status)
-{
-    __shared__ int wsum[17];
-    const int blk = blockIdx.x;
-    // rows emitted before this block = whole super-blocks + the blocks of its own super-block before it
-    const int nsup = blk >> kSupShift;
-    int part = 0;
-    for (int j = threadIdx.x; j < nsup; j += 256) part += sup[j];
-    if ((int)threadIdx.x < blk - (nsup << kSupShift)) part += bcnt[(nsup << kSupShift) + threadIdx.x];
-    int before;
-    block_exclusive_scan(part, wsum, &before);
-    const int wi = blk * kEmitWords + threadIdx.x;
-    unsigned m = wi < nwords ? bitmap[wi] : 0u;
-    int tot;
-    const int ex = block_exclusive_scan(__popc(m), wsum, &tot);
-    int row = before + ex;
-    if (wi < nwords) rank[wi] = row;                  // rank of a word = set bits before it
-    if (blk == nblk - 1 && threadIdx.x == 0) {
-        int total = before + tot;
-        if (total > cap_out) { if (status) atomicOr(status, SASSD_ST_VOXEL_OVERFLOW); total = cap_out; }
-        *n_out_ptr = total;
-    }
-    if (!m) return;
-    // coordinates of the word's first cell once (three divisions), then walk the <= 32 set bits with carries
-    unsigned lin = (unsigned)wi * 32u;
-    int x = lin % OW; lin /= OW;
-    int y = lin % OH; lin /= OH;
-    int z = lin % OD; lin /= OD;
-    int b = (int)lin, prev = 0;
-    while (m) {
-        const int bit = __ffs(m) - 1;
-        m &= m - 1;
-        x += bit - prev; prev = bit;
-        while (x >= OW) { x -= OW; if (++y == OH) { y = 0; if (++z == OD) { z = 0; ++b; } } }
-        if (row < cap_out) ((int4 *)out_idx)[row] = make_int4(b, z, y, x);
-        ++row;
-    }
-}
-
 constexpr int kMaxLevels = 8;
+constexpr int kBarWords = 64;            // grid-barrier state: 8 arrival shards (16-byte apart) + top + generation + abort
+
+struct PyrLevel {
+    int32_t *idx;              // [cap,4] coordinates (level 0: input)
+    int32_t *n_ptr;            // row count (level 0: input)
+    int cap, D, H, W;
+    Lookup look;               // this level's coordinate -> row index (level 0: hash)
+    int32_t *nbr_subm;         // [cap,27] or nullptr
+    int32_t *nbr_down;         // [cap,27] strided table into this level (l >= 1)
+    unsigned char *cells;      // l >= 1: byte per cell (32 * nwords bytes), marked by level l-1
+    unsigned *bitmap;          // l >= 1: occupancy bitmap of this level (= look.bitmap), written by C(l)
+    int *rank, *bcnt, *sup;
+    int nwords, nblk;
+};
+struct PyrArgs {
+    PyrLevel L[kMaxLevels];
+    int levels;
+    int32_t *status;
+    unsigned *bar;             // kBarWords zeroed words (persistent form)
+};
+
+// a row count that another phase of the SAME launch may have written: never through the scalar cache
+__device__ __forceinline__ int pyr_rows(const PyrLevel &V)
+{
+    const int n = __hip_atomic_load(V.n_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return min(n, V.cap);
+}
+
+// mark of one of the <= 8 strided outputs of the voxel c in the cell map of the next level; g in [0, 8) picks the candidate
+__device__ __forceinline__ void mark_next(const int4 c, int g, const PyrLevel &N)
+{
+    int oz[2], oy[2], ox[2];
+    const int nz = axis_outs(c.y, N.D, oz), ny = axis_outs(c.z, N.H, oy), nx = axis_outs(c.w, N.W, ox);
+    const int a = g & 1, b = (g >> 1) & 1, e = g >> 2;
+    if (a < nz && b < ny && e < nx) {
+        const unsigned lin = (((unsigned)c.x * N.D + oz[a]) * N.H + oy[b]) * N.W + ox[e];
+        N.cells[lin] = 1;                                  // every writer stores the same value: no atomic needed
+    }
+}
+
+enum { PH_A0 = 0, PH_C = 1, PH_E = 2, PH_T = 3 };           // phase id = 1 + 3 * (l - 1) + {0: C, 1: E, 2: T} for l >= 1; 0 = A0
+__device__ __host__ inline int pyr_phase_kind(int ph) { return ph == 0 ? PH_A0 : 1 + (ph - 1) % 3; }
+__device__ __host__ inline int pyr_phase_level(int ph) { return ph == 0 ? 0 : 1 + (ph - 1) / 3; }
+
+__device__ __host__ inline int pyr_phase_blocks(const PyrArgs &A, int ph)
+{
+    const int l = pyr_phase_level(ph);
+    switch (pyr_phase_kind(ph)) {
+    case PH_A0: return (A.L[0].cap * 9 + 255) / 256;
+    case PH_C:  return A.L[l].nblk + ((l == 1 && A.L[0].nbr_subm) ? (A.L[0].cap * 9 + 255) / 256 : 0);
+    case PH_E:  return A.L[l].nblk;
+    default:    return (A.L[l].cap * 9 + 255) / 256;
+    }
+}
+
+// submanifold table of level l (lookups in its own finished index), thread (row, g = (kz, ky))
+__device__ __forceinline__ void subm_rows(const PyrLevel &V, int row, int g, const int4 c)
+{
+    const int kz = g / 3, ky = g - kz * 3;
+    const int z = c.y + kz - 1, y = c.z + ky - 1;
+    int r[3] = {-1, -1, -1};
+    if (z >= 0 && z < V.D && y >= 0 && y < V.H)
+        lookup3(V.look, (((unsigned)c.x * V.D + z) * V.H + y) * V.W, c.w - 1, V.W, r);
+    if (g == 4) r[1] = row;                                  // the centre offset (k = 13) is the row itself
+    int32_t *dst = V.nbr_subm + (size_t)row * 27 + g * 3;
+    dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2];
+}
+
+__device__ __forceinline__ void pyr_phase(const PyrArgs &A, int ph, int vb, int *wsum)
+{
+    const int l = pyr_phase_level(ph), kind = pyr_phase_kind(ph);
+    const PyrLevel &V = A.L[l];
+    if (kind == PH_A0) {
+        // one thread per (row, g): g < 8 marks level 1, g == 8 inserts the row into the hash
+        const int n = pyr_rows(V);
+        const int t = vb * 256 + (int)threadIdx.x;
+        if (t >= n * 9) return;
+        const int row = t / 9, g = t - row * 9;
+        const int4 c = ((const int4 *)V.idx)[row];
+        if (g == 8) {
+            const unsigned key = (((unsigned)c.x * V.D + c.y) * V.H + c.z) * V.W + c.w;
+            const int e = hash2_insert(V.look.hv.ent, V.look.hv.mask, key);
+            if (e < 0) { if (A.status) atomicOr(A.status, SASSD_ST_HASH_FULL); return; }
+            V.look.hv.ent[e].y = (unsigned)row;
+        } else if (A.levels > 1) {
+            mark_next(c, g, A.L[1]);
+        }
+    } else if (kind == PH_C) {
+        if (vb >= V.nblk) {                                  // (l == 1) the submanifold table of level 0 rides along
+            const PyrLevel &Z = A.L[0];
+            const int n = pyr_rows(Z);
+            const int t = (vb - V.nblk) * 256 + (int)threadIdx.x;
+            if (t >= n * 9) return;
+            const int row = t / 9;
+            subm_rows(Z, row, t - row * 9, ((const int4 *)Z.idx)[row]);
+            return;
+        }
+        // 32 cell bytes -> one bitmap word; set bits per 256-word block and per 64-block super-block
+        const int i = vb * kEmitWords + (int)threadIdx.x;
+        unsigned word = 0;
+        if (i < V.nwords) {
+            const uint4 lo = ((const uint4 *)V.cells)[2 * (size_t)i], hi = ((const uint4 *)V.cells)[2 * (size_t)i + 1];
+            const unsigned q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) word |= ((q[j] * 0x01020408u) >> 24) << (4 * j);   // bytes are 0 / 1: b0 + 2 b1 + 4 b2 + 8 b3
+            V.bitmap[i] = word;
+        }
+        int tot;
+        block_exclusive_scan(__popc(word), wsum, &tot);
+        if (threadIdx.x == 0) {
+            V.bcnt[vb] = tot;
+            if (tot) atomicAdd(&V.sup[vb >> kSupShift], tot);
+        }
+    } else if (kind == PH_E) {
+        const int blk = vb;
+        const int nsup = blk >> kSupShift;
+        int part = 0;
+        for (int j = threadIdx.x; j < nsup; j += 256) part += V.sup[j];
+        if ((int)threadIdx.x < blk - (nsup << kSupShift)) part += V.bcnt[(nsup << kSupShift) + threadIdx.x];
+        int before;
+        block_exclusive_scan(part, wsum, &before);
+        const int wi = blk * kEmitWords + (int)threadIdx.x;
+        unsigned m = wi < V.nwords ? V.bitmap[wi] : 0u;
+        int tot;
+        const int ex = block_exclusive_scan(__popc(m), wsum, &tot);
+        int row = before + ex;
+        if (wi < V.nwords) V.rank[wi] = row;               // rank of a word = set bits before it
+        if (blk == V.nblk - 1 && threadIdx.x == 0) {
+            int total = before + tot;
+            if (total > V.cap) { if (A.status) atomicOr(A.status, SASSD_ST_VOXEL_OVERFLOW); total = V.cap; }
+            __hip_atomic_store(V.n_ptr, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!m) return;
+        // coordinates of the word's first cell once (three divisions), then walk the <= 32 set bits with carries
+        unsigned lin = (unsigned)wi * 32u;
+        int x = lin % V.W; lin /= V.W;
+        int y = lin % V.H; lin /= V.H;
+        int z = lin % V.D; lin /= V.D;
+        int b = (int)lin, prev = 0;
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            x += bit - prev; prev = bit;
+            while (x >= V.W) { x -= V.W; if (++y == V.H) { y = 0; if (++z == V.D) { z = 0; ++b; } } }
+            if (row < V.cap) ((int4 *)V.idx)[row] = make_int4(b, z, y, x);
+            ++row;
+        }
+    } else {
+        // T(l): submanifold table of level l, strided table into level l, marks of level l+1
+        const int n = pyr_rows(V);
+        const int t = vb * 256 + (int)threadIdx.x;
+        if (t >= n * 9) return;
+        const int row = t / 9, g = t - row * 9;
+        const int4 c = ((const int4 *)V.idx)[row];
+        if (V.nbr_subm) subm_rows(V, row, g, c);
+        if (V.nbr_down) {
+            const PyrLevel &P = A.L[l - 1];
+            const int kz = g / 3, ky = g - kz * 3;
+            const int z = 2 * c.y - 1 + kz, y = 2 * c.z - 1 + ky;
+            int r[3] = {-1, -1, -1};
+            if (z >= 0 && z < P.D && y >= 0 && y < P.H)
+                lookup3(P.look, (((unsigned)c.x * P.D + z) * P.H + y) * P.W, 2 * c.w - 1, P.W, r);
+            int32_t *dst = V.nbr_down + (size_t)row * 27 + g * 3;
+            dst[0] = r[0]; dst[1] = r[1]; dst[2] = r[2];
+        }
+        if (l + 1 < A.levels && g < 8) mark_next(c, g, A.L[l + 1]);
+    }
+}
+
+__global__ void __launch_bounds__(256) pyr_phase_kernel(PyrArgs A, int ph)
+{
+    __shared__ int wsum[17];
+    pyr_phase(A, ph, blockIdx.x, wsum);
+}
+
+// ---- the whole pyramid in one launch: every workgroup resident, phases separated by grid barriers ------------------------
+// Barrier (placement-independent; state zeroed by the fill launch in front): every wave drains its stores, lane 0 of the
+// workgroup publishes them (agent-scope release = L2 write-back), arrives on the counter of its shard (blockIdx % 8), the
+// last arriver of a shard arrives on the top counter, the last of those stores the generation word; everybody polls that
+// one word with relaxed agent-scope loads (+ s_sleep), then ONE agent-scope acquire per workgroup and a workgroup barrier.
+// A bounded spin: on timeout the abort word is set, the status word flagged and every workgroup leaves.
+__device__ __forceinline__ bool pyr_grid_sync(unsigned *bar, unsigned epoch, int32_t *status)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned nb = gridDim.x, g = blockIdx.x & 7u;
+        const unsigned members = (nb - g + 7u) / 8u, shards = nb < 8u ? nb : 8u;
+        const unsigned old = __hip_atomic_fetch_add(&bar[g * 4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == members * epoch) {
+            const unsigned t = __hip_atomic_fetch_add(&bar[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1 == shards * epoch) __hip_atomic_store(&bar[36], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int ok = 1;
+        for (unsigned spins = 0;; ++spins) {
+            if (__hip_atomic_load(&bar[36], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch) break;
+            if (spins > (1u << 22) || __hip_atomic_load(&bar[40], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(&bar[40], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (status) atomicOr(status, SASSD_ST_GRID_SYNC);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+__global__ void __launch_bounds__(256) pyr_persistent_kernel(PyrArgs A)
+{
+    __shared__ int wsum[17];
+    unsigned epoch = 0;
+    const int nph = A.levels > 1 ? 1 + 3 * (A.levels - 1) : 2;        // (one level: A0, then its table through C(1))
+    for (int ph = 0; ph < nph; ++ph) {
+        const int nvb = pyr_phase_blocks(A, ph);
+        for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+            pyr_phase(A, ph, vb, wsum);
+            __syncthreads();
+        }
+        if (ph + 1 < nph && !pyr_grid_sync(A.bar, ++epoch, A.status)) return;
+    }
+}
 
 struct PyramidLayout {
-    size_t keys, vals, bitmap[kMaxLevels], bcnt[kMaxLevels], sup[kMaxLevels], rank[kMaxLevels];
+    size_t keys, cells[kMaxLevels], bitmap[kMaxLevels], bcnt[kMaxLevels], sup[kMaxLevels], rank[kMaxLevels], bar;
     size_t keys_end, zero_begin, zero_end, total;
-    int nwords[kMaxLevels], nblk[kMaxLevels];
+    int nwords[kMaxLevels], nblk[kMaxLevels];      // of the bitmap of level l (l >= 1)
     int dims[kMaxLevels][3];
 };
 
@@ -386,21 +502,23 @@ bool pyramid_layout(int levels, const int *caps, int D, int H, int W, int B, Pyr
     size_t o = 0;
     L.keys = o; o += align_up((size_t)hash_cap(caps[0]) * 8, 256);          // level-0 hash only: {key, value} entries
     L.keys_end = o;
-    L.vals = o;
     L.zero_begin = o;
     L.dims[0][0] = D; L.dims[0][1] = H; L.dims[0][2] = W;
     if (!lin_fits(D, H, W, B)) return false;
-    for (int l = 0; l + 1 < levels; ++l) {
-        for (int a = 0; a < 3; ++a) L.dims[l + 1][a] = (L.dims[l][a] - 1) / 2 + 1;
-        const size_t cells = (size_t)B * L.dims[l + 1][0] * L.dims[l + 1][1] * L.dims[l + 1][2];
+    L.nwords[0] = L.nblk[0] = 0;
+    for (int l = 1; l < levels; ++l) {
+        for (int a = 0; a < 3; ++a) L.dims[l][a] = (L.dims[l - 1][a] - 1) / 2 + 1;
+        const size_t cells = (size_t)B * L.dims[l][0] * L.dims[l][1] * L.dims[l][2];
         L.nwords[l] = (int)((cells + 31) / 32);
         L.nblk[l] = cdiv(L.nwords[l], kEmitWords);
-        L.bitmap[l] = o; o += align_up((size_t)L.nwords[l] * 4, 256);
+        L.cells[l] = o;  o += align_up((size_t)L.nwords[l] * 32, 256);
         L.sup[l] = o;    o += align_up((size_t)((L.nblk[l] >> kSupShift) + 1) * 4, 256);
     }
+    L.bar = o; o += align_up((size_t)kBarWords * 4, 256);
     L.zero_end = o;
-    for (int l = 0; l + 1 < levels; ++l) { L.bcnt[l] = o; o += align_up((size_t)L.nblk[l] * 4, 256); }
-    for (int l = 0; l + 1 < levels; ++l) { L.rank[l] = o; o += align_up((size_t)L.nwords[l] * 4, 256); }
+    for (int l = 1; l < levels; ++l) { L.bitmap[l] = o; o += align_up((size_t)L.nwords[l] * 4, 256); }
+    for (int l = 1; l < levels; ++l) { L.bcnt[l] = o; o += align_up((size_t)L.nblk[l] * 4, 256); }
+    for (int l = 1; l < levels; ++l) { L.rank[l] = o; o += align_up((size_t)L.nwords[l] * 4, 256); }
     L.total = o;
     return true;
 }
@@ -510,65 +628,77 @@ extern "C" size_t sassd_rulebook_pyramid_workspace_bytes(int levels, const int *
 
 extern "C" int sassd_rulebook_pyramid(int levels, int32_t *const *indices, int32_t *const *n_ptrs, const int *caps,
                                       int D, int H, int W, int batch_size, int32_t *const *nbr_subm,
-                                      int32_t *const *nbr_down, int level_begin, int level_end, int32_t *status,
-                                      void *workspace, size_t workspace_bytes, void *stream_)
+                                      int32_t *const *nbr_down, int level_begin, int level_end, int flags,
+                                      int32_t *status, void *workspace, size_t workspace_bytes, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!indices || !n_ptrs || !caps || !nbr_subm || !nbr_down || !workspace) return SASSD_EINVAL;
     PyramidLayout L;
     if (!pyramid_layout(levels, caps, D, H, W, batch_size, L)) return SASSD_EINVAL;
     if (workspace_bytes < L.total) return SASSD_ENOSPC;
+    if (((uintptr_t)workspace) & 15) return SASSD_EINVAL;               // (the fill launch stores 16 bytes per thread)
     if (level_begin < 0 || level_end > levels || level_begin >= level_end) return SASSD_EINVAL;
     for (int l = 0; l < levels; ++l) {
         if (!indices[l] || !n_ptrs[l] || caps[l] <= 0) return SASSD_EINVAL;
         if (l > 0 && !nbr_down[l]) return SASSD_EINVAL;
     }
+    const bool persistent = (flags & SASSD_PYRAMID_PERSISTENT) != 0;
+    if (persistent && (level_begin != 0 || level_end != levels)) return SASSD_EINVAL;
     char *w = (char *)workspace;
     int rc;
-    Lookup look[kMaxLevels];
+    PyrArgs A;
+    memset(&A, 0, sizeof(A));                                           // (levels past the stack: no blocks)
+    A.levels = levels;
+    A.status = status;
+    A.bar = (unsigned *)(w + L.bar);
     for (int l = 0; l < levels; ++l) {
-        look[l].cap = caps[l];
+        PyrLevel &V = A.L[l];
+        V.idx = indices[l]; V.n_ptr = n_ptrs[l]; V.cap = caps[l];
+        V.D = L.dims[l][0]; V.H = L.dims[l][1]; V.W = L.dims[l][2];
+        V.nbr_subm = nbr_subm[l];
+        V.nbr_down = l > 0 ? nbr_down[l] : nullptr;
+        V.look.cap = caps[l];
+        V.look.hv.ent = (uint2 *)(w + L.keys);
+        V.look.hv.mask = hash_cap(caps[0]) - 1;
         if (l == 0) {
-            look[l].bitmap = nullptr; look[l].rank = nullptr;
-            look[l].hv.ent = (uint2 *)(w + L.keys);
-            look[l].hv.mask = hash_cap(caps[0]) - 1;
+            V.look.bitmap = nullptr; V.look.rank = nullptr;
+            V.cells = nullptr; V.bitmap = nullptr; V.rank = nullptr; V.bcnt = nullptr; V.sup = nullptr;
         } else {
-            look[l].bitmap = (const unsigned *)(w + L.bitmap[l - 1]);
-            look[l].rank = (const int *)(w + L.rank[l - 1]);
-            look[l].hv = look[0].hv;
+            V.cells = (unsigned char *)(w + L.cells[l]);
+            V.bitmap = (unsigned *)(w + L.bitmap[l]);
+            V.rank = (int *)(w + L.rank[l]);
+            V.bcnt = (int *)(w + L.bcnt[l]);
+            V.sup = (int *)(w + L.sup[l]);
+            V.look.bitmap = V.bitmap; V.look.rank = V.rank;
         }
+        V.nwords = L.nwords[l]; V.nblk = L.nblk[l];
     }
+    if (level_begin == 0 &&
+        (rc = sassd_fill2(w, L.keys_end, 0xFF, w + L.zero_begin, L.zero_end - L.zero_begin, 0x00, stream))) return rc;
+    if (persistent) {
+        // every workgroup must be resident: 256 threads, ~40 VGPRs and 72 bytes of LDS admit 6 per CU; at most 4 are asked for
+        int cus = 0;
+        if ((rc = sassd_num_cus(&cus))) return rc;
+        int per_cu = (flags >> 8) & 0xff;
+        if (per_cu < 1) per_cu = 2;
+        if (per_cu > 4) per_cu = 4;
+        hipLaunchKernelGGL(pyr_persistent_kernel, dim3(cus * per_cu), dim3(256), 0, stream, A);
+        return sassd_launch_status();
+    }
+    // level 0: A0, then C(1) (with the submanifold table of level 0).  level l >= 1: E(l), T(l), C(l+1)
+    auto launch = [&](int ph) {
+        const int nb = pyr_phase_blocks(A, ph);
+        if (nb > 0) hipLaunchKernelGGL(pyr_phase_kernel, dim3(nb), dim3(256), 0, stream, A, ph);
+    };
     for (int l = level_begin; l < level_end; ++l) {
         if (l == 0) {
-            if ((rc = sassd_fill2(w, L.keys_end, 0xFF, w + L.zero_begin,
-                                  L.zero_end > L.zero_begin ? L.zero_end - L.zero_begin : 0, 0x00, stream))) return rc;
-            hipLaunchKernelGGL(hash_build_kernel, dim3(cdiv(caps[0], 256)), dim3(256), 0, stream, indices[0],
-                               n_ptrs[0], caps[0], L.dims[0][0], L.dims[0][1], L.dims[0][2], look[0].hv, status);
+            launch(0);
+            launch(1);                                       // (one level: only its table; C(1) has no blocks)
         } else {
-            const int p = l - 1;
-            hipLaunchKernelGGL(rb_emit_kernel, dim3(L.nblk[p]), dim3(256), 0, stream,
-                               (const unsigned *)(w + L.bitmap[p]), L.nwords[p], L.nblk[p],
-                               (const int *)(w + L.bcnt[p]), (const int *)(w + L.sup[p]), (int *)(w + L.rank[p]),
-                               L.dims[l][0], L.dims[l][1], L.dims[l][2], caps[l], indices[l], n_ptrs[l], status);
+            launch(1 + 3 * (l - 1) + 1);
+            launch(1 + 3 * (l - 1) + 2);
+            if (l + 1 < levels) launch(1 + 3 * l);
         }
-        LevelArgs A;
-        A.idx = indices[l]; A.n_ptr = n_ptrs[l]; A.cap = caps[l];
-        A.D = L.dims[l][0]; A.H = L.dims[l][1]; A.W = L.dims[l][2];
-        A.cur = look[l];
-        A.nbr_subm = nbr_subm[l];
-        const int pl = l > 0 ? l - 1 : 0;
-        A.prev = look[pl];
-        A.pD = L.dims[pl][0]; A.pH = L.dims[pl][1]; A.pW = L.dims[pl][2];
-        A.nbr_down = l > 0 ? nbr_down[l] : nullptr;
-        const bool last = (l + 1 == levels);
-        A.bitmap_next = last ? nullptr : (unsigned *)(w + L.bitmap[l]);
-        A.OD = last ? 1 : L.dims[l + 1][0]; A.OH = last ? 1 : L.dims[l + 1][1]; A.OW = last ? 1 : L.dims[l + 1][2];
-        if (A.nbr_subm || A.nbr_down || A.bitmap_next)
-            hipLaunchKernelGGL(rb_level_kernel, dim3(cdiv(caps[l] * 9, 256)), dim3(256), 0, stream, A);
-        if (!last)
-            hipLaunchKernelGGL(rb_count_kernel, dim3(L.nblk[l]), dim3(256), 0, stream,
-                               (const unsigned *)(w + L.bitmap[l]), L.nwords[l], (int *)(w + L.bcnt[l]),
-                               (int *)(w + L.sup[l]));
     }
     return sassd_launch_status();
 }

@@ -63,7 +63,9 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int K, float *__
     packed[i] = transposed ? w[((size_t)k * COUT + co) * CIN + ci] : w[((size_t)k * CIN + ci) * COUT + co];
 }
 
-int g_spconv_dbg = 0;           // reserved debug switch (tools/ablate_spconv.py); 0 in production
+// (rounds 1-5 kept the ablation / geometry switches in two process-wide ints behind sassd_debug_set_spconv; since round 6 they
+// are the `cfg` argument of the entry points: bits 0-15 ablation flags, bits 16.. geometry -- per call, nothing a hipGraph
+// capture could bake in by accident)
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
@@ -233,11 +235,11 @@ spconv_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, 
 
 template <int CIN, int COUT>
 int launch_fwd(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp, int K,
-               const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
+               const float *scale, const float *shift, int relu, float *y, int dbg, hipStream_t stream)
 {
     using S = SpShape<CIN, COUT>;
     hipLaunchKernelGGL((spconv_fwd_kernel<CIN, COUT>), dim3(cdiv(cap, 64)), dim3(4 * kSplit * 64), 0, stream, x, nbr,
-                       n_ptr, cap, wp, K, scale, shift, relu, y, g_spconv_dbg);
+                       n_ptr, cap, wp, K, scale, shift, relu, y, dbg);
     return sassd_launch_status();
 }
 
@@ -491,11 +493,10 @@ spconv_gs_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
 
 #include "spconv_gq.h"
 
-int g_spconv_cfg = 0;           // 0 = default dispatch; 1 / 5 / 8 / 9 force one of its geometries, 10 = the round-3 ones (tools/, tests)
 
 template <int CIN, int COUT, int RW, int NW, int CS, int WPS>
 int launch_gs_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp,
-                  const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
+                  const float *scale, const float *shift, int relu, float *y, int dbg, hipStream_t stream)
 {
     constexpr size_t lds = gs_lds_bytes<COUT, RW, NW, CS>();
     static_assert(lds <= 160 * 1024, "workgroup slabs exceed the 160 KB LDS");
@@ -505,27 +506,28 @@ int launch_gs_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int 
     if (rc) return rc;
     const int grid = 64 * cdiv(cdiv(cap, RW), 64);
     hipLaunchKernelGGL((spconv_gs_kernel<CIN, COUT, RW, NW, CS, WPS>), dim3(grid), dim3(NW * 64), lds, stream, x, nbr,
-                       n_ptr, cap, wp, scale, shift, relu, y, g_spconv_dbg & 31);
+                       n_ptr, cap, wp, scale, shift, relu, y, dbg & 31);
     return sassd_launch_status();
 }
 
 template <int CIN, int COUT>
 int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp, int K,
-              const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
+              const float *scale, const float *shift, int relu, float *y, int cfg, hipStream_t stream)
 {
     (void)K;
-    // forced geometries (sassd_debug_set_spconv bits 16+): exactly the ones the default dispatch below picks by layer shape
+    const int geo = cfg >> 16, dbg = cfg & 0xFFFF;
+    // forced geometries (cfg bits 16+): exactly the ones the default dispatch below picks by layer shape
     // and capacity, so that tests / tools can run each of them on any input size.  (Rounds 2-4 carried nine more -- 128-row
     // slices, channel-split wave pairs, 8-wave and consecutive-slice forms of the balanced kernel -- as measured-and-
     // rejected alternatives; removed in round 5, their timings are in profiles/r04_spconv_layers_*.txt.)
     //   1 = spconv_gs_kernel, 4 waves, two workgroups per CU      5 = spconv_gs_kernel, 8 waves (10 = 1 or 5 by capacity)
     //   8 = balanced kernel, 4x4x1 quads, 4 waves                 9 = balanced kernel, 16x16x4 tiles, 4 waves
     constexpr int Q = (COUT >= 32) ? 1 : 0;                  // (16-channel outputs have no quad form: 16x16x4 tile)
-    if (g_spconv_cfg == 1) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 5) return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 8) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg == 9) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    if (g_spconv_cfg != 0 && g_spconv_cfg != 10) return SASSD_EINVAL;
+    if (geo == 1) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, dbg, stream);
+    if (geo == 5) return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, dbg, stream);
+    if (geo == 8) return launch_gq_cfg<CIN, COUT, 4, 2, Q, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, dbg, stream);
+    if (geo == 9) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, dbg, stream);
+    if (geo != 0 && geo != 10) return SASSD_EINVAL;
     // default (round 4, measured per layer shape; profiles/r04_spconv_layers_*.txt).  The balanced kernel pays for its
     // cooperative compaction and pays off where a layer is long enough to be bound by its heaviest workgroup: the
     // 64 -> 64 layers.  KITTI-scale single frames (one round of workgroups; level capacity 40 k rows): 16x16x4 tiles on 4
@@ -534,15 +536,15 @@ int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap,
     // of 111 us at 106 k rows): 4x4x1 quads.  Waymo-scale levels (13-17 pairs per row: 16-pair tiles are full) and every
     // narrower layer stay on the round-3 geometry.
     if constexpr (CIN == 64 && COUT == 64) {
-        if (g_spconv_cfg != 10) {
-            if (cap <= 65536) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-            if (cap <= 400000) return launch_gq_cfg<CIN, COUT, 4, 2, 1, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+        if (geo != 10) {
+            if (cap <= 65536) return launch_gq_cfg<CIN, COUT, 4, 2, 0, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, dbg, stream);
+            if (cap <= 400000) return launch_gq_cfg<CIN, COUT, 4, 2, 1, 1>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, dbg, stream);
         }
     }
     // round-3 geometry (cfg 10 forces it everywhere): KITTI-scale single frames (capacity <= 64 k rows) one 8-wave
     // workgroup per CU, larger batches / frames two 4-wave workgroups per CU
-    if (cap > 65536) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
-    return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+    if (cap > 65536) return launch_gs_cfg<CIN, COUT, 64, 4, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, dbg, stream);
+    return launch_gs_cfg<CIN, COUT, 64, 8, 1, 2>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, dbg, stream);
 }
 
 // forward / data-gradient dispatch: gather-GEMM-scatter for 27-offset layers with Cin >= 16, the streaming kernel for the
@@ -550,16 +552,16 @@ int launch_gs(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap,
 // switch (debug bit 8) is set
 template <int CIN, int COUT>
 int launch_conv(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp, int K,
-                const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
+                const float *scale, const float *shift, int relu, float *y, int cfg, hipStream_t stream)
 {
     if constexpr (CIN >= 16) {
-        if (nbr && !(g_spconv_dbg & 256)) return launch_gs<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, stream);
-        if (!nbr && !(g_spconv_dbg & 256)) return launch_pw<CIN, COUT>(x, n_ptr, cap, wp, scale, shift, relu, y, stream);
+        if (nbr && !(cfg & 256)) return launch_gs<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, cfg, stream);
+        if (!nbr && !(cfg & 256)) return launch_pw<CIN, COUT>(x, n_ptr, cap, wp, scale, shift, relu, y, stream);
     }
     if constexpr (CIN == 4) {
-        if (nbr && !(g_spconv_dbg & 256)) return launch_c4<COUT>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
+        if (nbr && !(cfg & 256)) return launch_c4<COUT>(x, nbr, n_ptr, cap, wp, scale, shift, relu, y, stream);
     }
-    return launch_fwd<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, stream);
+    return launch_fwd<CIN, COUT>(x, nbr, n_ptr, cap, wp, K, scale, shift, relu, y, cfg & 0xFFFF, stream);
 }
 
 #define SP_DISPATCH(FN, ...)                                                     \
@@ -826,12 +828,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
 
 template <int CIN, int COUT>
 int launch_wgrad(const float *x, const float *dy, const int32_t *nbr, const int32_t *n_ptr, int cap, float *part,
-                 float *dw, int accumulate, hipStream_t stream)
+                 float *dw, int accumulate, int cfg, hipStream_t stream)
 {
     constexpr int MT = (CIN + 15) / 16, NTT = COUT / 16;
     constexpr int WPW = MT * NTT < 8 ? MT * NTT : 8;
     int wg_rows = kWgRows;
-    if (g_spconv_dbg & 32) {    // debug bit 5: the tile-per-wave formulation
+    if (cfg & 32) {    // cfg bit 5: the tile-per-wave formulation
         hipLaunchKernelGGL((spconv_wgrad_kernel<CIN, COUT>), dim3(cdiv(cap, kWgRows), MT * NTT / WPW), dim3(WPW * 64), 0,
                            stream, x, dy, nbr, n_ptr, cap, part);
     } else {
@@ -891,14 +893,14 @@ extern "C" int sassd_spconv_pack_weight_t(const float *w, int K, int Cin, int Co
 }
 
 extern "C" int sassd_spconv_bwd_data(const float *dy, const int32_t *nbrT, const int32_t *n_in_ptr, int cap_in,
-                                     const float *wT_packed, int K, int Cin, int Cout, float *dx, void *stream_)
+                                     const float *wT_packed, int K, int Cin, int Cout, float *dx, int cfg, void *stream_)
 {
     // dx [cap_in, Cin] = sum_k dy[nbrT[i,k]] @ W[k]^T : the forward kernel with (Cin', Cout') = (Cout, Cin)
     if (!dy || !n_in_ptr || !wT_packed || !dx || cap_in <= 0) return SASSD_EINVAL;
     if (nbrT ? (K != kK) : (K != 1)) return SASSD_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     { const int t = Cin; Cin = Cout; Cout = t; }
-    SP_DISPATCH(launch_conv, dy, nbrT, n_in_ptr, cap_in, wT_packed, K, nullptr, nullptr, 0, dx, stream)
+    SP_DISPATCH(launch_conv, dy, nbrT, n_in_ptr, cap_in, wT_packed, K, nullptr, nullptr, 0, dx, cfg, stream)
 }
 
 extern "C" size_t sassd_spconv_bwd_weight_workspace_bytes(int cap_out, int K, int Cin, int Cout)
@@ -907,24 +909,23 @@ extern "C" size_t sassd_spconv_bwd_weight_workspace_bytes(int cap_out, int K, in
 }
 
 extern "C" int sassd_spconv_bwd_weight(const float *x, const float *dy, const int32_t *nbr, const int32_t *n_out_ptr,
-                                       int cap_out, int K, int Cin, int Cout, float *dw, int accumulate,
+                                       int cap_out, int K, int Cin, int Cout, float *dw, int accumulate, int cfg,
                                        void *workspace, size_t workspace_bytes, void *stream_)
 {
     if (!x || !dy || !nbr || !n_out_ptr || !dw || !workspace || cap_out <= 0 || K != kK) return SASSD_EINVAL;
     if (workspace_bytes < sassd_spconv_bwd_weight_workspace_bytes(cap_out, K, Cin, Cout)) return SASSD_ENOSPC;
     hipStream_t stream = (hipStream_t)stream_;
     float *part = (float *)workspace;
-    SP_DISPATCH(launch_wgrad, x, dy, nbr, n_out_ptr, cap_out, part, dw, accumulate, stream)
+    SP_DISPATCH(launch_wgrad, x, dy, nbr, n_out_ptr, cap_out, part, dw, accumulate, cfg, stream)
 }
 
 namespace {
 }  // namespace
 
-// debug / ablation switches (tools/ablate_spconv.py): bit0 no gather loads, bit1 no slab accumulate, bit2 no MFMA,
-// bit3 no weight loads, bit4 dynamic (ticket) offset assignment instead of the static table, bit5 tile-per-wave weight
-// gradient, bit8 legacy
-// register-stationary kernel; bits 16.. select the workgroup geometry (0 default)
-extern "C" void sassd_debug_set_spconv(int flags) { g_spconv_dbg = flags & 0xFFFF; g_spconv_cfg = flags >> 16; }
+// `cfg` of sassd_spconv_fwd / _bwd_data / _bwd_weight (0 in production; tools/ablate_spconv.py, tests): bit2 no MFMA, bit5
+// (forward) every gather reads row 0 / (weight gradient) the tile-per-wave formulation, bit6 one weight image for every offset,
+// bit8 the legacy register-stationary kernel; bits 16.. force a workgroup geometry (launch_gs).  Per call: no process-wide
+// switch selects a kernel (ADVICE r04 / VERDICT r05 item 8).
 
 extern "C" size_t sassd_spconv_packed_floats(int K, int Cin, int Cout) { return (size_t)K * Cin * Cout; }
 
@@ -937,12 +938,12 @@ extern "C" int sassd_spconv_pack_weight(const float *w, int K, int Cin, int Cout
 
 extern "C" int sassd_spconv_fwd(const float *x, const int32_t *nbr, const int32_t *n_out_ptr, int cap_out,
                                 const float *w_packed, int K, int Cin, int Cout, const float *scale,
-                                const float *shift, int relu, float *y, void *stream_)
+                                const float *shift, int relu, float *y, int cfg, void *stream_)
 {
     if (!x || !n_out_ptr || !w_packed || !y || cap_out <= 0) return SASSD_EINVAL;
     if (nbr ? (K != kK) : (K != 1)) return SASSD_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    SP_DISPATCH(launch_conv, x, nbr, n_out_ptr, cap_out, w_packed, K, scale, shift, relu, y, stream)
+    SP_DISPATCH(launch_conv, x, nbr, n_out_ptr, cap_out, w_packed, K, scale, shift, relu, y, cfg, stream)
 }
 
 extern "C" int sassd_densify(const float *feats, const int32_t *indices, const int32_t *n_ptr, int cap, int C,

@@ -333,7 +333,7 @@ spconv_gq_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr, c
 
 template <int CIN, int COUT, int NW, int WPS, int QUAD, int ILV>
 int launch_gq_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int cap, const float *wp,
-                  const float *scale, const float *shift, int relu, float *y, hipStream_t stream)
+                  const float *scale, const float *shift, int relu, float *y, int dbg, hipStream_t stream)
 {
     constexpr size_t lds = gq_lds_bytes<COUT, NW>();
     static_assert(lds <= 160 * 1024, "workgroup slabs exceed the 160 KB LDS");
@@ -343,7 +343,7 @@ int launch_gq_cfg(const float *x, const int32_t *nbr, const int32_t *n_ptr, int 
     int rc = sassd_dyn_lds(fn, lds, attr_done);
     if (rc) return rc;
     hipLaunchKernelGGL((spconv_gq_kernel<CIN, COUT, NW, WPS, QUAD, ILV>), dim3(gq_grid(cap, ILV)), dim3(NW * 64), lds, stream, x,
-                       nbr, n_ptr, cap, wp, scale, shift, relu, y, g_spconv_dbg & 127);
+                       nbr, n_ptr, cap, wp, scale, shift, relu, y, dbg & 127);
     return sassd_launch_status();
 }
 

@@ -198,11 +198,13 @@ class RulebookPyramid:
             raise ValueError("rulebook pyramid: unsupported level count / grid too large")
         self.ws = torch.empty(self.wsb, dtype=torch.uint8, device=dev)
 
-    def build(self, level_begin=0, level_end=None):
+    def build(self, level_begin=0, level_end=None, persistent=False, wgs_per_cu=0):
+        """`persistent`: every phase in ONE launch with in-launch grid barriers (whole pyramid only)."""
         level_end = self.levels if level_end is None else level_end
         d, h, w = self.shape0
+        flags = (1 | (int(wgs_per_cu) << 8)) if persistent else 0
         rc = _C.lib().sassd_rulebook_pyramid(self.levels, self.indices, self.n_ptrs, self.caps, d, h, w, self.B,
-                                             self.nbr_subm, self.nbr_down, level_begin, level_end,
+                                             self.nbr_subm, self.nbr_down, level_begin, level_end, flags,
                                              _C.ptr(self.status), _C.ptr(self.ws), self.wsb, _C.stream())
         _C.check(rc, "sassd_rulebook_pyramid")
 
@@ -239,12 +241,38 @@ class Graph:
             pass
 
 
-def debug_set_wino4(cfg=0, dbg=0):
-    _C.lib().sassd_debug_set_wino4(int(cfg), int(dbg))
+# ---- kernel selection: a per-call `cfg` word of the C ABI (include/sassd.h); 0 in production -----------------------------
+# DEFAULT_CFG is what the wrappers below pass when the caller gives none: host-side state of THIS binding (the library has no
+# process-wide switch any more).  SASSD_SPCONV_DEBUG / SASSD_WINO4_CFG preset it for an unmodified test / bench command.
+import os as _os
+DEFAULT_CFG = {"spconv": int(_os.environ.get("SASSD_SPCONV_DEBUG", "0"), 0),
+               "wino4": int(_os.environ.get("SASSD_WINO4_CFG", "0"), 0)}
 
 
-def debug_set_spconv(flags):
-    _C.lib().sassd_debug_set_spconv(int(flags))
+def spconv_cfg(geometry=0, flags=0):
+    """cfg word of the sparse-conv entry points: ablation flags (low 16 bits) + forced workgroup geometry."""
+    return (int(geometry) << 16) | (int(flags) & 0xFFFF)
+
+
+def wino4_cfg(geometry=0, dbg=0):
+    """cfg word of the Winograd entry points: GEMM geometry (bits 0-7) + ablation / stage-skip flags."""
+    return (int(geometry) & 0xFF) | (int(dbg) << 8)
+
+
+class default_cfg:
+    """`with K.default_cfg(spconv=..., wino4=...):` -- the cfg the wrappers pass inside the block (tests, tools)."""
+
+    def __init__(self, spconv=None, wino4=None):
+        self.new = {k: int(v) for k, v in (("spconv", spconv), ("wino4", wino4)) if v is not None}
+
+    def __enter__(self):
+        self.old = dict(DEFAULT_CFG)
+        DEFAULT_CFG.update(self.new)
+        return self
+
+    def __exit__(self, *exc):
+        DEFAULT_CFG.update(self.old)
+        return False
 
 
 def rulebook_pairs(nbr, n_out_ptr, cap_out):
@@ -269,12 +297,13 @@ def spconv_pack_weight(w):
     return packed
 
 
-def spconv_fwd(x, nbr, n_out_ptr, cap_out, w_packed, k, cin, cout, scale=None, shift=None, relu=False, y=None):
+def spconv_fwd(x, nbr, n_out_ptr, cap_out, w_packed, k, cin, cout, scale=None, shift=None, relu=False, y=None, cfg=None):
     _chk_cuda(x, nbr, w_packed, scale, shift)
     if y is None:
         y = torch.empty(cap_out, cout, dtype=torch.float32, device=x.device)
     rc = _C.lib().sassd_spconv_fwd(_C.ptr(x), _C.ptr(nbr), _C.ptr(n_out_ptr), cap_out, _C.ptr(w_packed), k, cin, cout,
-                                   _C.ptr(scale), _C.ptr(shift), 1 if relu else 0, _C.ptr(y), _C.stream())
+                                   _C.ptr(scale), _C.ptr(shift), 1 if relu else 0, _C.ptr(y),
+                                   DEFAULT_CFG["spconv"] if cfg is None else int(cfg), _C.stream())
     _C.check(rc, "sassd_spconv_fwd")
     return y
 
@@ -296,15 +325,16 @@ def spconv_pack_weight_t(w):
     return packed
 
 
-def spconv_bwd_data(dy, nbrT, n_in_ptr, cap_in, wT_packed, k, cin, cout):
+def spconv_bwd_data(dy, nbrT, n_in_ptr, cap_in, wT_packed, k, cin, cout, cfg=None):
     _chk_cuda(dy, nbrT, wT_packed)
     dx = torch.empty(cap_in, cin, dtype=torch.float32, device=dy.device)
     _C.check(_C.lib().sassd_spconv_bwd_data(_C.ptr(dy), _C.ptr(nbrT), _C.ptr(n_in_ptr), cap_in, _C.ptr(wT_packed), k,
-                                            cin, cout, _C.ptr(dx), _C.stream()), "sassd_spconv_bwd_data")
+                                            cin, cout, _C.ptr(dx), DEFAULT_CFG["spconv"] if cfg is None else int(cfg),
+                                            _C.stream()), "sassd_spconv_bwd_data")
     return dx
 
 
-def spconv_bwd_weight(x, dy, nbr, n_out_ptr, cap_out, cin, cout, dw=None, accumulate=False):
+def spconv_bwd_weight(x, dy, nbr, n_out_ptr, cap_out, cin, cout, dw=None, accumulate=False, cfg=None):
     _chk_cuda(x, dy, nbr)
     L = _C.lib()
     if dw is None:                                  # (the reduction kernel overwrites every element unless `accumulate`)
@@ -312,7 +342,8 @@ def spconv_bwd_weight(x, dy, nbr, n_out_ptr, cap_out, cin, cout, dw=None, accumu
     wsb = L.sassd_spconv_bwd_weight_workspace_bytes(cap_out, 27, cin, cout)
     ws = workspace("spconv_wgrad", wsb, x.device)
     _C.check(L.sassd_spconv_bwd_weight(_C.ptr(x), _C.ptr(dy), _C.ptr(nbr), _C.ptr(n_out_ptr), cap_out, 27, cin, cout,
-                                       _C.ptr(dw), 1 if accumulate else 0, _C.ptr(ws), wsb, _C.stream()),
+                                       _C.ptr(dw), 1 if accumulate else 0,
+                                       DEFAULT_CFG["spconv"] if cfg is None else int(cfg), _C.ptr(ws), wsb, _C.stream()),
              "sassd_spconv_bwd_weight")
     return dw
 
@@ -402,9 +433,9 @@ def conv2d_wino4_workspace(b, cin, cout, h, w, device):
     return torch.empty(max(n, 256), dtype=torch.uint8, device=device)
 
 
-def conv2d_wino4_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=None, ws=None):
+def conv2d_wino4_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=None, ws=None, cfg=None):
     """3x3 pad-1 conv through Winograd F(4x4,3x3): input transform, 36 GEMMs (fp32 products on the bf16 MFMA over exactly
-    split operands; `debug_set_wino4(1)` = the fp32 MFMA), output transform + epilogue."""
+    split operands; `cfg = wino4_cfg(1)` = the fp32 MFMA), output transform + epilogue."""
     _chk_cuda(x, w_packed)
     b, cin, h, w = x.shape
     if y is None:
@@ -414,7 +445,8 @@ def conv2d_wino4_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=No
     if ws is None or ws.numel() < wsb:
         ws = workspace("conv2d_wino4", wsb, x.device)
     _C.check(L.sassd_conv2d_wino4_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
-                                      _C.ptr(y), b, cin, cout, h, w, _C.ptr(ws), ws.numel(), _C.stream()),
+                                      _C.ptr(y), b, cin, cout, h, w, DEFAULT_CFG["wino4"] if cfg is None else int(cfg),
+                                      _C.ptr(ws), ws.numel(), _C.stream()),
              "sassd_conv2d_wino4_fwd")
     return y
 
@@ -430,7 +462,7 @@ def conv2d_wino4_chain_workspace(b, cmax, h, w, device):
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
-def conv2d_wino4_chain(x, prev, w_packed, cin, cout, cmax, batch, h, w, scale, shift, relu, y, ws):
+def conv2d_wino4_chain(x, prev, w_packed, cin, cout, cmax, batch, h, w, scale, shift, relu, y, ws, cfg=None):
     """One layer of a chain of Winograd F(4x4,3x3) convolutions (sassd_conv2d_wino4_chain).  `x`: NCHW input map, or None
     to continue from the products the previous call left in `ws` (then prev = (scale, shift, relu) of that layer).
     `y`: NCHW output map, or None to leave the products in `ws` for the next call."""
@@ -438,7 +470,8 @@ def conv2d_wino4_chain(x, prev, w_packed, cin, cout, cmax, batch, h, w, scale, s
     ps, pb, pr = prev if prev is not None else (None, None, False)
     _C.check(_C.lib().sassd_conv2d_wino4_chain(_C.ptr(x), 0 if x is not None else 1, _C.ptr(ps), _C.ptr(pb), 1 if pr else 0,
                                                _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
-                                               _C.ptr(y), batch, cin, cout, cmax, h, w, _C.ptr(ws), ws.numel(),
+                                               _C.ptr(y), batch, cin, cout, cmax, h, w,
+                                               DEFAULT_CFG["wino4"] if cfg is None else int(cfg), _C.ptr(ws), ws.numel(),
                                                _C.stream()), "sassd_conv2d_wino4_chain")
     return y
 
@@ -457,13 +490,15 @@ def conv1x1_gemm_pack_weight(w):
     return packed
 
 
-def conv1x1_gemm_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=None):
+def conv1x1_gemm_fwd(x, w_packed, cout, scale=None, shift=None, relu=False, y=None, cfg=None):
     _chk_cuda(x, w_packed, scale, shift)
     b, cin, h, w = x.shape
     if y is None:
         y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
     _C.check(_C.lib().sassd_conv1x1_gemm_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
-                                             _C.ptr(y), b, cin, cout, h, w, _C.stream()), "sassd_conv1x1_gemm_fwd")
+                                             _C.ptr(y), b, cin, cout, h, w,
+                                             DEFAULT_CFG["wino4"] if cfg is None else int(cfg), _C.stream()),
+             "sassd_conv1x1_gemm_fwd")
     return y
 
 

@@ -56,7 +56,7 @@ class InferencePlan:
                  sparse_shape=(40, 1600, 1408), anchors=None, anchors_bv=None, anchor_area_threshold=1,
                  anchors_per_loc=2, grid_offsets=(0., 40.), featmap_stride=0.4, rpn_thr=0.1, score_thr=0.3,
                  iou_thr=0.1, cap_k=4096, cap_d=512, device=None, level_cap_factor=2, overlap=True, winograd=True,
-                 fused_rulebooks=True, chain_bev=True):
+                 fused_rulebooks=True, chain_bev=True, pyramid_persistent=False, spconv_cfg=None, wino4_cfg=None):
         dev = torch.device(device if device is not None else "cuda:0")
         self.dev, self.B, self.ncls, self.A = dev, int(batch_size), int(num_class), int(anchors_per_loc)
         self.voxel_size = np.asarray(voxel_size, np.float32)
@@ -176,12 +176,16 @@ class InferencePlan:
         self.det = dict(boxes=z(B, self.capD, 7), scores=z(B, self.capD), labels=z(B, self.capD, dt=i32),
                         counts=z(B, dt=i32))
         self.middle = {}
-        # all seven rulebooks through the fused pyramid (11 launches); the per-op chain (30) stays selectable for A/B
+        # all seven rulebooks through the fused pyramid (1 fill + 8 launches); the per-op chain (30) stays selectable for A/B
         self.pyr = None
         if fused_rulebooks:
             self.pyr = K.RulebookPyramid(self.idx, self.n, self.caps, self.shape0, B,
                                          [self.nbr["subm%d" % l] for l in range(4)],
                                          [None] + [self.nbr["down%d" % l] for l in range(3)], self.status)
+        # True: the whole pyramid as ONE persistent launch (in-launch grid barriers) instead of two launches per level
+        self.pyramid_persistent = bool(pyramid_persistent)
+        # per-call kernel-selection words of the C ABI (None: the binding's default, 0 in production)
+        self.spconv_cfg, self.wino4_cfg = spconv_cfg, wino4_cfg
         self.graph = None
         self._wsid = id(self)
         # coordinate-only work (rulebooks, anchors_mask) runs on a side stream, overlapping the feature path
@@ -236,6 +240,11 @@ class InferencePlan:
         a side HIP stream and overlap the feature path; `self.rb_ev[key]` fires when a rulebook is ready."""
         B = self.B
         if self.pyr is not None:
+            if self.pyramid_persistent:
+                self.pyr.build(persistent=True)
+                for ev in self.rb_ev.values():
+                    ev.record()
+                return
             for lvl in range(4):
                 self._rulebook_level(lvl)
             return
@@ -259,7 +268,7 @@ class InferencePlan:
         if lvl > 0:
             self.rb_ev["down%d" % (lvl - 1)].record()
 
-    def backbone(self, keep_middle=False, anchors_mask=None, densify=True, masks=True):
+    def backbone(self, keep_middle=False, anchors_mask=None, densify=True, masks=True, rulebooks=True, convs=True):
         """7 rulebooks + 14 sparse convs (+ densify).  Two streams: coordinate-only work (rulebook pyramid, anchors_mask) on the
         side stream, features on the main stream, which waits for each rulebook event once.  (Round 5 measured the alternative
         issue order -- pyramid level l+1 issued behind the first conv of level l, so that a conv never waits for more of the
@@ -270,12 +279,15 @@ class InferencePlan:
         if self.overlap:
             self.side.wait_stream(main)                 # voxel coordinates are ready
             with torch.cuda.stream(self.side):
-                self.rulebooks()
+                if rulebooks:
+                    self.rulebooks()
                 if masks:
                     self.anchor_masks(anchors_mask)     # also coordinate-only work
                 self.mask_ev.record()
-        else:
+        elif rulebooks:
             self.rulebooks()
+        if not convs:                                   # (measurement: the rulebook pyramid alone)
+            return
         x = self.mean
         lvl = 0
         cur = 0
@@ -284,13 +296,14 @@ class InferencePlan:
             y = self.feat[cur]
             if kind == "down":
                 lvl += 1
-            if key is not None and self.overlap and key not in waited:
+            if key is not None and self.overlap and rulebooks and key not in waited:
                 main.wait_event(self.rb_ev[key])
                 waited.add(key)
             if kind == "subm" or kind == "down":
-                K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y)
+                K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y,
+                             cfg=self.spconv_cfg)
             else:
-                K.spconv_fwd(x, None, self.n[lvl], self.caps[lvl], wp, 1, cin, cout, scale, shift, True, y)
+                K.spconv_fwd(x, None, self.n[lvl], self.caps[lvl], wp, 1, cin, cout, scale, shift, True, y, cfg=self.spconv_cfg)
             if keep_middle:
                 self.middle[li] = (y.clone(), lvl, cout)
             x = y
@@ -314,11 +327,11 @@ class InferencePlan:
                 keep = i + 1 < 8 and self.chain[i + 1]
                 prev = self.bev[i - 1][3:5] + (True,) if self.chain[i] else None
                 K.conv2d_wino4_chain(None if self.chain[i] else x, prev, wp, self.bev_cin[i], cout, self.cmax, self.B,
-                                     self.H, self.W, scale, shift, True, None if keep else y, self.wino4_ws)
+                                     self.H, self.W, scale, shift, True, None if keep else y, self.wino4_ws, cfg=self.wino4_cfg)
             elif wino == 2:
                 K.conv2d_wino_fwd(x, wp, cout, scale, shift, True, y)
             elif wino == 1:
-                K.conv1x1_gemm_fwd(x, wp, cout, scale, shift, True, y)
+                K.conv1x1_gemm_fwd(x, wp, cout, scale, shift, True, y, cfg=self.wino4_cfg)
             else:
                 K.conv2d_fwd(x, wp, cout, ks, scale, shift, True, y)
             self._seg("bev_conv%d" % i, e0)
@@ -423,6 +436,10 @@ class InferencePlan:
                     self.backbone()
                 elif "sparse" in stages:              # rulebooks + the 14 sparse convs only (roofline measurement)
                     self.backbone(densify=False, masks=False)
+                elif "sparse_convs" in stages:        # the 14 sparse convs on the rulebooks of the previous pass (floor model)
+                    self.backbone(densify=False, masks=False, rulebooks=False)
+                elif "pyramid" in stages:             # the rulebook pyramid alone
+                    self.backbone(densify=False, masks=False, convs=False)
                 if "tail" in stages:
                     self._tail(None)
                 elif self.overlap:

@@ -1,5 +1,5 @@
 """Steady-state phase timing of one training step (wall clock with device syncs between phases, and the same loop
-without syncs) -- tells host-bound from GPU-bound.  usage: python tools/time_train_phases.py [steps]"""
+without syncs) -- tells host-bound from GPU-bound.  usage: python tests/analysis/time_train_phases.py [steps]"""
 import os
 import sys
 import time
@@ -7,7 +7,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402

@@ -14,7 +14,7 @@ def test_argument_validation_returns_error_codes():
     null = None
     assert L.sassd_voxelize(null, 10, 4, null, null, 5, 100, 0, null, null, 3, null, null, 4, null, null, 100, null,
                             null, 0, null) == EINVAL
-    assert L.sassd_spconv_fwd(null, null, null, 0, null, 27, 16, 16, null, null, 0, null, null) == EINVAL
+    assert L.sassd_spconv_fwd(null, null, null, 0, null, 27, 16, 16, null, null, 0, null, 0, null) == EINVAL
     assert L.sassd_conv2d_fwd(null, null, null, null, 0, null, 1, 16, 16, 8, 8, 3, null) == EINVAL
     assert L.sassd_conv2d_fwd(C.c_void_p(16), C.c_void_p(16), null, null, 0, C.c_void_p(16), 1, 16, 16, 8, 8, 5,
                               null) == EINVAL                       # kernel size 5 does not exist on the path

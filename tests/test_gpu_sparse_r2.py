@@ -20,10 +20,12 @@ def _level0(name="k21", seed=0, batch=1):
     return np.concatenate(idx, 0)
 
 
-@pytest.mark.parametrize("batch,staged", [(1, False), (2, True), (8, False)])
-def test_rulebook_pyramid_bit_exact(dev, batch, staged):
+@pytest.mark.parametrize("batch,staged,persistent", [(1, False, False), (2, True, False), (8, False, False),
+                                                     (1, False, True), (2, False, True), (8, False, True)])
+def test_rulebook_pyramid_bit_exact(dev, batch, staged, persistent):
     """All seven VxNet rulebooks + the three down-sampled coordinate sets from ONE pyramid build, bit-exact against
-    the oracle (same bar as the per-op chain); batch 8 exercises the chained scan past the resident-grid size."""
+    the oracle (same bar as the per-op chain); batch 8 exercises the chained scan past the resident-grid size.
+    `persistent`: the one-launch form (phases separated by in-launch grid barriers)."""
     idx0 = _level0("k21" if batch < 8 else "k17", 0, batch)
     shape = (40, 1600, 1408)
     n0 = len(idx0)
@@ -41,7 +43,7 @@ def test_rulebook_pyramid_bit_exact(dev, batch, staged):
             for l in range(4):
                 pyr.build(l, l + 1)
         else:
-            pyr.build()
+            pyr.build(persistent=persistent)
     torch.cuda.synchronize()
     assert int(st.item()) == 0
     ref_idx, ref_shape = idx0, shape
@@ -59,6 +61,56 @@ def test_rulebook_pyramid_bit_exact(dev, batch, staged):
             assert np.array_equal(down[l + 1][:md].cpu().numpy(), nbr_d), "down level %d" % l
             ref_idx, ref_shape = nxt_idx, nxt_shape
     assert ref_shape == (5, 200, 176)
+
+
+def test_rulebook_pyramid_persistent_under_load(dev):
+    """The one-launch pyramid hands data between workgroups INSIDE a launch (agent-scope release / acquire grid barriers):
+    its outputs must equal the phase-per-launch form's bit for bit on every one of 30 builds while two other streams keep
+    the chip unevenly busy (a bandwidth-bound copy and a short-kernel stream), with consumers' caches warm from the
+    previous build -- idle chips and cold caches hide stale hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility)."""
+    idx0 = _level0("k21", 0, 2)
+    shape = (40, 1600, 1408)
+    n0 = len(idx0)
+    caps = [n0 + 11] + [2 * n0 + 64] * 3
+    i32 = torch.int32
+
+    def mk():
+        idx = [torch.zeros(c, 4, dtype=i32, device=dev) for c in caps]
+        idx[0][:n0] = torch.from_numpy(idx0).to(dev)
+        n = [torch.tensor([n0 if l == 0 else -7], dtype=i32, device=dev) for l in range(4)]
+        subm = [torch.full((c, 27), -5, dtype=i32, device=dev) for c in caps]
+        down = [None] + [torch.full((c, 27), -5, dtype=i32, device=dev) for c in caps[1:]]
+        st = K.new_status(dev)
+        return idx, n, subm, down, st, K.RulebookPyramid(idx, n, caps, shape, 2, subm, down, st)
+    ref = mk()
+    ref[5].build()
+    torch.cuda.synchronize()
+    tst = mk()
+    big = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    small = torch.zeros(4096, device=dev)
+    s1, s2, s3 = (torch.cuda.Stream(device=dev) for _ in range(3))
+    for rep in range(30):
+        with torch.cuda.stream(s1):
+            for _ in range(1 + rep % 3):
+                big.add_(1.0)
+        with torch.cuda.stream(s2):
+            for _ in range(20):
+                small.add_(1.0)
+        with torch.cuda.stream(s3):
+            tst[5].build(persistent=True, wgs_per_cu=1 + rep % 4)
+        torch.cuda.synchronize()
+        assert int(tst[4].item()) == 0, "status 0x%x at rep %d" % (int(tst[4].item()), rep)
+        for l in range(4):
+            m = int(ref[1][l].item())
+            assert int(tst[1][l].item()) == m
+            assert torch.equal(tst[0][l][:m], ref[0][l][:m]), "coordinates level %d rep %d" % (l, rep)
+            assert torch.equal(tst[2][l][:m], ref[2][l][:m]), "subm level %d rep %d" % (l, rep)
+            if l:
+                assert torch.equal(tst[3][l][:m], ref[3][l][:m]), "down level %d rep %d" % (l, rep)
+        for l in range(1, 4):                      # poison the outputs: a stale read must not pass on old data
+            tst[2][l].fill_(-5)
+            tst[3][l].fill_(-5)
+            tst[0][l].zero_()
 
 
 def test_rulebook_pyramid_overflow_flag(dev):
@@ -92,8 +144,7 @@ def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
     idx1, nbr_d1, shape1 = orb.conv_rulebook(idx, shape, 1)
     idx2, nbr_d2, shape2 = orb.conv_rulebook(idx1, shape1, 1)
     _, nbr_s = orb.subm_rulebook(idx2, shape2)
-    K.debug_set_spconv(flags)
-    try:
+    with K.default_cfg(spconv=flags):
         for nbr, n_in in ((nbr_s, len(idx2)), (nbr_d2, len(idx1))):
             n = len(nbr)
             g = torch.Generator().manual_seed(cin * 100 + cout)
@@ -116,8 +167,6 @@ def test_spconv_gather_gemm_scatter(dev, cin, cout, mode):
             assert bool((y[n:] == 7.0).all()), "rows past the device row count must stay untouched"
             y2 = K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout)
             assert (y2[:n].cpu() - raw).abs().max().item() < tol
-    finally:
-        K.debug_set_spconv(0)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 5, 8, 9, 10])
@@ -139,14 +188,11 @@ def test_spconv_balanced_kernel_many_blocks(dev, cin, cout, mode):
     nb[:n] = torch.from_numpy(nbr).to(dev)
     nptr = torch.tensor([n], dtype=torch.int32, device=dev)
     wp = K.spconv_pack_weight(w.to(dev))
-    K.debug_set_spconv(mode << 16)
-    try:
+    with K.default_cfg(spconv=mode << 16):
         y = torch.full((cap, cout), 7.0, device=dev)
         K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout, None, None, False, y)
         y2 = y.clone()
         K.spconv_fwd(x.to(dev), nb, nptr, cap, wp, 27, cin, cout, None, None, False, y2)
-    finally:
-        K.debug_set_spconv(0)
     tol = 2e-4 * max(1.0, raw.abs().max().item())
     assert (y[:n].cpu() - raw).abs().max().item() < tol
     assert bool((y[n:] == 7.0).all())
@@ -262,11 +308,8 @@ def test_weight_gradient_formulations_agree(dev):
         dy[:n] = torch.randn(n, cout, generator=g).to(dev)
         new = K.spconv_bwd_weight(x, dy, nbr, n_ptr, cap, cin, cout)
         assert torch.equal(new, K.spconv_bwd_weight(x, dy, nbr, n_ptr, cap, cin, cout))
-        K.debug_set_spconv(32)
-        try:
+        with K.default_cfg(spconv=32):
             old = K.spconv_bwd_weight(x, dy, nbr, n_ptr, cap, cin, cout)
-        finally:
-            K.debug_set_spconv(0)
         err = float((new - old).abs().max()) / float(old.abs().max())
         assert err < 1e-5, (cin, cout, err)
 
@@ -415,12 +458,9 @@ def test_spconv_input_layer_kernel(dev, legacy):
     nb = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
     nb[:n] = torch.from_numpy(nbr).to(dev)
     nptr = torch.tensor([n], dtype=torch.int32, device=dev)
-    K.debug_set_spconv(256 if legacy else 0)
-    try:
+    with K.default_cfg(spconv=256 if legacy else 0):
         y = torch.full((cap, 16), 9.0, device=dev)
         K.spconv_fwd(x.to(dev), nb, nptr, cap, K.spconv_pack_weight(w.to(dev)), 27, 4, 16, scale.to(dev), shift.to(dev), True, y)
-    finally:
-        K.debug_set_spconv(0)
     ref = torch.relu(raw * scale + shift)
     assert (y[:n].cpu() - ref).abs().max().item() < 2e-4 * max(1.0, raw.abs().max().item())
     assert bool((y[n:] == 9.0).all())

@@ -42,7 +42,7 @@ def test_conv2d_wino4(dev, b, cin, cout, hw, relu):
 
 @pytest.mark.parametrize("cfg", [0, 11, 13, 14])
 def test_conv2d_wino4_gemm_geometries(dev, cfg):
-    """The launch geometries of the Winograd GEMM behind sassd_debug_set_wino4 -- 1 = the fp32 MFMA, 0 (default) and 11..14 =
+    """The launch geometries of the Winograd GEMM selected by the per-call cfg word -- 1 = the fp32 MFMA, 0 (default) and 11..14 =
     fp32 products on the bf16 MFMA over exactly-split operands (three bf16 pieces per fp32 value, eight of the nine piece
     products) --
     against torch-CPU conv2d at the bar of the default path, on the KITTI BEV layer and on a ragged multi-image shape with
@@ -59,12 +59,9 @@ def test_conv2d_wino4_gemm_geometries(dev, cfg):
         wp = K.conv2d_wino4_pack_weight(w.to(dev))
         tol = 1e-4 * max(1.0, raw.abs().max().item())
         for c in (1, cfg):
-            K.debug_set_wino4(c, 0)
-            try:
+            with K.default_cfg(wino4=K.wino4_cfg(c)):
                 y = K.conv2d_wino4_fwd(x.to(dev), wp, cout)
                 torch.cuda.synchronize()
-            finally:
-                K.debug_set_wino4(0, 0)
             errs[c] = (y.cpu().double() - raw).abs().max().item()
             assert errs[c] <= tol, (c, shape, errs[c])
         print("wino4 geometry %d %s: max abs err vs fp64 %.2e (fp32 MFMA %.2e, tol %.2e)" % (cfg, shape, errs[cfg], errs[1], tol))
@@ -115,12 +112,9 @@ def test_split_operand_gemm_dynamic_range(dev):
     bound = torch.nn.functional.conv2d(x.double().abs(), w.double().abs())
     errs = {}
     for c in (1, 0):
-        K.debug_set_wino4(c, 0)
-        try:
+        with K.default_cfg(wino4=K.wino4_cfg(c)):
             y = K.conv1x1_gemm_fwd(x.to(dev), wp, cout)
             torch.cuda.synchronize()
-        finally:
-            K.debug_set_wino4(0, 0)
         assert torch.isfinite(y).all()
         errs[c] = ((y.cpu().double() - y64).abs() / bound.clamp(min=1e-300)).max().item()
     print("split-operand GEMM, operands over 2^-40..2^40: max |err| / sum|w||x| = %.2e (fp32 MFMA %.2e)" % (errs[0], errs[1]))

@@ -75,8 +75,7 @@ for kind, cin, cout, key, wp, scale, shift, lvl in layers:
     k = 27 if key else 1
     line = "%-5s %-6s %2d->%2d rows %7d:" % (kind, key or "-", cin, cout, work["n"][lvl])
     for mname, flags in MODES:
-        K.debug_set_spconv(flags)
-        us = timeit(lambda: K.spconv_fwd(x, nbr, plan.n[lvl], plan.caps[lvl], wp, k, cin, cout, scale, shift, True, y))
+        us = timeit(lambda: K.spconv_fwd(x, nbr, plan.n[lvl], plan.caps[lvl], wp, k, cin, cout, scale, shift, True, y, cfg=flags))
         tot[mname] += us
         line += "  %s %7.1f us" % (mname, us)
     print(line)
@@ -87,10 +86,8 @@ for kind, cin, cout, key, wp, scale, shift, lvl in layers:
             bits = ((2, "no-slab"), (4, "no-mfma"), (6, "neither")) if mname == "r3" else \
                    ((4, "no-mfma"), (32, "hot-gather"), (64, "hot-w"), (96, "hot-both"), (100, "skeleton"))
             for bit, nm in bits:
-                K.debug_set_spconv(base | bit)
                 s += "  %s %6.1f" % (nm, timeit(lambda: K.spconv_fwd(x, nbr, plan.n[lvl], plan.caps[lvl], wp, k, cin,
-                                                                      cout, scale, shift, True, y)))
+                                                                      cout, scale, shift, True, y, cfg=base | bit)))
             print(s)
-K.debug_set_spconv(0)
 print("sum of 14 layers:", {m: round(v, 1) for m, v in tot.items()}, "us;  bytes_gs GB/s:",
       {m: round(work["bytes_gs"] / v / 1e3, 1) for m, v in tot.items()})

@@ -23,7 +23,7 @@ ap.add_argument("--no-overlap", action="store_true", help="rulebooks on the main
 ap.add_argument("--spconv-cfg", type=int, default=0, help="kernel / workgroup geometry switch of the sparse conv (spconv.hip)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-K.debug_set_spconv(args.spconv_cfg << 16)
+K.DEFAULT_CFG["spconv"] = K.spconv_cfg(args.spconv_cfg)      # host-side default of the binding: passed per call
 w = synth.workload(args.config)
 B = args.batch or w["batch"]
 model, _ = synth.build_detector_for(w, 0)

@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--cin", type=int, default=256)
 ap.add_argument("--reps", type=int, default=30)
-ap.add_argument("--cfgs", default="", help="comma-separated geometry numbers of sassd_debug_set_wino4 (default: all)")
+ap.add_argument("--cfgs", default="", help="comma-separated geometry numbers of the Winograd cfg word (include/sassd.h) (default: all)")
 ap.add_argument("--profile", action="store_true", help="default geometry only, `reps` launches: the target of rocprofv3 "
                 "--kernel-trace / --pmc passes")
 args = ap.parse_args()
@@ -65,14 +65,13 @@ for cfg in cfgs:
     split = cfg >= 11 or cfg == 0
     modes = ((0, "full"), (1, "no-dma"), (4, "no-split-valu")) if split else ((0, "full"), (1, "no-dma"), (2, "no-mfma"), (3, "neither"))
     for dbg, nm in modes:
-        _C.lib().sassd_debug_set_wino4(cfg, dbg)
-        t4 = timeit(lambda: K.conv2d_wino4_fwd(x, w4, 256, sc, sh, True, y, ws))
+        word = K.wino4_cfg(cfg, dbg)
+        t4 = timeit(lambda: K.conv2d_wino4_fwd(x, w4, 256, sc, sh, True, y, ws, cfg=word))
         line += "  %s %6.1f us" % (nm, t4)
         if dbg == 0:
             line += " (%.0f TF eq, err vs F(2x2) %.1e, vs fp64 %.2e rms %.2e)" % (
                 flops / t4 / 1e6, (y - ref).abs().max().item(), (y.double() - ref64).abs().max().item(),
                 (y.double() - ref64).pow(2).mean().sqrt().item())
     print(line, flush=True)
-_C.lib().sassd_debug_set_wino4(0, 0)
 t2 = timeit(lambda: K.conv2d_wino_fwd(x, w2, 256, sc, sh, True, y))
 print("F(2x2) fused: %.1f us (%.1f TF direct-equivalent)" % (t2, flops / t2 / 1e6))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time the Winograd GEMM launch alone (36 GEMMs 256 x 256 x tiles, B=1 @200x176) on a random transformed input, with the
-A/B and ablation switches of sassd_debug_set_wino4:   python tools/run_wino4_gemm.py [--reps 100]"""
+A/B and ablation switches of the Winograd cfg word:   python tools/run_wino4_gemm.py [--reps 100]"""
 import argparse
 import json
 import os
@@ -27,8 +27,8 @@ sc, sh = torch.ones(256, device=dev), torch.zeros(256, device=dev)
 
 
 def timed(flags):
-    K.debug_set_wino4(0, flags)
-    call = lambda: K.conv2d_wino4_chain(None, (sc, sh, True), w4, 256, 256, 256, B, H, W, sc, sh, True, None, ws)  # noqa: E731
+    call = lambda: K.conv2d_wino4_chain(None, (sc, sh, True), w4, 256, 256, 256, B, H, W, sc, sh, True, None, ws,  # noqa: E731
+                                        cfg=K.wino4_cfg(0, flags))
     for _ in range(max(10, a.reps // 2)):
         call()
     torch.cuda.synchronize()
@@ -38,7 +38,6 @@ def timed(flags):
         call()
     e1.record()
     torch.cuda.synchronize()
-    K.debug_set_wino4(0, 0)
     return e0.elapsed_time(e1) / a.reps
 
 

@@ -472,6 +472,10 @@ def main():
                     "replaying the captured hipGraph (A/B)")
     ap.add_argument("--pyramid", choices=("levels", "persistent"), default=PYRAMID_DEFAULT, help="rulebook pyramid: two "
                     "launches per level, or ONE persistent launch with in-launch grid barriers (A/B)")
+    ap.add_argument("--rb-sync", default="1,3", help="rulebook levels at which the feature stream joins the coordinate stream "
+                    "(A/B: 0,1,2,3 = one wait per level, the round 2-5 form)")
+    ap.add_argument("--dense-conv0", action="store_true", help="BEV conv0 on every tile instead of the active tiles of the "
+                    "sparse map only (A/B)")
     ap.add_argument("--no-extra", action="store_true", help="default (car) run: skip the `infer_multi` / `infer_waymo` / "
                     "`train_waymo` records (BASELINE configs[3] / [4]) that follow the headline measurement")
     args = ap.parse_args()
@@ -490,7 +494,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from sassd import kernels as K0
-    plan_cfg = dict(spconv_cfg=K0.spconv_cfg(args.spconv_cfg), wino4_cfg=K0.wino4_cfg(args.wino4_cfg))   # per-call words
+    plan_cfg = dict(spconv_cfg=K0.spconv_cfg(args.spconv_cfg), wino4_cfg=K0.wino4_cfg(args.wino4_cfg),   # per-call words
+                    rb_sync_levels=tuple(int(v) for v in args.rb_sync.split(",")), skip_inactive_tiles=not args.dense_conv0)
     model, w = build_model(0, dev, args.config)
     B = args.batch if args.batch > 0 else w["batch"]
     S = max(1, args.inflight)

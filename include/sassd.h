@@ -80,6 +80,7 @@ int sassd_graph_destroy(void *graph_exec);
  *               row_offset[1] = row_offset[0] + voxel_num is written back (batch concatenation,
  *               detectors/single_stage.py:52-73 merge_second_batch).
  *   voxel_num   device int32 scalar: number of voxels of THIS cloud
+ *   workspace   16-byte aligned (its tables are cleared by 16-byte stores; SASSD_EINVAL otherwise)
  * ---------------------------------------------------------------------------------------------- */
 size_t sassd_voxelize_workspace_bytes(int n_points, int max_points);
 int sassd_voxelize(const float *points, int n_points, int ndim, const float *voxel_size,
@@ -197,6 +198,15 @@ int sassd_conv2d_fwd(const float *x, const float *w_packed, const float *scale, 
                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, int ksize,
                      void *stream);
 
+/* 1x1 convolution with <= 32 output channels (the fused SSD head, ssd_rotate_head.py:120-125; the second conv of the
+ * part-sensitive head, :424-429) as an HBM stream on the vector ALU: same contract as sassd_conv2d_fwd with ksize 1, but
+ * the weights are handed over TRANSPOSED and zero-padded, wT [Cin][CO] fp32, CO = sassd_conv1x1_narrow_pad(Cout), 16-byte
+ * aligned. */
+int sassd_conv1x1_narrow_supported(int Cin, int Cout);
+int sassd_conv1x1_narrow_pad(int Cout);
+int sassd_conv1x1_narrow_fwd(const float *x, const float *wT, const float *scale, const float *shift, int relu,
+                             float *y, int batch, int Cin, int Cout, int H, int W, void *stream);
+
 /* Winograd F(2x2,3x3) variant of the 3x3 / stride 1 / pad 1 convolution (the BEVNet layers cmn.py:240-262): 2.25x
  * fewer multiplications on the fp32 MFMA, transforms fused (nothing but x, packed weights and y touches HBM).  Same
  * epilogue as sassd_conv2d_fwd (y = relu?(conv * scale[co] + shift[co]), NULL scale/shift = 1/0).  Requires
@@ -239,8 +249,18 @@ int sassd_conv2d_wino4_chain_supported(int Cin, int Cout, int H, int W);
 size_t sassd_conv2d_wino4_chain_workspace_bytes(int batch, int cmax, int H, int W);
 int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev_scale, const float *prev_shift,
                              int prev_relu, const float *w_packed, const float *scale, const float *shift, int relu,
-                             float *y, int batch, int Cin, int Cout, int cmax, int H, int W, int cfg, void *workspace,
-                             size_t workspace_bytes, void *stream);
+                             float *y, int batch, int Cin, int Cout, int cmax, int H, int W, const int32_t *tile_map,
+                             const int32_t *prev_tile_map, int cfg, void *workspace, size_t workspace_bytes,
+                             void *stream);
+/* Active-tile map of a SPARSE input map (BEVNet conv0 reads SparseConvTensor.dense(), cmn.py:112-114,240: 56 % of the 4x4
+ * tiles of a KITTI frame have an occupied pixel in their 6x6 patch).  indices [cap,4] (b, z, y, x) = the sparse rows that
+ * were densified.  A chain call with `tile_map` (src_products == 0) transforms and multiplies the active tiles only
+ * (compacted columns); the NEXT chain call passes the same map as `prev_tile_map` (or this call, with y != NULL, its own):
+ * an inactive tile's products are exactly zero, so the result is bit-identical to the dense launch.  NULL = all tiles.
+ * tile_map: sassd_wino4_tile_map_ints(batch, H, W) int32 (0 = unsupported: more than 65536 tiles). */
+size_t sassd_wino4_tile_map_ints(int batch, int H, int W);
+int sassd_wino4_tile_map(const int32_t *indices, const int32_t *n_ptr, int cap, int batch, int H, int W,
+                         int32_t *tile_map, void *stream);
 
 /* 1x1 convolution with >= 128 output channels (BEVNet conv7, cmn.py:262) as a plain fp32-MFMA GEMM over the NCHW
  * tensor (y[b] [Cout x HW] = W [Cout x Cin] . x[b] [Cin x HW]) with the folded BatchNorm / bias / ReLU epilogue; the

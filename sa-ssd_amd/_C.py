@@ -95,6 +95,9 @@ _SIGS = {
     "sassd_conv2d_wino4_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_conv1x1_gemm_supported": (_I, [_I, _I, _I, _I]),
     "sassd_conv1x1_gemm_pack_weight": (_I, [_P, _I, _I, _P, _P]),
+    "sassd_conv1x1_narrow_supported": (_I, [_I, _I]),
+    "sassd_conv1x1_narrow_pad": (_I, [_I]),
+    "sassd_conv1x1_narrow_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv1x1_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_bf16_supported": (_I, [_I, _I, _I, _I]),
     "sassd_debug_set_bf16": (None, [_I]),
@@ -137,7 +140,9 @@ _SIGS = {
     "sassd_focal_loss": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "sassd_conv2d_wino4_chain_supported": (_I, [_I, _I, _I, _I]),
     "sassd_conv2d_wino4_chain_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
-    "sassd_conv2d_wino4_chain": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "sassd_conv2d_wino4_chain": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _SZ, _P]),
+    "sassd_wino4_tile_map_ints": (_SZ, [_I, _I, _I]),
+    "sassd_wino4_tile_map": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "sassd_gather_pack": (_I, [_P, _P, _P, C.c_long, _I, _P]),
     "sassd_grad_sumsq": (_I, [_P, C.c_long, _P, _P]),
     "sassd_adam_step": (_I, [_P, _P, _P, _P, C.c_long, _P, _F, _F, _F, _F, _F, _I, _F, _F, _P]),

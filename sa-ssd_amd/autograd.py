@@ -65,14 +65,24 @@ class _PackCache(dict):
     tensor's and the lookup would return the dead tensor's image (round 5: the sparse data gradient of the third 64 -> 64 layer
     a test created was computed with the first one's transposed weights; models built through build_detector bump the
     generation, hand-made layers and tests do not).  So an entry PINS the tensor it was packed from: while the entry exists
-    that storage cannot be freed, hence no other tensor can sit on its address.  Bounded (the oldest entries go first; a
-    dropped entry only costs a re-pack)."""
+    that storage cannot be freed, hence no other tensor can sit on its address.  Bounded, LEAST RECENTLY USED first (ADVICE r05:
+    insertion order dropped the long-lived parameter packs a PackPlan installs first once 256 transient keys had piled up):
+    every hit and every put moves the key to the young end; a dropped entry only costs a re-pack."""
     MAX = 256
 
+    def get(self, key, default=None):
+        hit = dict.get(self, key, default)
+        if hit is not default and key in self:
+            dict.__delitem__(self, key)                     # re-insert: dicts keep insertion order, the front is the oldest
+            dict.__setitem__(self, key, hit)
+        return hit
+
     def put(self, key, gen, pack, source):
-        if key not in self and len(self) >= self.MAX:
+        if key in self:
+            dict.__delitem__(self, key)
+        elif len(self) >= self.MAX:
             for k in list(self)[:self.MAX // 4]:
-                del self[k]
+                dict.__delitem__(self, k)
         self[key] = (gen, pack, source)
 
 
@@ -90,7 +100,9 @@ def _spconv_t_pack(weight, reverse=False):
         return hit[1]
     w = weight.detach()
     pack = K.spconv_pack_weight_t((w.flip(0) if reverse else w).contiguous())
-    _sp_t_packs.put(key, gen, pack, weight)
+    # the entry pins the STORAGE (so that no other tensor can land on the address), not the autograd graph: the weight handed
+    # in is a view of the module parameter (grad_fn = a view node) -- pinning it would keep that graph alive
+    _sp_t_packs.put(key, gen, pack, w if weight.grad_fn is not None else weight)
     return pack
 
 

@@ -59,8 +59,12 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(BnFwdArgs P)
     double ds[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
     f32x4 fs = {0.f, 0.f, 0.f, 0.f}, fq = fs;
     int cnt = 0;
+    // sums of (x - shift), shift = the channel's value in row 0: with fp32 partial sums of x^2 a channel whose
+    // |mean| >> std lost its variance to the cancellation E[x^2] - mean^2 (mean 40, var 1e-2: ~1 % error in invstd); any
+    // value of the channel is within a few std of its mean, so the shifted sums have nothing to cancel
+    const f32x4 sh = P.n > 0 ? ((const f32x4 *)P.x)[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int row = r0 + r; row < r1; row += rl) {
-        const f32x4 v = ((const f32x4 *)P.x)[(size_t)row * C4 + c4];
+        const f32x4 v = ((const f32x4 *)P.x)[(size_t)row * C4 + c4] - sh;
         fs += v;
         fq += v * v;
         if (++cnt == 16) {
@@ -114,9 +118,10 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(BnApplyArgs P)
     double ss, qq;
     bn_reduce_channel(P.part, P.nb, P.C, c, red, ss, qq);
     if (threadIdx.x == 0) {
-        const double mean = ss / P.n;
-        double var = qq / P.n - mean * mean;
+        const double ms = ss / P.n;                          // mean of (x - shift): see bn_stats_kernel
+        double var = qq / P.n - ms * ms;
         if (var < 0.0) var = 0.0;
+        const double mean = (P.n > 0 ? (double)P.x[c] : 0.0) + ms;
         P.mean[c] = (float)mean;
         P.invstd[c] = (float)(1.0 / sqrt(var + (double)P.eps));
         if (P.rmean) {

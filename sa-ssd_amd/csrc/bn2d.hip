@@ -53,12 +53,15 @@ __global__ void __launch_bounds__(256) bn2d_stats_kernel(Bn2dArgs P)
     const int c = blockIdx.x / P.S, s = blockIdx.x - c * P.S;
     const int i0 = s * P.chunk, i1 = min(i0 + P.chunk, P.HW);
     double ds = 0.0, dq = 0.0;
+    // sums of (x - shift), shift = the channel's first element: fp32 partial sums of x^2 would lose the variance of a channel
+    // whose |mean| >> std to the cancellation E[x^2] - mean^2 (ADVICE r05 on the sparse twin of this kernel)
+    const float sh = P.x[(size_t)c * P.HW];
     for (int b = 0; b < P.B; ++b) {
         const float *plane = P.x + ((size_t)b * P.C + c) * P.HW;
         float fs = 0.f, fq = 0.f;
         int cnt = 0;
         for (int i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
-            const f32x4 v = *(const f32x4 *)(plane + i);
+            const f32x4 v = *(const f32x4 *)(plane + i) - sh;
             fs += (v[0] + v[1]) + (v[2] + v[3]);
             fq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
             if (++cnt == 16) { ds += (double)fs; dq += (double)fq; fs = fq = 0.f; cnt = 0; }
@@ -82,9 +85,10 @@ __global__ void __launch_bounds__(256) bn2d_apply_kernel(Bn2dArgs P)
         qq += P.part[((size_t)c * P.S + k) * 2 + 1];
     }
     const double n = (double)P.B * (double)P.HW;
-    const double mean = ss / n;
-    double var = qq / n - mean * mean;
+    const double ms = ss / n;                                // mean of (x - shift): see bn2d_stats_kernel
+    double var = qq / n - ms * ms;
     if (var < 0.0) var = 0.0;
+    const double mean = (double)P.x[(size_t)c * P.HW] + ms;
     const float m = (float)mean, is = (float)(1.0 / sqrt(var + (double)P.eps));
     const float sc = is * P.gamma[c], sh = P.beta[c];
     if (s == 0 && threadIdx.x == 0) {

@@ -45,7 +45,9 @@ static inline int sassd_dyn_lds(const void *fn, size_t bytes, std::atomic<unsign
 
 // Two byte-pattern fills in ONE launch (a workspace that needs an all-ones hash table next to zeroed counters took two
 // hipMemsetAsync calls = two __amd_rocclr_fillBufferAligned launches per call: 6 per inference frame in the round-4 trace).
-// Both regions 16-byte aligned with sizes that are multiples of 16 (every workspace segment is 256-byte aligned).
+// Both regions 16-byte aligned with sizes that are multiples of 16 (every workspace segment is 256-byte aligned): an ABI
+// precondition of the entry points that clear through it (sassd_voxelize, sassd_rulebook_pyramid -- stated in
+// include/sassd.h; SASSD_EINVAL before any launch otherwise; hipMemsetAsync, which it replaced, took any pointer).
 static __global__ void sassd_fill2_kernel(uint4 *a, size_t na16, unsigned pa, uint4 *b, size_t nb16, unsigned pb)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -60,7 +62,7 @@ static inline int sassd_fill2(void *a, size_t abytes, unsigned char pa, void *b,
     if (((uintptr_t)a | (uintptr_t)b | abytes | bbytes) & 15) return SASSD_EINVAL;
     const size_t n16 = (abytes + bbytes) / 16;
     if (n16 == 0) return SASSD_OK;
-    size_t blocks = (n16 + 4 * 256 - 1) / (4 * 256);             // <= 4 stores per thread
+    size_t blocks = (n16 + 4 * 256 - 1) / (4 * 256);             // 4 stores per thread up to 16 MB, then a grid-stride loop
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sassd_fill2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4 *)a, abytes / 16, 0x01010101u * pa,
                        (uint4 *)b, bbytes / 16, 0x01010101u * pb);

@@ -464,3 +464,94 @@ extern "C" int sassd_conv2d_fwd(const float *x, const float *w_packed, const flo
     }
 #undef SASSD_CONV_GO
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1x1 convolution with FEW output channels (<= 32): the fused SSD head (ssd_rotate_head.py:120-125: 14 + 2 + 4 = 20 maps
+// from 256 channels) and the second conv of the part-sensitive head (:424-429, 28 -> 28).  y [Cout x HW] = W [Cout x Cin]
+// x [Cin x HW] is 0.36 GFLOP over a 36 MB input: an HBM stream (7 us), not a matrix-core problem -- on the generic MFMA
+// kernel (32-cout tile, four waves splitting K, 10 MFMAs between barriers) the two launches took 19-24 us each.  Here a
+// workgroup owns 64 consecutive pixels; wave w streams its quarter of the input channels (one coalesced 256-byte row
+// segment per channel, 8 in flight) and multiplies each value by the channel's Cout weights, which sit in SGPRs (the weight
+// row index is wave-uniform: scalar loads, v_fmac with a scalar operand -- no LDS, no operand shuffles); the four partial
+// sums meet in LDS in wave order (a fixed summation order).  wT is the weight TRANSPOSED and zero-padded to the kernel's
+// channel count, [Cin][CO] fp32 with CO = sassd_conv1x1_narrow_pad(Cout) (whole 16-byte scalar loads per weight row).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int CO>
+__global__ void __launch_bounds__(256) conv1x1_narrow_kernel(const float *__restrict__ x, const float *__restrict__ wT,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             int relu, float *__restrict__ y, int Cin, int Cout, int HW)
+{
+    __shared__ float part[4][CO][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 64 + lane;
+    const bool ok = p < HW;
+    const int pc = ok ? p : HW - 1;
+    const int cq = (Cin + 3) / 4;
+    const int c0 = wave * cq, c1 = min(c0 + cq, Cin);
+    const float *xp = x + ((size_t)b * Cin + c0) * HW + pc;
+    float acc[CO];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) acc[j] = 0.f;
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)u * HW];
+        xp += (size_t)8 * HW;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float *wr = wT + (size_t)(c + u) * CO;            // wave-uniform: scalar loads
+#pragma unroll
+            for (int j = 0; j < CO; ++j) acc[j] = fmaf(v[u], wr[j], acc[j]);
+        }
+    }
+    for (; c < c1; ++c) {
+        const float v = *xp;
+        xp += HW;
+        const float *wr = wT + (size_t)c * CO;
+#pragma unroll
+        for (int j = 0; j < CO; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < CO; ++j) part[wave][j][lane] = acc[j];
+    __syncthreads();
+    for (int j = wave; j < Cout; j += 4) {
+        float s = (part[0][j][lane] + part[1][j][lane]) + (part[2][j][lane] + part[3][j][lane]);
+        s = s * (scale ? scale[j] : 1.f) + (shift ? shift[j] : 0.f);
+        if (relu) s = fmaxf(s, 0.f);
+        if (ok) y[((size_t)b * Cout + j) * HW + p] = s;
+    }
+}
+}  // namespace
+
+extern "C" int sassd_conv1x1_narrow_supported(int Cin, int Cout) { return Cin >= 1 && Cout >= 1 && Cout <= 32 ? 1 : 0; }
+
+// padded channel count of the weight image [Cin][CO] (the kernel instantiations: 8, 16, 20, 24, 28, 32)
+extern "C" int sassd_conv1x1_narrow_pad(int Cout)
+{
+    return Cout <= 8 ? 8 : Cout <= 16 ? 16 : Cout <= 20 ? 20 : Cout <= 24 ? 24 : Cout <= 28 ? 28 : 32;
+}
+
+extern "C" int sassd_conv1x1_narrow_fwd(const float *x, const float *wT, const float *scale, const float *shift, int relu,
+                                        float *y, int batch, int Cin, int Cout, int H, int W, void *stream_)
+{
+    if (!x || !wT || !y || batch < 1 || H < 1 || W < 1 || !sassd_conv1x1_narrow_supported(Cin, Cout)) return SASSD_EINVAL;
+    const int HW = H * W;
+    const dim3 grid((unsigned)cdiv(HW, 64), (unsigned)batch);
+    hipStream_t s = (hipStream_t)stream_;
+#define SASSD_NARROW(CO) hipLaunchKernelGGL((conv1x1_narrow_kernel<CO>), grid, dim3(256), 0, s, x, wT, scale, shift, relu, y, Cin, Cout, HW)
+    if (((uintptr_t)wT) & 15) return SASSD_EINVAL;
+    switch (sassd_conv1x1_narrow_pad(Cout)) {
+    case 8: SASSD_NARROW(8); break;
+    case 16: SASSD_NARROW(16); break;
+    case 20: SASSD_NARROW(20); break;
+    case 24: SASSD_NARROW(24); break;
+    case 28: SASSD_NARROW(28); break;
+    default: SASSD_NARROW(32); break;
+    }
+#undef SASSD_NARROW
+    return sassd_launch_status();
+}

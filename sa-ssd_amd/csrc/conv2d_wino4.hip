@@ -89,16 +89,22 @@ __device__ __forceinline__ void bt_vec(const float (&d)[6], float (&o)[6])
 }
 
 struct W4Geom { int B, C, H, W, TH, TW, T, Tp; };
+constexpr int kTmapHead = 4;       // tile map: [0] active tiles, [1..3] reserved, then tpos[T] (column of tile t or -1), tlist[T]
 
 // one thread = one (channel, tile): 36 loads (neighbouring threads' patches overlap: L1); the 36 x 256 results of a
 // workgroup go through LDS so that every plane row leaves as 16-byte stores (dword stores cost ~6x more per byte)
-__global__ void __launch_bounds__(256) wino4_in_kernel(const float *__restrict__ x, W4Geom G, float *__restrict__ V)
+// `tmap` (optional, sassd_wino4_tile_map): only the ACTIVE tiles are transformed, column j of V = tile tlist[j]
+__global__ void __launch_bounds__(256) wino4_in_kernel(const float *__restrict__ x, W4Geom G, float *__restrict__ V,
+                                                       const int32_t *__restrict__ tmap)
 {
     __shared__ __attribute__((aligned(16))) float tr[36 * 256];
     const int t0 = blockIdx.x * 256;
-    const int t = t0 + threadIdx.x;
+    const int nt = tmap ? tmap[0] : G.T;                  // columns in use
+    if (t0 >= nt) return;                                 // (uniform)
+    const int j = t0 + threadIdx.x;
     const int c = blockIdx.y;
-    if (t < G.T) {
+    if (j < nt) {
+        const int t = tmap ? tmap[kTmapHead + G.T + j] : j;
         const int tpi = G.TH * G.TW;
         const int b = t / tpi, r = t - b * tpi;
         const int ty = r / G.TW, tx = r - ty * G.TW;
@@ -160,20 +166,21 @@ __device__ __forceinline__ void at_vec(const float (&m)[6], float (&o)[4])
 __global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict__ M, W4Geom G, int Cout,
                                                         const float *__restrict__ scale,
                                                         const float *__restrict__ shift, int relu,
-                                                        float *__restrict__ y)
+                                                        float *__restrict__ y, const int32_t *__restrict__ tmap)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int co = blockIdx.y;
     if (t >= G.T) return;
     const size_t plane = (size_t)Cout * G.Tp;
-    const float *src = M + (size_t)co * G.Tp + t;
+    const int col = tmap ? tmap[kTmapHead + t] : t;       // compacted launch: an inactive tile's products are exactly zero
+    const float *src = M + (size_t)co * G.Tp + (col < 0 ? 0 : col);
     float v[4][6];                                    // A^T m : 4 rows x 6 columns
     {
         float m[6][6];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) m[i][j] = src[(size_t)(i * 6 + j) * plane];
+            for (int j = 0; j < 6; ++j) m[i][j] = col < 0 ? 0.f : src[(size_t)(i * 6 + j) * plane];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
@@ -212,7 +219,7 @@ __global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict_
 __global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restrict__ M, W4Geom G,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu, int pitch,
-                                                          float *__restrict__ V)
+                                                          float *__restrict__ V, const int32_t *__restrict__ tmap)
 {
     extern __shared__ __attribute__((aligned(16))) float w4_plane[];
     const int c = blockIdx.x, b = blockIdx.y;
@@ -224,14 +231,16 @@ __global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restric
     const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
     // ---- phase 1: A^T M A + epilogue -> LDS plane (pixel (y, x) at [(y + 1) * pitch + x + 1]) ------------------------
     for (int t = threadIdx.x; t < tpi; t += 256) {
-        const float *src = M + (size_t)c * G.Tp + (size_t)b * tpi + t;
+        // products of an inactive tile of the previous layer's (compacted) launch are exactly zero: nothing to load
+        const int col = tmap ? tmap[kTmapHead + b * tpi + t] : b * tpi + t;
+        const float *src = M + (size_t)c * G.Tp + (col < 0 ? 0 : col);
         float v[4][6];
         {
             float m[6][6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) m[i][j] = src[(size_t)(i * 6 + j) * plane];
+                for (int j = 0; j < 6; ++j) m[i][j] = col < 0 ? 0.f : src[(size_t)(i * 6 + j) * plane];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const float col[6] = {m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j]};
@@ -324,6 +333,7 @@ struct W4Gemm {
     int nseg, seglen;        // every (problem, channel block) pair is cut into nseg runs of seglen column blocks
     int pairs_per_xcd;       // (pair, run) items per XCD
     int dbg;                 // ablation: bit0 stage only the first chunk, bit1 no MFMA
+    const int32_t *ncols_dev;  // optional: columns in use (device count; column blocks past it leave at once)
 };
 
 // ---- fp32 products on the bf16 MFMA (SPLIT = 1) ------------------------------------------------------------------------
@@ -406,6 +416,7 @@ __global__ void __launch_bounds__(WM * WN * 64) wino4_gemm_kernel(W4Gemm P)
     if (item >= P.np * P.nmb * P.nseg) return;
     const int pair = item / P.nseg, nb = (item - pair * P.nseg) * P.seglen + within;
     if (nb >= P.nnb) return;
+    if (P.ncols_dev && nb * BN >= *P.ncols_dev) return;                    // (uniform) compacted launch: unused column block
     const int p = pair / P.nmb, mb = pair - p * P.nmb;
     const float *Ub = P.U + (size_t)p * P.su + mb * BM;                    // + k * Cout
     const float *Vb = P.V + (size_t)p * P.sv + nb * BN;                    // + k * ldv
@@ -708,9 +719,9 @@ extern "C" int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, con
     // the padding columns of V feed padding columns of M that the output transform never reads; they only have to be
     // finite-or-not-read: the GEMM's columns are independent, so stale values cannot leak into real tiles
     if (!(dbg & 16))
-        hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V);
+        hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V, (const int32_t *)nullptr);
     W4Gemm P;
-    P.U = w_packed; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0;
+    P.U = w_packed; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0; P.ncols_dev = nullptr;
     P.np = 36; P.Cin = Cin; P.Cout = Cout; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;
     P.su = (size_t)Cin * Cout; P.sv = (size_t)Cin * G.Tp; P.sm = (size_t)Cout * G.Tp;
     int rc = SASSD_OK;
@@ -720,7 +731,7 @@ extern "C" int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, con
     Go.C = Cout;
     if (!(dbg & 64))
         hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
-                           scale, shift, relu, y);
+                           scale, shift, relu, y, (const int32_t *)nullptr);
     return sassd_launch_status();
 }
 
@@ -746,10 +757,14 @@ extern "C" size_t sassd_conv2d_wino4_chain_workspace_bytes(int batch, int cmax, 
 extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev_scale,
                                         const float *prev_shift, int prev_relu, const float *w_packed,
                                         const float *scale, const float *shift, int relu, float *y, int batch, int Cin,
-                                        int Cout, int cmax, int H, int W, int cfg, void *workspace,
+                                        int Cout, int cmax, int H, int W, const int32_t *tile_map,
+                                        const int32_t *prev_tile_map, int cfg, void *workspace,
                                         size_t workspace_bytes, void *stream_)
 {
     const int geo = w4_geo(cfg), dbg = w4_dbg(cfg);
+    // tile_map: this layer runs on the ACTIVE tiles of its input only (needs the NCHW input, src_products == 0);
+    // prev_tile_map: the previous chain call did, and left compacted products (needs src_products != 0)
+    if ((tile_map && src_products) || (prev_tile_map && !src_products)) return SASSD_EINVAL;
     if (!w_packed || !workspace || batch < 1 || !sassd_conv2d_wino4_supported(Cin, Cout, H, W) || cmax < Cin ||
         cmax < Cout || (!src_products && !x))
         return SASSD_EINVAL;
@@ -769,7 +784,7 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
     float *M = (float *)((char *)workspace + need / 2);
     if (!src_products) {
         if (!(dbg & 16))
-            hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V);
+            hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V, tile_map);
     } else if (!(dbg & 128)) {
         // the previous call left M [36][Cin][Tp] (its Cout = this Cin, same tile geometry) in the workspace
         static std::atomic<unsigned long long> attr_done{0};
@@ -777,10 +792,10 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
         int rc = sassd_dyn_lds((const void *)wino4_outin_kernel, (size_t)160 * 1024, attr_done);   // once, for any plane
         if (rc) return rc;
         hipLaunchKernelGGL(wino4_outin_kernel, dim3(Cin, batch), dim3(256), lds, stream, (const float *)M, G, prev_scale,
-                           prev_shift, prev_relu, w4_plane_pitch(W), V);
+                           prev_shift, prev_relu, w4_plane_pitch(W), V, prev_tile_map);
     }
     W4Gemm P;
-    P.U = w_packed; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0;
+    P.U = w_packed; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0; P.ncols_dev = tile_map;
     P.np = 36; P.Cin = Cin; P.Cout = Cout; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;
     P.su = (size_t)Cin * Cout; P.sv = (size_t)Cin * G.Tp; P.sm = (size_t)Cout * G.Tp;
     int rc = SASSD_OK;
@@ -790,8 +805,67 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
         W4Geom Go = G;
         Go.C = Cout;
         hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
-                           scale, shift, relu, y);
+                           scale, shift, relu, y, tile_map);
     }
+    return sassd_launch_status();
+}
+
+// ---- active-tile map of a SPARSE input map (BEV conv0 reads the densified sparse tensor: 17 % of its pixels / 56 % of its
+// 4x4-tile patches are occupied on a KITTI frame) -------------------------------------------------------------------------
+// A tile is active when any occupied pixel lies in its 6x6 input patch; inactive tiles have all-zero transformed input,
+// all-zero products and the output relu(shift) -- exactly what the dense launch computes for them, so skipping them is
+// bit-identical.  One workgroup: flags in LDS (benign same-value byte stores), ordered compaction by a block scan.
+namespace {
+__global__ void __launch_bounds__(1024) w4_tile_map_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ n_ptr,
+                                                           int cap, int B, int H, int W, int TH, int TW,
+                                                           int32_t *__restrict__ tmap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char w4_flags[];
+    __shared__ int wsum[17];
+    const int T = B * TH * TW;
+    for (int i = threadIdx.x; i < (T + 3) / 4; i += 1024) ((unsigned *)w4_flags)[i] = 0u;
+    __syncthreads();
+    const int n = min(*n_ptr, cap);
+    for (int r = threadIdx.x; r < n; r += 1024) {
+        const int4 c = ((const int4 *)idx)[r];               // (b, z, y, x)
+        if (c.x < 0 || c.x >= B || c.z < 0 || c.z >= H || c.w < 0 || c.w >= W) continue;
+        // pixel y lies in the patch rows 4 ty - 1 .. 4 ty + 4 of tile ty = y / 4, of ty - 1 when y % 4 == 0, of ty + 1 when y % 4 == 3
+        const int ty = c.z >> 2, tx = c.w >> 2;
+        const int y0 = ((c.z & 3) == 0 && ty > 0) ? ty - 1 : ty, y1 = ((c.z & 3) == 3 && ty + 1 < TH) ? ty + 1 : ty;
+        const int x0 = ((c.w & 3) == 0 && tx > 0) ? tx - 1 : tx, x1 = ((c.w & 3) == 3 && tx + 1 < TW) ? tx + 1 : tx;
+        for (int a = y0; a <= y1; ++a)
+            for (int e = x0; e <= x1; ++e) w4_flags[(c.x * TH + a) * TW + e] = 1;
+    }
+    __syncthreads();
+    const int per = (T + 1023) / 1024;
+    const int t0 = min((int)threadIdx.x * per, T), t1 = min(t0 + per, T);
+    int cnt = 0;
+    for (int t = t0; t < t1; ++t) cnt += w4_flags[t];
+    int total;
+    int j = block_exclusive_scan(cnt, wsum, &total);
+    for (int t = t0; t < t1; ++t) {
+        const bool on = w4_flags[t] != 0;
+        tmap[kTmapHead + t] = on ? j : -1;
+        if (on) tmap[kTmapHead + T + j++] = t;
+    }
+    if (threadIdx.x == 0) { tmap[0] = total; tmap[1] = T; tmap[2] = tmap[3] = 0; }
+}
+}  // namespace
+
+extern "C" size_t sassd_wino4_tile_map_ints(int batch, int H, int W)
+{
+    if (batch < 1 || H < 4 || W < 4 || H % 4 || W % 4) return 0;
+    const size_t T = (size_t)batch * (H / 4) * (W / 4);
+    return T <= 65536 ? kTmapHead + 2 * T : 0;               // (the flags of all tiles live in one workgroup's LDS)
+}
+
+extern "C" int sassd_wino4_tile_map(const int32_t *indices, const int32_t *n_ptr, int cap, int batch, int H, int W,
+                                    int32_t *tile_map, void *stream_)
+{
+    if (!indices || !n_ptr || !tile_map || cap < 1 || sassd_wino4_tile_map_ints(batch, H, W) == 0) return SASSD_EINVAL;
+    const int TH = H / 4, TW = W / 4, T = batch * TH * TW;
+    hipLaunchKernelGGL(w4_tile_map_kernel, dim3(1), dim3(1024), (size_t)align_up((size_t)T, 16), (hipStream_t)stream_, indices,
+                       n_ptr, cap, batch, H, W, TH, TW, tile_map);
     return sassd_launch_status();
 }
 
@@ -830,7 +904,7 @@ extern "C" int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, con
     if (((uintptr_t)y & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)x & 15)) return SASSD_EINVAL;
     const int hw = H * W;
     W4Gemm P;
-    P.U = w_packed; P.V = x; P.M = y; P.scale = scale; P.shift = shift; P.relu = relu;
+    P.U = w_packed; P.V = x; P.M = y; P.scale = scale; P.shift = shift; P.relu = relu; P.ncols_dev = nullptr;
     P.np = batch; P.Cin = Cin; P.Cout = Cout; P.ldv = hw; P.ldm = hw; P.ncols = hw;
     P.su = 0; P.sv = (size_t)Cin * hw; P.sm = (size_t)Cout * hw;
     hipStream_t stream = (hipStream_t)stream_;

@@ -381,6 +381,31 @@ def conv2d_fwd(x, w_packed, cout, ksize, scale=None, shift=None, relu=False, y=N
     return y
 
 
+def conv1x1_narrow_supported(cin, cout):
+    return bool(_C.lib().sassd_conv1x1_narrow_supported(int(cin), int(cout)))
+
+
+def conv1x1_narrow_pack_weight(w):
+    """w [Cout,Cin,1,1] -> wT [Cin][CO], CO = Cout padded to the kernel's channel count with zeros (the layout
+    sassd_conv1x1_narrow_fwd streams whole scalar weight rows from)."""
+    cout, cin = w.shape[0], w.shape[1]
+    co = _C.lib().sassd_conv1x1_narrow_pad(int(cout))
+    wt = torch.zeros(cin, co, dtype=torch.float32, device=w.device)
+    wt[:, :cout] = w.reshape(cout, cin).t().float()
+    return wt
+
+
+def conv1x1_narrow_fwd(x, wT, cout, scale=None, shift=None, relu=False, y=None):
+    """1x1 conv with <= 32 output channels as an HBM stream (fused SSD head, part-sensitive head)."""
+    _chk_cuda(x, wT, scale, shift)
+    b, cin, h, w = x.shape
+    if y is None:
+        y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().sassd_conv1x1_narrow_fwd(_C.ptr(x), _C.ptr(wT), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
+                                               _C.ptr(y), b, cin, cout, h, w, _C.stream()), "sassd_conv1x1_narrow_fwd")
+    return y
+
+
 def conv2d_wino_supported(cin, cout, h, w):
     return bool(_C.lib().sassd_conv2d_wino_supported(int(cin), int(cout), int(h), int(w)))
 
@@ -462,15 +487,29 @@ def conv2d_wino4_chain_workspace(b, cmax, h, w, device):
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
-def conv2d_wino4_chain(x, prev, w_packed, cin, cout, cmax, batch, h, w, scale, shift, relu, y, ws, cfg=None):
+def wino4_tile_map(indices, n_ptr, cap, batch, h, w, out=None):
+    """Active-tile map of a sparse BEV input (sassd_wino4_tile_map); None when the shape has too many tiles."""
+    n = _C.lib().sassd_wino4_tile_map_ints(int(batch), int(h), int(w))
+    if n == 0:
+        return None
+    if out is None:
+        out = torch.zeros(n, dtype=torch.int32, device=indices.device)
+    _C.check(_C.lib().sassd_wino4_tile_map(_C.ptr(indices), _C.ptr(n_ptr), int(cap), int(batch), int(h), int(w), _C.ptr(out),
+                                           _C.stream()), "sassd_wino4_tile_map")
+    return out
+
+
+def conv2d_wino4_chain(x, prev, w_packed, cin, cout, cmax, batch, h, w, scale, shift, relu, y, ws, cfg=None, tile_map=None,
+                       prev_tile_map=None):
     """One layer of a chain of Winograd F(4x4,3x3) convolutions (sassd_conv2d_wino4_chain).  `x`: NCHW input map, or None
     to continue from the products the previous call left in `ws` (then prev = (scale, shift, relu) of that layer).
-    `y`: NCHW output map, or None to leave the products in `ws` for the next call."""
+    `y`: NCHW output map, or None to leave the products in `ws` for the next call.  `tile_map` (wino4_tile_map): run on the
+    active tiles of a sparse input only; the next call names the same map as `prev_tile_map`."""
     _chk_cuda(x, w_packed, scale, shift, y, ws)
     ps, pb, pr = prev if prev is not None else (None, None, False)
     _C.check(_C.lib().sassd_conv2d_wino4_chain(_C.ptr(x), 0 if x is not None else 1, _C.ptr(ps), _C.ptr(pb), 1 if pr else 0,
                                                _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
-                                               _C.ptr(y), batch, cin, cout, cmax, h, w,
+                                               _C.ptr(y), batch, cin, cout, cmax, h, w, _C.ptr(tile_map), _C.ptr(prev_tile_map),
                                                DEFAULT_CFG["wino4"] if cfg is None else int(cfg), _C.ptr(ws), ws.numel(),
                                                _C.stream()), "sassd_conv2d_wino4_chain")
     return y

@@ -56,7 +56,8 @@ class InferencePlan:
                  sparse_shape=(40, 1600, 1408), anchors=None, anchors_bv=None, anchor_area_threshold=1,
                  anchors_per_loc=2, grid_offsets=(0., 40.), featmap_stride=0.4, rpn_thr=0.1, score_thr=0.3,
                  iou_thr=0.1, cap_k=4096, cap_d=512, device=None, level_cap_factor=2, overlap=True, winograd=True,
-                 fused_rulebooks=True, chain_bev=True, pyramid_persistent=False, spconv_cfg=None, wino4_cfg=None):
+                 fused_rulebooks=True, chain_bev=True, pyramid_persistent=False, spconv_cfg=None, wino4_cfg=None,
+                 skip_inactive_tiles=True, rb_sync_levels=(1, 3)):
         dev = torch.device(device if device is not None else "cuda:0")
         self.dev, self.B, self.ncls, self.A = dev, int(batch_size), int(num_class), int(anchors_per_loc)
         self.voxel_size = np.asarray(voxel_size, np.float32)
@@ -132,12 +133,18 @@ class InferencePlan:
         self.n_cls = sd["rpn_head.conv_cls.weight"].shape[0]
         self.n_dir = sd["rpn_head.conv_dir_cls.weight"].shape[0]
         self.head_c = hw.shape[0]
-        self.head_w, self.head_b = K.conv2d_pack_weight(hw), hb
+        # 1x1 convs with <= 32 output channels (the single-class fused head, the second part-sensitive conv) stream on the
+        # vector ALU (sassd_conv1x1_narrow_fwd); wider ones (three-class head: 60 maps) stay on the MFMA kernel
+        self.head_narrow = K.conv1x1_narrow_supported(hw.shape[1], hw.shape[0])
+        self.head_w = K.conv1x1_narrow_pack_weight(hw) if self.head_narrow else K.conv2d_pack_weight(hw)
+        self.head_b = hb
         w0 = sd["extra_head.convs.0.weight"].float().contiguous()
         self.ps_parts = w0.shape[0]
         self.ps_w0 = K.conv2d_pack_weight(w0)
         self.ps_s0, self.ps_b0 = fold_bn(sd, "extra_head.convs.1")
-        self.ps_w1 = K.conv2d_pack_weight(sd["extra_head.convs.3.weight"].float().contiguous())
+        w1 = sd["extra_head.convs.3.weight"].float().contiguous()
+        self.ps_narrow = K.conv1x1_narrow_supported(w1.shape[1], w1.shape[0])
+        self.ps_w1 = K.conv1x1_narrow_pack_weight(w1) if self.ps_narrow else K.conv2d_pack_weight(w1)
 
         # ---- anchors --------------------------------------------------------------------------------
         self.Atot = self.ncls * self.H * self.W * self.A
@@ -193,6 +200,17 @@ class InferencePlan:
         self.side = torch.cuda.Stream(device=dev) if self.overlap else None
         self.rb_ev = {k: torch.cuda.Event() for k in self.nbr}
         self.mask_ev = torch.cuda.Event()
+        # BEV conv0 reads the densified sparse map: its Winograd launch runs on the tiles that have an occupied pixel in their
+        # 6x6 patch only (56 % on a KITTI frame; bit-identical, the others' products are exactly zero).  The map is built from
+        # the level-3 coordinates on the side stream.
+        self.tile_map = None
+        if skip_inactive_tiles and self.bev[0][5] == 4:
+            n_ints = K._C.lib().sassd_wino4_tile_map_ints(B, H, W)
+            if n_ints:
+                self.tile_map = z(n_ints, dt=i32)
+        self.tmap_ev = torch.cuda.Event()
+        self.rb_sync_levels = tuple(sorted(int(l) for l in rb_sync_levels))   # levels whose completion the main stream waits
+        assert self.rb_sync_levels and self.rb_sync_levels[-1] == 3           # for ((0, 1, 2, 3): one wait per level)
         self.prof = None           # set to {} to collect (name, start_event, end_event) tuples per frame
 
     def _ev(self):
@@ -281,24 +299,35 @@ class InferencePlan:
             with torch.cuda.stream(self.side):
                 if rulebooks:
                     self.rulebooks()
+                if self.tile_map is not None and densify:
+                    K.wino4_tile_map(self.idx[3], self.n[3], self.caps[3], self.B, self.H, self.W, out=self.tile_map)
+                    self.tmap_ev.record()
                 if masks:
                     self.anchor_masks(anchors_mask)     # also coordinate-only work
                 self.mask_ev.record()
-        elif rulebooks:
-            self.rulebooks()
+        else:
+            if rulebooks:
+                self.rulebooks()
+            if self.tile_map is not None and densify:
+                K.wino4_tile_map(self.idx[3], self.n[3], self.caps[3], self.B, self.H, self.W, out=self.tile_map)
         if not convs:                                   # (measurement: the rulebook pyramid alone)
             return
         x = self.mean
         lvl = 0
         cur = 0
-        waited = set()
+        # cross-stream waits: the main stream joins the side stream at `rb_sync_levels` only -- a wait on level L's event covers
+        # every level <= L (stream order).  Round 6 measured one wait per rulebook (7 graph edges, each 6-14 us between the end
+        # of the producer and the start of the consumer) against two (after level 1 and after level 3): the first five convs
+        # then run while the side stream builds levels 2-3, and nothing waits afterwards (profiles/r06_pyramid_forms.txt).
+        covered = -1
         for li, (kind, cin, cout, key, wp, scale, shift) in enumerate(self.sp):
             y = self.feat[cur]
             if kind == "down":
                 lvl += 1
-            if key is not None and self.overlap and rulebooks and key not in waited:
-                main.wait_event(self.rb_ev[key])
-                waited.add(key)
+            if key is not None and self.overlap and rulebooks and lvl > covered:
+                upto = min([l for l in self.rb_sync_levels if l >= lvl] or [3])
+                main.wait_event(self.rb_ev["subm%d" % upto])
+                covered = upto
             if kind == "subm" or kind == "down":
                 K.spconv_fwd(x, self.nbr[key], self.n[lvl], self.caps[lvl], wp, 27, cin, cout, scale, shift, True, y,
                              cfg=self.spconv_cfg)
@@ -326,8 +355,13 @@ class InferencePlan:
                 # feeds the part-sensitive head, the last F(4x4) layer feeds a 1x1 / direct layer
                 keep = i + 1 < 8 and self.chain[i + 1]
                 prev = self.bev[i - 1][3:5] + (True,) if self.chain[i] else None
+                tmap = self.tile_map if i == 0 else None                     # conv0: the active tiles of the sparse map only
+                ptmap = self.tile_map if (i == 1 and self.chain[1]) else None   # conv1 reads conv0's compacted products
+                if tmap is not None and self.overlap:
+                    torch.cuda.current_stream(self.dev).wait_event(self.tmap_ev)
                 K.conv2d_wino4_chain(None if self.chain[i] else x, prev, wp, self.bev_cin[i], cout, self.cmax, self.B,
-                                     self.H, self.W, scale, shift, True, None if keep else y, self.wino4_ws, cfg=self.wino4_cfg)
+                                     self.H, self.W, scale, shift, True, None if keep else y, self.wino4_ws, cfg=self.wino4_cfg,
+                                     tile_map=tmap, prev_tile_map=ptmap)
             elif wino == 2:
                 K.conv2d_wino_fwd(x, wp, cout, scale, shift, True, y)
             elif wino == 1:
@@ -339,9 +373,15 @@ class InferencePlan:
             if i == 6:
                 self.conv6 = y
         self.x = x
-        K.conv2d_fwd(x, self.head_w, self.head_c, 1, None, self.head_b, False, self.head_out)
+        if self.head_narrow:
+            K.conv1x1_narrow_fwd(x, self.head_w, self.head_c, None, self.head_b, False, self.head_out)
+        else:
+            K.conv2d_fwd(x, self.head_w, self.head_c, 1, None, self.head_b, False, self.head_out)
         K.conv2d_fwd(self.conv6, self.ps_w0, self.ps_parts, 3, self.ps_s0, self.ps_b0, True, self.ps_t[0])
-        K.conv2d_fwd(self.ps_t[0], self.ps_w1, self.ps_parts, 1, None, None, False, self.ps_t[1])
+        if self.ps_narrow:
+            K.conv1x1_narrow_fwd(self.ps_t[0], self.ps_w1, self.ps_parts, None, None, False, self.ps_t[1])
+        else:
+            K.conv2d_fwd(self.ps_t[0], self.ps_w1, self.ps_parts, 1, None, None, False, self.ps_t[1])
 
     def anchor_masks(self, masks=None):
         if masks is not None:

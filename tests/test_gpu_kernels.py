@@ -63,6 +63,37 @@ def test_voxelizer_full_frame(dev, name, seed):
         assert m == 16111
 
 
+@pytest.mark.parametrize("T", [1, 5, 8])
+@pytest.mark.parametrize("nfeat,cols", [(4, 4), (3, 3), (4, 3)])
+def test_voxelizer_emit_kernels_agree(dev, T, nfeat, cols):
+    """the level-by-level emit kernel (vox_emit8_kernel: ndim 4, max_points <= 8, 16-byte aligned points) against the
+    point-by-point one (vox_emit_kernel, the generic path) on the SAME cloud -- the generic path is forced by handing the points
+    over 4 bytes off a 16-byte boundary -- voxels, coordinates, point counts, means and the voxel count bit for bit, for
+    max_points 1 / 5 / 8, 3 and 4 mean features, 3 and 4 coordinate columns, with and without the max_voxels break."""
+    pts = H.frame("k21", 3)
+    n = len(pts)
+    flat = torch.zeros(n * 4 + 8, device=dev)
+    assert flat.data_ptr() % 16 == 0
+    aligned = flat[4:4 + 4 * n].view(n, 4)
+    aligned.copy_(torch.from_numpy(pts))
+    off = torch.zeros(n * 4 + 8, device=dev)[1:1 + 4 * n].view(n, 4)
+    off.copy_(torch.from_numpy(pts))
+    assert aligned.data_ptr() % 16 == 0 and off.data_ptr() % 16 == 4
+    for max_voxels in (20000, 3000):
+        res = []
+        for p in (aligned, off):
+            st = K.new_status(dev)
+            r = K.voxelize(p, synth.KITTI_VOXEL, synth.KITTI_RANGE, T, max_voxels, batch_idx=2, coors_cols=cols,
+                           want_voxels=True, want_mean=True, nfeat=nfeat, status=st)
+            torch.cuda.synchronize()
+            m = int(r["voxel_num"].item())
+            res.append((m, r["voxels"][:m].clone(), r["coors"][:m].clone(), r["num_points"][:m].clone(), r["mean"][:m].clone()))
+        a, b = res
+        assert a[0] == b[0] and a[0] > 0 and (max_voxels != 3000 or a[0] == 3000)
+        for i, name in ((1, "voxels"), (2, "coors"), (3, "num_points"), (4, "mean")):
+            assert torch.equal(a[i], b[i]), (name, T, nfeat, cols, max_voxels)
+
+
 def test_voxelizer_waymo_scale_break(dev):
     pts = synth.waymo_synth(0)[:180000]
     v, c, n = clib.points_to_voxel(pts, synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, True, 60000)   # break triggers
@@ -182,6 +213,28 @@ def test_conv2d(dev, cin, cout, ks, h, w, b):
     assert err < 1e-4, err
     y2 = K.conv2d_fwd(x.to(dev), wp, cout, ks).cpu()
     assert (y2 - torch.nn.functional.conv2d(x, wt, None, 1, ks // 2)).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,h,w,b", [(256, 20, 200, 176, 1), (28, 28, 200, 176, 2), (256, 20, 7, 50, 2), (30, 1, 5, 31, 1),
+                                            (7, 32, 3, 70, 3), (64, 9, 188, 188, 1)])
+def test_conv1x1_narrow(dev, cin, cout, h, w, b):
+    """1x1 convolution with <= 32 output channels on the streaming vector-ALU kernel (fused SSD head 256 -> 20, part-sensitive
+    28 -> 28; ragged pixel counts, Cin not a multiple of the four waves' split, every padded channel count) against float64
+    conv2d at the fp32 bar of the MFMA kernel it replaces."""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    assert K.conv1x1_narrow_supported(cin, cout) and not K.conv1x1_narrow_supported(cin, 33)
+    raw = torch.nn.functional.conv2d(x.double(), wt.double())
+    ref = torch.relu(raw * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    wp = K.conv1x1_narrow_pack_weight(wt.to(dev))
+    y = K.conv1x1_narrow_fwd(x.to(dev), wp, cout, scale.to(dev), shift.to(dev), True).cpu().double()
+    assert (y - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    y2 = torch.full((b, cout, h, w), 7.0, device=dev)
+    K.conv1x1_narrow_fwd(x.to(dev), wp, cout, None, None, False, y2)
+    assert (y2.cpu().double() - raw).abs().max().item() < 2e-6 * max(1.0, raw.abs().max().item())
+    assert torch.equal(y2, K.conv1x1_narrow_fwd(x.to(dev), wp, cout))              # a fixed summation order
 
 
 def test_iou_matrices_and_nms(dev):

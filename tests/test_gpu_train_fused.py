@@ -379,6 +379,43 @@ def test_bn2d_relu_fused_matches_torch(dev, shape):
     assert torch.equal(y2, y.detach())
 
 
+@pytest.mark.parametrize("kind", ["sparse", "nchw"])
+def test_bn_statistics_of_a_large_mean_small_variance_channel(dev, kind):
+    """the statistics kernels add <= 16 (64) elements in fp32 before they widen to double; with raw x^2 sums a channel
+    with |mean| >> std (mean 40, variance 1e-2) lost ~1 % of its invstd to the cancellation E[x^2] - mean^2.  They sum
+    (x - shift) with shift = a value of the channel, so the saved mean / invstd must match a FLOAT64 evaluation: invstd to 1e-4
+    relative (the fp32 input itself carries 40 * 2^-24 = 2.4e-6 of noise per element against a std of 0.1), the output to 1e-3
+    of its scale.  One ordinary channel rides along."""
+    from sassd import kernels as K
+    g = torch.Generator().manual_seed(7)
+    if kind == "sparse":
+        x = torch.randn(20011, 16, generator=g, dtype=torch.float64)
+        x[:, 3] = 40.0 + 0.1 * torch.randn(20011, generator=g, dtype=torch.float64)
+        x[:, 7] = -1e3 + 0.5 * torch.randn(20011, generator=g, dtype=torch.float64)
+        xf = x.float().to(dev)
+        gam, bet = torch.ones(16, device=dev), torch.zeros(16, device=dev)
+        y, mean, invstd = K.bn_relu_fwd(xf, gam, bet, None, None, 0.01, 1e-3)
+        x64 = xf.double().cpu()                               # what the kernel was given, in float64
+        m64, v64 = x64.mean(0), x64.var(0, unbiased=False)
+    else:
+        x = torch.randn(2, 8, 40, 44, generator=g, dtype=torch.float64)
+        x[:, 3] = 40.0 + 0.1 * torch.randn(2, 40, 44, generator=g, dtype=torch.float64)
+        x[:, 5] = -1e3 + 0.5 * torch.randn(2, 40, 44, generator=g, dtype=torch.float64)
+        xf = x.float().to(dev)
+        gam, bet = torch.ones(8, device=dev), torch.zeros(8, device=dev)
+        y, mean, invstd = K.bn2d_relu_fwd(xf, gam, bet, None, None, 0.01, 1e-3)
+        x64 = xf.double().cpu()
+        m64, v64 = x64.mean((0, 2, 3)), x64.var((0, 2, 3), unbiased=False)
+    is64 = 1.0 / torch.sqrt(v64 + 1e-3)
+    rel = ((invstd.double().cpu() - is64).abs() / is64).max().item()
+    dm = ((mean.double().cpu() - m64).abs() / m64.abs().clamp(min=1.0)).max().item()
+    print("BN statistics (%s) with mean 40 / -1000 channels: invstd rel err %.2e, mean rel err %.2e" % (kind, rel, dm))
+    assert rel < 1e-4 and dm < 1e-6, (rel, dm)
+    shape = (1, -1) if kind == "sparse" else (1, -1, 1, 1)
+    ref = torch.relu((x64 - m64.view(shape)) * is64.view(shape))
+    assert (y.double().cpu() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_fused_aux_head_matches_module_path(dev):
     """The fused auxiliary head (sassd_aux_prepare / sassd_aux_head_fwd / _bwd: voxel centres, point-in-box labels,
     interpolation weights, three interpolations, three Linear layers, focal + smooth-L1 and the whole backward) against the

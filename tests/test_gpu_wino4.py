@@ -1,6 +1,7 @@
 """-m gpu parity of the Winograd F(4x4,3x3) BEV convolution (input transform -> 36 GEMMs -> output transform) against
 torch-CPU conv2d (plain fp32 reference of the same op).  The GEMMs run their fp32 products on the bf16 MFMA over exactly
 split operands by default; the fp32-MFMA form and the other workgroup shapes are held to the same bar against fp64."""
+import numpy as np
 import pytest
 import torch
 
@@ -155,3 +156,70 @@ def test_conv2d_wino4_chain(dev, b, cin0, hw):
                                                                                           torch.equal(y, ref)))
     assert err <= 1e-6 * max(1.0, ref.abs().max().item()), err
     assert not K.conv2d_wino4_chain_supported(256, 256, 400, 352)          # plane does not fit the LDS
+
+
+@pytest.mark.parametrize("b,cin0,hw,frac", [(1, 320, (200, 176), 0.002), (3, 64, (20, 44), 0.01), (2, 320, (188, 188), 0.0),
+                                            (1, 96, (8, 8), 1.0)])
+def test_conv2d_wino4_chain_on_active_tiles_is_bit_identical(dev, b, cin0, hw, frac):
+    """conv0 of the BEV stack reads the densified sparse map; with a tile map (sassd_wino4_tile_map, built from the sparse rows'
+    coordinates) its Winograd launch transforms and multiplies only the tiles with an occupied pixel in their 6 x 6 patch.
+    An inactive tile's products are exactly zero, so both forms of the layer -- with its own output transform, and chained
+    into a second layer through the fused transform -- must equal the dense launch BIT FOR BIT; the map itself is checked
+    against a numpy restatement (patch rows 4 t - 1 .. 4 t + 4).  Cases: a KITTI-sized map with clustered occupancy, a batch
+    of small images, an EMPTY map, a map where every pixel is occupied."""
+    g = torch.Generator().manual_seed(int(frac * 1000) + hw[0])
+    H_, W_ = hw
+    occ = torch.rand(b, H_, W_, generator=g) < frac
+    if 0.0 < frac < 1.0:                                    # clustered: occupancy only in a band of rows
+        occ[:, : H_ // 3] = False
+    x = torch.randn(b, cin0, H_, W_, generator=g) * occ.unsqueeze(1).float()
+    nz = occ.nonzero()                                       # (b, y, x)
+    n = nz.shape[0]
+    cap = n + 37
+    idx = torch.zeros(cap, 4, dtype=torch.int32)
+    idx[:n, 0], idx[:n, 2], idx[:n, 3] = nz[:, 0].int(), nz[:, 1].int(), nz[:, 2].int()
+    idx[n:] = torch.tensor([0, 0, 1, 1], dtype=torch.int32)  # rows past the count must be ignored
+    nptr = torch.tensor([n], dtype=torch.int32, device=dev)
+    tmap = K.wino4_tile_map(idx.to(dev), nptr, cap, b, H_, W_)
+    TH, TW = H_ // 4, W_ // 4
+    T = b * TH * TW
+    want = np.zeros((b, TH, TW), bool)
+    for bb, yy, xx in nz.numpy():
+        for ty in {yy // 4, (yy - 1) // 4 if yy % 4 == 0 else yy // 4, (yy + 1) // 4 if yy % 4 == 3 else yy // 4}:
+            for tx in {xx // 4, (xx - 1) // 4 if xx % 4 == 0 else xx // 4, (xx + 1) // 4 if xx % 4 == 3 else xx // 4}:
+                if 0 <= ty < TH and 0 <= tx < TW:
+                    want[bb, ty, tx] = True
+    tm = tmap.cpu().numpy()
+    act = np.flatnonzero(want.reshape(-1))
+    assert tm[0] == len(act) and tm[1] == T
+    assert np.array_equal(tm[4 + T:4 + T + len(act)], act)
+    pos = np.full(T, -1, np.int64)
+    pos[act] = np.arange(len(act))
+    assert np.array_equal(tm[4:4 + T], pos)
+    ws = [torch.randn(256, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5 for c in (cin0, 256)]
+    scs = [(torch.rand(256, generator=g) + 0.5).to(dev) for _ in ws]
+    shs = [(torch.randn(256, generator=g) * 0.1).to(dev) for _ in ws]
+    wps = [K.conv2d_wino4_pack_weight(w.to(dev)) for w in ws]
+    cmax = max(cin0, 256)
+    wsb = K.conv2d_wino4_chain_workspace(b, cmax, H_, W_, dev)
+    xd = x.to(dev)
+
+    def one_layer(tile_map):
+        y = torch.empty(b, 256, H_, W_, device=dev)
+        wsb.view(torch.float32).fill_(float("nan"))          # stale columns must never be read
+        K.conv2d_wino4_chain(xd, None, wps[0], cin0, 256, cmax, b, H_, W_, scs[0], shs[0], True, y, wsb, tile_map=tile_map)
+        return y
+
+    def two_layers(tile_map):
+        y = torch.empty(b, 256, H_, W_, device=dev)
+        wsb.view(torch.float32).fill_(float("nan"))
+        K.conv2d_wino4_chain(xd, None, wps[0], cin0, 256, cmax, b, H_, W_, scs[0], shs[0], True, None, wsb, tile_map=tile_map)
+        K.conv2d_wino4_chain(None, (scs[0], shs[0], True), wps[1], 256, 256, cmax, b, H_, W_, scs[1], shs[1], True, y, wsb,
+                             prev_tile_map=tile_map)
+        return y
+    for fn in (one_layer, two_layers):
+        dense, sparse = fn(None), fn(tmap)
+        torch.cuda.synchronize()
+        assert torch.isfinite(sparse).all()
+        assert torch.equal(dense, sparse), (fn.__name__, (dense - sparse).abs().max().item())
+    print("wino4 active tiles %s: %d of %d tiles active, outputs bit-identical" % ((b, cin0, hw), len(act), T))

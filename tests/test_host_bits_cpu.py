@@ -48,6 +48,14 @@ def test_pack_cache_pins_its_source_and_stays_bounded():
     n = len(c)
     c.put(("k", c.MAX + 9), ("gen", "new"), torch.zeros(1), torch.zeros(1))
     assert len(c) == n and c[("k", c.MAX + 9)][0] == ("gen", "new")
+    # least recently USED goes first: a long-lived entry that keeps being hit survives any number of transient keys
+    c2 = AG._PackCache()
+    c2.put("param", 0, torch.zeros(1), torch.zeros(1))
+    for i in range(3 * c2.MAX):
+        assert c2.get("param") is not None
+        c2.put(("transient", i), 0, torch.zeros(1), torch.zeros(1))
+    assert "param" in c2 and len(c2) <= c2.MAX and ("transient", 0) not in c2
+    assert c2.get("missing") is None
 
 
 def test_cached_batch_constants():

@@ -472,8 +472,8 @@ def main():
                     "replaying the captured hipGraph (A/B)")
     ap.add_argument("--pyramid", choices=("levels", "persistent"), default=PYRAMID_DEFAULT, help="rulebook pyramid: two "
                     "launches per level, or ONE persistent launch with in-launch grid barriers (A/B)")
-    ap.add_argument("--rb-sync", default="1,3", help="rulebook levels at which the feature stream joins the coordinate stream "
-                    "(A/B: 0,1,2,3 = one wait per level, the round 2-5 form)")
+    ap.add_argument("--rb-sync", default="0,1,2,3", help="rulebook levels at which the feature stream joins the coordinate stream "
+                    "(0,1,2,3 = one wait per level, the default; A/B: 1,3 or 3)")
     ap.add_argument("--dense-conv0", action="store_true", help="BEV conv0 on every tile instead of the active tiles of the "
                     "sparse map only (A/B)")
     ap.add_argument("--no-extra", action="store_true", help="default (car) run: skip the `infer_multi` / `infer_waymo` / "

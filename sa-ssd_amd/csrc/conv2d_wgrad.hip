@@ -270,6 +270,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad_bf16_kernel(WgradParams p
 
     for (int i = tid; i < 6 * kRowH / 2; i += 256) ((unsigned *)ylds)[i] = 0u;     // pad columns stay zero
 
+    // (Round 6 measured TWO register sets -- the rows a step stores requested two steps earlier, every fetch unconditional, exact
+    // vmcnt(12) waits in the ISA, 244 VGPRs: 0.1262 against 0.1267-0.1284 ms for the 3x3 layer and 0.089 against 0.072 ms for
+    // the 1x1 one.  The 2.3 us a row step takes are NOT load latency: 143 VALU / LDS instructions per 27 MFMAs and two
+    // barriers per row issue from the same four waves.  Not adopted; profiles/r06_wgrad_prefetch.txt.)
     // the raw fp32 pairs stay in registers across the MFMAs (loads in flight) and are rounded when they are stored;
     // loads are unconditional (clamped address) with a select on the raw value -- a select on the CONVERTED value
     // makes the compiler branch around load + wait + convert, which serialises the twelve loads

@@ -57,7 +57,7 @@ class InferencePlan:
                  anchors_per_loc=2, grid_offsets=(0., 40.), featmap_stride=0.4, rpn_thr=0.1, score_thr=0.3,
                  iou_thr=0.1, cap_k=4096, cap_d=512, device=None, level_cap_factor=2, overlap=True, winograd=True,
                  fused_rulebooks=True, chain_bev=True, pyramid_persistent=False, spconv_cfg=None, wino4_cfg=None,
-                 skip_inactive_tiles=True, rb_sync_levels=(1, 3)):
+                 skip_inactive_tiles=True, rb_sync_levels=(0, 1, 2, 3)):
         dev = torch.device(device if device is not None else "cuda:0")
         self.dev, self.B, self.ncls, self.A = dev, int(batch_size), int(num_class), int(anchors_per_loc)
         self.voxel_size = np.asarray(voxel_size, np.float32)
@@ -315,10 +315,10 @@ class InferencePlan:
         x = self.mean
         lvl = 0
         cur = 0
-        # cross-stream waits: the main stream joins the side stream at `rb_sync_levels` only -- a wait on level L's event covers
-        # every level <= L (stream order).  Round 6 measured one wait per rulebook (7 graph edges, each 6-14 us between the end
-        # of the producer and the start of the consumer) against two (after level 1 and after level 3): the first five convs
-        # then run while the side stream builds levels 2-3, and nothing waits afterwards (profiles/r06_pyramid_forms.txt).
+        # cross-stream waits: the main stream joins the side stream at `rb_sync_levels` -- a wait on level L's event covers
+        # every level <= L (stream order).  Round 6 measured one wait per level (the default) against two (after levels 1 and
+        # 3) and one (after level 3): sparse segment 0.320 / 0.332 / 0.334 ms, frames/s equal -- fewer graph edges do not pay
+        # for the later start of the first convs (profiles/r06_pyramid_forms.txt).
         covered = -1
         for li, (kind, cin, cout, key, wp, scale, shift) in enumerate(self.sp):
             y = self.feat[cur]

@@ -285,6 +285,12 @@ size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout);
 int sassd_conv2d_bf16_pack_weight(const float *w, int Cout, int Cin, void *packed, void *stream);
 int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const float *shift, float *y, int batch, int Cin,
                           int Cout, int H, int W, void *stream);
+/* The same convolution over relu(batchnorm(x)), the normalisation applied by the kernel's loader waves (round 6): x is the RAW
+ * output of the previous convolution, in_affine [3][Cin] = mean | invstd * gamma | beta as sassd_bn2d_stats writes it.  The
+ * operand that reaches the MFMA is bit-identical to the one sassd_bn2d_relu_fwd + sassd_conv2d_bf16_fwd produce, and the
+ * normalised map (cmn.py:236-237 between two BEV layers) is never written to HBM.  Cin <= 1024. */
+int sassd_conv2d_bf16_bnrelu_fwd(const float *x, const float *in_affine, const void *w_packed, const float *shift, float *y,
+                                 int batch, int Cin, int Cout, int H, int W, void *stream);
 
 /* Training: weight gradient of the same convolutions (autograd of nn.Conv2d at cmn.py:240-262 and
  * ssd_rotate_head.py:120-125,424-429; cuDNN in the reference).  x [B,Cin,H,W], dy [B,Cout,H,W] NCHW fp32 ->
@@ -299,6 +305,11 @@ int sassd_conv2d_bwd_weight(const float *x, const float *dy, float *dw, int batc
  * (SASSD_EINVAL otherwise).  What the reference gets from cuDNN under torch autocast / apex O1. */
 int sassd_conv2d_bwd_weight_bf16(const float *x, const float *dy, float *dw, int batch, int Cin, int Cout, int H, int W,
                                  int ksize, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+/* ... with the X operand = relu(batchnorm(x)) applied on the way into LDS (x_affine as above; 3x3 only): the weight gradient of
+ * a layer whose input map was never materialised (sassd_conv2d_bf16_bnrelu_fwd). */
+int sassd_conv2d_bwd_weight_bf16_bnrelu(const float *x, const float *x_affine, const float *dy, float *dw, int batch, int Cin,
+                                        int Cout, int H, int W, int ksize, int accumulate, void *workspace,
+                                        size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (f-3 / a18) fused training targets and RPN loss.
@@ -554,6 +565,12 @@ size_t sassd_bn2d_relu_workspace_bytes(int C);
 int sassd_bn2d_relu_fwd(const float *x, int B, int C, int HW, const float *gamma, const float *beta, float *running_mean,
                         float *running_var, float momentum, float eps, float *y, float *save_mean, float *save_invstd,
                         void *workspace, size_t workspace_bytes, void *stream);
+/* Statistics only: mean / invstd / running statistics exactly as sassd_bn2d_relu_fwd computes them, plus the affine triple
+ * [3][C] = mean | invstd * gamma | beta for consumers that apply BatchNorm + ReLU themselves (sassd_conv2d_bf16_bnrelu_fwd,
+ * sassd_conv2d_bwd_weight_bf16_bnrelu); the backward is sassd_bn2d_relu_bwd on the raw map. */
+int sassd_bn2d_stats(const float *x, int B, int C, int HW, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, float momentum, float eps, float *save_mean, float *save_invstd, float *affine,
+                     void *workspace, size_t workspace_bytes, void *stream);
 int sassd_bn2d_relu_bwd(const float *x, const float *dy, int B, int C, int HW, const float *gamma, const float *beta,
                         const float *save_mean, const float *save_invstd, float *dx, float *dgamma, float *dbeta,
                         void *workspace, size_t workspace_bytes, void *stream);

@@ -104,6 +104,7 @@ _SIGS = {
     "sassd_conv2d_bf16_packed_elems": (_SZ, [_I, _I]),
     "sassd_conv2d_bf16_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv2d_bf16_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sassd_conv2d_bf16_bnrelu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "sassd_conv2d_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_assign_targets_workspace_bytes": (_SZ, [_I, _I, _I]),
@@ -114,6 +115,7 @@ _SIGS = {
     "sassd_rpn_loss_workspace_bytes": (_SZ, [_I, _I]),
     "sassd_rpn_loss": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "sassd_conv2d_bwd_weight_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "sassd_conv2d_bwd_weight_bf16_bnrelu": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_rotate_iou_eval": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "sassd_kitti_eval_statistics": (_I, [_P, C.c_int64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, C.c_double, _P, _I, _I, _P,
                                          _P, _P]),
@@ -128,6 +130,7 @@ _SIGS = {
     "sassd_bn_relu_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "sassd_bn2d_relu_workspace_bytes": (_SZ, [_I]),
     "sassd_bn2d_relu_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _SZ, _P]),
+    "sassd_bn2d_stats": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _SZ, _P]),
     "sassd_bn2d_relu_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "sassd_aux_head_workspace_bytes": (_SZ, [_I]),
     "sassd_aux_prepare": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),

@@ -412,6 +412,61 @@ class BnRelu2dFn(Function):
         return dx, dg, db, None, None, None, None
 
 
+class BnReluConvBf16Fn(Function):
+    """relu(batchnorm2d(x)) -> 3x3 conv on the bf16 MFMA as ONE unit (round 6; cmn.py:236-237 + the next layer's conv): the
+    batch statistics come from sassd_bn2d_stats, the normalisation + ReLU is applied by the LOADER WAVES of the convolution (and
+    of its weight gradient) to the raw map x, with the expression of the stand-alone apply kernel -- so forward, data gradient and
+    weight gradient are bit-identical to BnRelu2dFn followed by Conv2dFn, and the normalised map is never written to HBM
+    (72 MB written + read back per 256-channel layer at batch 2: the bn2d_apply_kernel pass).  Backward: weight gradient with the
+    same fused operand, data gradient as before, then sassd_bn2d_relu_bwd on the raw map."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, weight, bias):
+        x = x.contiguous()
+        cout = weight.shape[0]
+        mean, invstd, aff = K.bn2d_stats(x, gamma.detach().contiguous(), beta.detach().contiguous(), running_mean, running_var,
+                                         momentum, eps)
+        shift = bias.detach().contiguous() if bias is not None else None
+        y = K.conv2d_bf16_fwd(x, _bf16_pack(weight, False), cout, shift, in_affine=aff)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, aff, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd, aff, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        cout, cin = weight.shape[0], weight.shape[1]
+        dw = K.conv2d_bwd_weight(x, dy, 3, bf16=True, x_affine=aff) if ctx.needs_input_grad[7] else None
+        db = dy.sum((0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[8]) else None
+        dx = dg = dbt = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            if K.conv2d_bf16_supported(cout, cin, dy.shape[2], dy.shape[3]):
+                da = K.conv2d_bf16_fwd(dy, _bf16_pack(weight, True), cin)
+            else:
+                pk = _dgrad_pack(weight, dy.shape[2], dy.shape[3])
+                da = _conv_any(dy, pk["wt"], 3, pk.get("packed"), pk.get("wino"), None, pk.get("wino4"))
+            dx, dg, dbt = K.bn2d_relu_bwd(x, da, gamma.detach().contiguous(), beta.detach().contiguous(), mean, invstd)
+        return dx, dg, dbt, None, None, None, None, dw, db
+
+
+def bn_relu_conv_fusable(bn, conv, x):
+    """Can relu(bn(x)) -> conv run as BnReluConvBf16Fn?  bf16 BEV precision, training-mode affine BatchNorm with running
+    statistics, a 3x3 / stride 1 / pad 1 convolution of a shape the bf16 kernels take (W even for its weight gradient)."""
+    return (_BEV_PRECISION == "bf16" and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+            and torch.is_grad_enabled() and K.bn2d_relu_supported(x) and conv.kernel_size[0] == 3 and conv.stride[0] == 1
+            and conv.padding[0] == 1 and x.shape[1] <= 1024 and x.shape[3] % 2 == 0
+            and K.conv2d_bf16_supported(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3]))
+
+
+def bn_relu_conv(bn, conv, x):
+    """conv(relu(bn(x))) through BnReluConvBf16Fn (caller checked bn_relu_conv_fusable)."""
+    y = BnReluConvBf16Fn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, conv.weight,
+                               conv.bias)
+    count_bn_batch(bn)
+    return y
+
+
 import weakref
 
 _pending_nbt = weakref.WeakKeyDictionary()      # BatchNorm module -> increments not yet applied (no strong references:

@@ -183,6 +183,36 @@ __global__ void __launch_bounds__(256) bn2d_bwd_apply_kernel(Bn2dArgs P)
     }
 }
 
+// statistics only (round 6): what bn2d_apply_kernel computes per channel before it touches the map, for consumers that apply
+// the normalisation themselves (sassd_conv2d_bf16_bnrelu_fwd / sassd_conv2d_bwd_weight_bf16_bnrelu): mean, invstd, running
+// statistics, and the affine triple [3][C] = mean | invstd * gamma | beta those kernels read.  Same sums, same order.
+__global__ void __launch_bounds__(256) bn2d_finalize_kernel(Bn2dArgs P, float *__restrict__ aff)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= P.C) return;
+    double ss = 0.0, qq = 0.0;
+    for (int k = 0; k < P.S; ++k) {
+        ss += P.part[((size_t)c * P.S + k) * 2 + 0];
+        qq += P.part[((size_t)c * P.S + k) * 2 + 1];
+    }
+    const double n = (double)P.B * (double)P.HW;
+    const double ms = ss / n;
+    double var = qq / n - ms * ms;
+    if (var < 0.0) var = 0.0;
+    const double mean = (double)P.x[(size_t)c * P.HW] + ms;
+    const float m = (float)mean, is = (float)(1.0 / sqrt(var + (double)P.eps));
+    P.mean[c] = m;
+    P.invstd[c] = is;
+    if (P.rmean) {
+        const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+        P.rmean[c] = (float)((1.0 - P.momentum) * P.rmean[c] + P.momentum * mean);
+        P.rvar[c] = (float)((1.0 - P.momentum) * P.rvar[c] + P.momentum * unb);
+    }
+    aff[c] = m;
+    aff[P.C + c] = is * P.gamma[c];
+    aff[2 * P.C + c] = P.beta[c];
+}
+
 bool bn2d_shape_ok(int B, int C, int HW) { return B >= 1 && C >= 1 && HW >= 4 && HW % 4 == 0; }
 
 void bn2d_geometry(Bn2dArgs &P)
@@ -239,5 +269,25 @@ extern "C" int sassd_bn2d_relu_bwd(const float *x, const float *dy, int B, int C
     P.dgamma = dgamma; P.dbeta = dbeta;
     hipLaunchKernelGGL(bn2d_bwd_reduce_kernel, dim3(C * P.S), dim3(256), 0, s, P);
     hipLaunchKernelGGL(bn2d_bwd_apply_kernel, dim3(C * P.S), dim3(256), 0, s, P);
+    return sassd_launch_status();
+}
+
+extern "C" int sassd_bn2d_stats(const float *x, int B, int C, int HW, const float *gamma, const float *beta,
+                                float *running_mean, float *running_var, float momentum, float eps, float *save_mean,
+                                float *save_invstd, float *affine, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (!x || !gamma || !beta || !save_mean || !save_invstd || !affine || !workspace || !bn2d_shape_ok(B, C, HW) ||
+        (!running_mean) != (!running_var) || ((uintptr_t)x & 15))
+        return SASSD_EINVAL;
+    if (workspace_bytes < sassd_bn2d_relu_workspace_bytes(C)) return SASSD_ENOSPC;
+    hipStream_t s = (hipStream_t)stream_;
+    Bn2dArgs P = {};
+    P.x = x; P.B = B; P.C = C; P.HW = HW;
+    bn2d_geometry(P);
+    P.part = (double *)workspace;
+    P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd; P.rmean = running_mean; P.rvar = running_var;
+    P.momentum = momentum; P.eps = eps;
+    hipLaunchKernelGGL(bn2d_stats_kernel, dim3(C * P.S), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(bn2d_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, P, affine);
     return sassd_launch_status();
 }

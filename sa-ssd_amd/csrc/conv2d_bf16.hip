@@ -59,6 +59,8 @@ struct BfParams {
     int strips;                                    // cout tiles x B x tiles_x, cout tile slowest
     int wr_map;                                    // loader item order: 1 channel group fastest (default), 0 pixel quad fastest
     int mma_prio;                                  // 1: MMA waves at s_setprio 1 (default); 0: none; 2: loader waves at 2
+    const float *in_aff;                           // BN = 1: [3][Cin] mean | invstd * gamma | beta of the BatchNorm + ReLU the
+                                                   // loader waves apply to the input on its way into LDS (round 6)
 };
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi)
@@ -104,7 +106,12 @@ struct LoadTile {                                  // what the loader waves need
     int r0, c0, rows;                              // first output row / column, live LDS rows (2 nb + 2)
 };
 
-template <int COW, int NLW, int DBG>
+// BN = 1 (round 6): the input is the RAW output of the previous convolution and the loader waves normalise it -- training-mode
+// BatchNorm2d + ReLU with the batch statistics sassd_bn2d_stats left in `in_aff`, z = fmaf(x - mean, invstd * gamma, beta),
+// max(z, 0): the very expression of bn2d_apply_kernel, so the operand that reaches the MFMA is bit-identical to the one the
+// stand-alone apply pass would have written -- before they round it to bf16.  The normalised map is never written to HBM
+// (72 MB written + read back per 256-channel layer at batch 2 = the 20.7 us bn2d_apply_kernel took).
+template <int COW, int NLW, int DBG, int BN = 0>
 __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfParams p)
 {
     constexpr int NLT = 64 * NLW;                  // loader threads
@@ -112,6 +119,7 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 input buffers | COW images | tile list
     float *img_base = (float *)(lds + 2 * kBufB);
     int *tl = (int *)(lds + 2 * kBufB + COW * kImgB);   // [0] = tiles, then (strip, first block, blocks) per tile
+    float *aff = (float *)(tl + 4 * ((1 + 3 * kMaxTiles + 3) / 4));   // BN: [3][CinP] (16-byte aligned: 8-channel groups are b128 reads)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // in an SGPR: what depends on it alone stays scalar
     const bool loader = wave >= COW;
@@ -141,6 +149,12 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
             g0 += seg;
         }
         tl[0] = n;                                 // <= kMaxTiles: the launcher bounds the run length
+    }
+    if constexpr (BN) {
+        for (int i = tid; i < 3 * p.CinP; i += 64 * (COW + NLW)) {
+            const int k = i / p.CinP, c = i - k * p.CinP;
+            aff[i] = p.in_aff[k * p.Cin + min(c, p.Cin - 1)];      // padding channels: any finite value (their weights are zero)
+        }
     }
     __syncthreads();
     const int ntile = tl[0];
@@ -190,16 +204,35 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(st[j]) : "v"(a));
             }
         };
-        auto item_store = [&](int e, const LoadTile &T, const f32x4 (&st)[8], int buf) {
+        auto item_store = [&](int e, const LoadTile &T, const f32x4 (&st)[8], int buf, int ci0) {
             bool live, ok; int d, g; const float *q;
             item_geom(e, T, live, ok, d, q, g);
             if (!live) return;
             unsigned char *dst = lds + buf * kBufB + d;
+            float am[8], as[8], ab[8];
+            if constexpr (BN) {
+                const float *a0 = aff + ci0 + g * 8;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 m4 = *(const f32x4 *)(a0 + 4 * h), s4 = *(const f32x4 *)(a0 + p.CinP + 4 * h),
+                                b4 = *(const f32x4 *)(a0 + 2 * p.CinP + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { am[4 * h + j] = m4[j]; as[4 * h + j] = s4[j]; ab[4 * h + j] = b4[j]; }
+                }
+            }
+            auto val = [&](int j, int px) {
+                float v = st[j][px];
+                if constexpr (BN) {
+                    const float z = fmaf(v - am[j], as[j], ab[j]);     // == bn2d_apply_kernel
+                    v = z > 0.f ? z : 0.f;
+                }
+                return v;
+            };
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 u32x4 v4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v4[j] = ok ? pack2(st[2 * j][px], st[2 * j + 1][px]) : 0u;
+                for (int j = 0; j < 4; ++j) v4[j] = ok ? pack2(val(2 * j, px), val(2 * j + 1, px)) : 0u;   // zero padding AFTER the ReLU
                 *(u32x4 *)(dst + px * kPixB) = v4;
             }
         };
@@ -212,12 +245,12 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
             if (one) item_issue(lt, T, s0, ci0);
             if (two) item_issue(lt + NLT, T, s1, ci0);
         };
-        auto land = [&](const LoadTile &T, int buf) {   // every hand-issued load of this wave has returned; registers -> LDS
+        auto land = [&](const LoadTile &T, int buf, int ci0) {   // every hand-issued load of this wave has returned; registers -> LDS
             asm volatile("s_waitcnt vmcnt(0)"
                          : "+v"(s0[0]), "+v"(s0[1]), "+v"(s0[2]), "+v"(s0[3]), "+v"(s0[4]), "+v"(s0[5]), "+v"(s0[6]), "+v"(s0[7]),
                            "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3]), "+v"(s1[4]), "+v"(s1[5]), "+v"(s1[6]), "+v"(s1[7]));
-            if (one) item_store(lt, T, s0, buf);
-            if (two) item_store(lt + NLT, T, s1, buf);
+            if (one) item_store(lt, T, s0, buf, ci0);
+            if (two) item_store(lt + NLT, T, s1, buf, ci0);
         };
         // two cursors over the (tile, chunk) sequence: the one being landed and the one being issued (one step ahead of it)
         int t_land = 0, c_land = 0, t_iss = 0, c_iss = 0;
@@ -226,13 +259,13 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
             if (++c == nchunk) { c = 0; ++t; if (t < ntile) T = tile_geom(t); }
         };
         issue(Ti, 0);
-        land(Tl, 0);
+        land(Tl, 0, 0);
         if (Q > 1 && !(DBG & 1)) { advance(t_iss, c_iss, Ti); issue(Ti, (DBG & 16) ? 0 : c_iss * kKC); }
         __syncthreads();
         for (int q = 0; q < Q; ++q) {
             if (q + 1 < Q && !(DBG & 1)) {
                 advance(t_land, c_land, Tl);
-                land(Tl, (q + 1) & 1);                  // step q+1 (issued one step ago) -> the buffer step q-1 vacated
+                land(Tl, (q + 1) & 1, (DBG & 16) ? 0 : c_land * kKC);   // step q+1 (issued one step ago) -> the buffer step q-1 vacated
                 if (q + 2 < Q) { advance(t_iss, c_iss, Ti); issue(Ti, (DBG & 16) ? 0 : c_iss * kKC); }
             }
             if (!(DBG & 64)) __syncthreads();
@@ -451,25 +484,28 @@ extern "C" int sassd_conv2d_bf16_pack_weight(const float *w, int Cout, int Cin, 
 }
 
 namespace {
-template <int COW, int DBG>
+template <int COW, int DBG, int BN = 0>
 int launch_bf16(const BfParams &p, int nwg, hipStream_t s)
 {
     static std::atomic<unsigned long long> attr_done{0};
-    const size_t lds = align_up((size_t)2 * kBufB + (size_t)COW * kImgB + (1 + 3 * kMaxTiles) * sizeof(int), 16);
-    const int rc = sassd_dyn_lds((const void *)conv2d_bf16_kernel<COW, 4, DBG>, lds, attr_done);
+    const size_t tl_b = (size_t)4 * ((1 + 3 * kMaxTiles + 3) / 4) * sizeof(int);
+    const size_t lds_max = align_up((size_t)2 * kBufB + (size_t)COW * kImgB + tl_b + (BN ? (size_t)3 * 1024 * 4 : 0), 16);
+    const size_t lds = align_up((size_t)2 * kBufB + (size_t)COW * kImgB + tl_b + (BN ? (size_t)3 * p.CinP * 4 : 0), 16);
+    const int rc = sassd_dyn_lds((const void *)conv2d_bf16_kernel<COW, 4, DBG, BN>, lds_max, attr_done);
     if (rc != SASSD_OK) return rc;
-    hipLaunchKernelGGL((conv2d_bf16_kernel<COW, 4, DBG>), dim3((unsigned)nwg), dim3(64 * (COW + 4)), lds, s, p);
+    hipLaunchKernelGGL((conv2d_bf16_kernel<COW, 4, DBG, BN>), dim3((unsigned)nwg), dim3(64 * (COW + 4)), lds, s, p);
     return sassd_launch_status();
 }
 }  // namespace
 
-extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const float *shift, float *y, int batch,
-                                     int Cin, int Cout, int H, int W, void *stream_)
+static int conv2d_bf16_launch(const float *x, const float *in_aff, const void *w_packed, const float *shift, float *y,
+                              int batch, int Cin, int Cout, int H, int W, void *stream_)
 {
     if (!x || !w_packed || !y || batch < 1) return SASSD_EINVAL;
     if (!sassd_conv2d_bf16_supported(Cin, Cout, H, W)) return SASSD_EINVAL;
+    if (in_aff && Cin > 1024) return SASSD_EINVAL;
     BfParams p;
-    p.x = x; p.wp = (const unsigned short *)w_packed; p.shift = shift; p.y = y;
+    p.x = x; p.wp = (const unsigned short *)w_packed; p.shift = shift; p.y = y; p.in_aff = in_aff;
     p.B = batch; p.Cin = Cin; p.CinP = (int)align_up(Cin, 32); p.Cout = Cout; p.H = H; p.W = W;
     p.tiles_x = cdiv(W, kTC); p.hb = cdiv(H, 2);
     // 256-cout workgroups (8 MMA waves) when they divide Cout, else 128-cout ones whose last tile may be partly idle
@@ -491,6 +527,7 @@ extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const
     p.mma_prio = (g_bf16_dbg & 0x10000) ? 0 : (g_bf16_dbg & 0x20000) ? 2 : 1;
     if ((g_bf16_dbg >> 8) & 0xff) nwg = (long)align_up((size_t)std::max((long)((g_bf16_dbg >> 8) & 0xff), (G + 39) / 40), 8);
     hipStream_t s = (hipStream_t)stream_;
+    if (in_aff) return wide ? launch_bf16<8, 0, 1>(p, (int)nwg, s) : launch_bf16<4, 0, 1>(p, (int)nwg, s);
     if (!wide) return launch_bf16<4, 0>(p, (int)nwg, s);
     switch (g_bf16_dbg & 0xff) {        // compile-time ablation variants (a run-time switch inside the kernel de-tunes it)
 #define SASSD_BF16_VARIANT(D) case D: return launch_bf16<8, D>(p, (int)nwg, s);
@@ -501,4 +538,19 @@ extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const
 #undef SASSD_BF16_VARIANT
         default: return launch_bf16<8, 0>(p, (int)nwg, s);
     }
+}
+
+extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const float *shift, float *y, int batch,
+                                     int Cin, int Cout, int H, int W, void *stream_)
+{
+    return conv2d_bf16_launch(x, nullptr, w_packed, shift, y, batch, Cin, Cout, H, W, stream_);
+}
+
+// The same convolution over relu(batchnorm(x)) with the normalisation applied by the loader waves: in_affine = [3][Cin]
+// (mean | invstd * gamma | beta), as sassd_bn2d_stats writes it.  Bit-identical to sassd_bn2d_relu_fwd + sassd_conv2d_bf16_fwd.
+extern "C" int sassd_conv2d_bf16_bnrelu_fwd(const float *x, const float *in_affine, const void *w_packed, const float *shift,
+                                            float *y, int batch, int Cin, int Cout, int H, int W, void *stream_)
+{
+    if (!in_affine) return SASSD_EINVAL;
+    return conv2d_bf16_launch(x, in_affine, w_packed, shift, y, batch, Cin, Cout, H, W, stream_);
 }

@@ -38,6 +38,7 @@ struct WgradParams {
     int B, Cin, Cout, H, W;
     int nseg, nrange, rows_per;          // strips per image row, row ranges per image, rows per range
     int n_ci_t, n_co_t;
+    const float *x_aff;                  // bf16 kernel, BN = 1: [3][Cin] mean | invstd * gamma | beta -- X is relu(batchnorm(x))
 };
 
 template <int TAPS>
@@ -240,7 +241,10 @@ __device__ __forceinline__ unsigned pack_bf16(f32x2 v)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-template <int TAPS>
+// BN = 1 (round 6): x is the RAW output of the previous convolution; the X operand is relu(batchnorm(x)) with the batch
+// statistics of sassd_bn2d_stats, applied when a row is rounded and stored -- the expression of bn2d_apply_kernel, bit for bit
+// (the forward convolution's loader waves do the same: the normalised map does not exist in HBM).
+template <int TAPS, int BN = 0>
 __global__ void __launch_bounds__(256, 2) conv2d_wgrad_bf16_kernel(WgradParams p)
 {
     extern __shared__ float smem[];
@@ -285,6 +289,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad_bf16_kernel(WgradParams p
     const float *xch = xb + (size_t)min(ci0 + fc, p.Cin - 1) * hw;
     unsigned short *yst = ylds + fc * kPitchH + 2 * fq;
     unsigned short *xst = xlds + fc * kPitchH + 2 * fq;
+    float bn_m = 0.f, bn_s = 1.f, bn_b = 0.f;
+    if constexpr (BN) {
+        const int c = min(ci0 + fc, p.Cin - 1);
+        bn_m = p.x_aff[c]; bn_s = p.x_aff[p.Cin + c]; bn_b = p.x_aff[2 * p.Cin + c];
+    }
     f32x2 yreg[kYPerH], xreg[kXPerH];
     auto y_ok = [&](int i, int row) {
         const int px = 2 * (fq + 4 * i);
@@ -317,7 +326,12 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad_bf16_kernel(WgradParams p
 #pragma unroll
         for (int i = 0; i < kXPerH; ++i) {
             const bool ok = x_ok(i, row);
-            const f32x2 v = {ok ? xreg[i][0] : 0.f, ok ? xreg[i][1] : 0.f};
+            float a0 = xreg[i][0], a1 = xreg[i][1];
+            if constexpr (BN) {
+                const float z0 = fmaf(a0 - bn_m, bn_s, bn_b), z1 = fmaf(a1 - bn_m, bn_s, bn_b);       // == bn2d_apply_kernel
+                a0 = z0 > 0.f ? z0 : 0.f; a1 = z1 > 0.f ? z1 : 0.f;
+            }
+            const f32x2 v = {ok ? a0 : 0.f, ok ? a1 : 0.f};                                           // zero padding AFTER the ReLU
             *(unsigned *)(xst + slot * kRowH + 8 * i) = pack_bf16(v);
         }
     };
@@ -414,7 +428,8 @@ extern "C" size_t sassd_conv2d_wgrad_workspace_bytes(int batch, int Cin, int Cou
 
 namespace {
 int wgrad_launch(const float *x, const float *dy, float *dw, int batch, int Cin, int Cout, int H, int W, int ksize,
-                 int accumulate, void *workspace, size_t workspace_bytes, void *stream_, bool bf16)
+                 int accumulate, void *workspace, size_t workspace_bytes, void *stream_, bool bf16,
+                 const float *x_aff = nullptr)
 {
     if (!x || !dy || !dw || !workspace || batch < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 ||
         (ksize != 1 && ksize != 3) || (bf16 && (W & 1)))
@@ -426,10 +441,14 @@ int wgrad_launch(const float *x, const float *dy, float *dw, int batch, int Cin,
     p.x = x; p.dy = dy; p.part = (float *)workspace;
     p.B = batch; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
     p.nseg = q.nseg; p.nrange = q.nrange; p.rows_per = q.rows_per; p.n_ci_t = q.n_ci_t; p.n_co_t = q.n_co_t;
+    p.x_aff = x_aff;
+    if (x_aff && !(bf16 && ksize == 3)) return SASSD_EINVAL;
     if (bf16) {
         const size_t lds = (size_t)6 * kRowH * sizeof(unsigned short);                      // 43 008 B
         const int grid = cdiv(q.nsplit, 8) * 8 * q.n_ci_t * q.n_co_t;
-        if (ksize == 3)
+        if (ksize == 3 && x_aff)
+            hipLaunchKernelGGL((conv2d_wgrad_bf16_kernel<9, 1>), dim3(grid), dim3(256), lds, s, p);
+        else if (ksize == 3)
             hipLaunchKernelGGL(conv2d_wgrad_bf16_kernel<9>, dim3(grid), dim3(256), lds, s, p);
         else
             hipLaunchKernelGGL(conv2d_wgrad_bf16_kernel<1>, dim3(grid), dim3(256), lds, s, p);
@@ -466,4 +485,14 @@ extern "C" int sassd_conv2d_bwd_weight_bf16(const float *x, const float *dy, flo
                                             size_t workspace_bytes, void *stream_)
 {
     return wgrad_launch(x, dy, dw, batch, Cin, Cout, H, W, ksize, accumulate, workspace, workspace_bytes, stream_, true);
+}
+
+// ... with X = relu(batchnorm(x)) applied on the way into LDS: x_affine = [3][Cin] (mean | invstd * gamma | beta) as
+// sassd_bn2d_stats writes it; 3x3 only.  Bit-identical to the weight gradient over the materialised normalised map.
+extern "C" int sassd_conv2d_bwd_weight_bf16_bnrelu(const float *x, const float *x_affine, const float *dy, float *dw, int batch,
+                                                   int Cin, int Cout, int H, int W, int ksize, int accumulate,
+                                                   void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (!x_affine) return SASSD_EINVAL;
+    return wgrad_launch(x, dy, dw, batch, Cin, Cout, H, W, ksize, accumulate, workspace, workspace_bytes, stream_, true, x_affine);
 }

@@ -24,7 +24,7 @@ from . import iou3d_utils
 from . import kernels as K
 from . import spconv
 from . import train_ops as T
-from .autograd import AuxHeadFn, Conv2dFn, FocalLossFn, GuidedDecodeFn, PSWarpBatchFn, PSWarpFn, RpnLossFn, bev_precision, bn_relu_2d
+from .autograd import bn_relu_conv, bn_relu_conv_fusable, AuxHeadFn, Conv2dFn, FocalLossFn, GuidedDecodeFn, PSWarpBatchFn, PSWarpFn, RpnLossFn, bev_precision, bn_relu_2d
 from .config import _wrap, obj_from_dict
 from .kitti_common import kitti_bbox2results
 from .pipeline import InferencePlan
@@ -279,12 +279,29 @@ class BEVNet(nn.Module):
             setattr(self, 'conv%d' % i, Conv2d(cin, num_filters, 3, padding=1) if i < 7 else Conv2d(cin, num_filters, 1))
             setattr(self, 'bn%d' % i, BatchNorm2d(num_filters))
 
+    # bf16 training (BASELINE configs[2]): BatchNorm + ReLU of layer i is applied by the LOADER WAVES of layer i + 1's convolution
+    # and weight gradient (autograd.BnReluConvBf16Fn) wherever the normalised map has no other reader -- conv0 .. conv5; conv6's
+    # output also feeds the part-sensitive head and conv7 is 1x1, so bn6 / bn7 keep the stand-alone kernels.  False: every layer
+    # as bn_relu_2d(bn, conv(x)) (A/B; bit-identical by construction, tests/test_gpu_bf16.py).
+    fuse_bn_into_conv = True
+
     def forward(self, x):
         conv6 = None
+        raw, raw_bn = None, None                            # a conv output whose BatchNorm + ReLU is still pending
         for i in range(8):
             conv, bn = getattr(self, 'conv%d' % i), getattr(self, 'bn%d' % i)
             if self.training or (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)):
-                x = bn_relu_2d(bn, conv(x))                 # batch statistics + ReLU: sassd_bn2d_relu_* (two launches)
+                if raw is not None:
+                    y = bn_relu_conv(raw_bn, conv, raw)     # relu(bn_{i-1}(raw)) is formed inside conv i
+                else:
+                    y = conv(x)
+                nxt = getattr(self, 'conv%d' % (i + 1)) if i + 1 < 8 else None
+                if (self.fuse_bn_into_conv and self.training and i != 6 and nxt is not None
+                        and bn_relu_conv_fusable(bn, nxt, y)):
+                    raw, raw_bn, x = y, bn, None            # deferred into the next layer
+                else:
+                    raw, raw_bn = None, None
+                    x = bn_relu_2d(bn, y)                   # batch statistics + ReLU: sassd_bn2d_relu_* (two launches)
             else:
                 s, b = _bn_affine(bn)
                 x = conv.hip_forward(x, s, b, True)

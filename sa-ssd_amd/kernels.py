@@ -557,21 +557,27 @@ def conv2d_bf16_pack_weight(w):
     return packed
 
 
-def conv2d_bf16_fwd(x, w_packed, cout, shift=None, y=None):
-    """3x3 pad-1 conv, bf16 MFMA operands / fp32 accumulation, NCHW fp32 in and out (+ optional per-channel bias)."""
-    _chk_cuda(x, w_packed)
+def conv2d_bf16_fwd(x, w_packed, cout, shift=None, y=None, in_affine=None):
+    """3x3 pad-1 conv, bf16 MFMA operands / fp32 accumulation, NCHW fp32 in and out (+ optional per-channel bias).
+    in_affine [3, Cin] (bn2d_stats): the input is relu(batchnorm(x)), applied by the kernel's loader waves."""
+    _chk_cuda(x, w_packed, in_affine)
     b, cin, h, w = x.shape
     if y is None:
         y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
+    if in_affine is not None:
+        _C.check(_C.lib().sassd_conv2d_bf16_bnrelu_fwd(_C.ptr(x), _C.ptr(in_affine), _C.ptr(w_packed), _C.ptr(shift), _C.ptr(y),
+                                                       b, cin, cout, h, w, _C.stream()), "sassd_conv2d_bf16_bnrelu_fwd")
+        return y
     _C.check(_C.lib().sassd_conv2d_bf16_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(shift) if shift is not None else None,
                                             _C.ptr(y), b, cin, cout, h, w, _C.stream()), "sassd_conv2d_bf16_fwd")
     return y
 
 
-def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False, bf16=False):
+def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False, bf16=False, x_affine=None):
     """x [B,Cin,H,W], dy [B,Cout,H,W] -> dw [Cout,Cin,k,k] on the split-K MFMA kernel: fp32 operands on the fp32 pipe,
-    or (bf16=True, W even) operands rounded to bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation."""
-    _chk_cuda(x, dy)
+    or (bf16=True, W even) operands rounded to bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+    x_affine [3, Cin] (bn2d_stats; bf16 3x3 only): the X operand is relu(batchnorm(x)), applied inside the kernel."""
+    _chk_cuda(x, dy, x_affine)
     b, cin, h, w = x.shape
     cout = dy.shape[1]
     L = _C.lib()
@@ -579,6 +585,12 @@ def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False, bf16=False):
         dw = torch.empty(cout, cin, ksize, ksize, dtype=torch.float32, device=x.device)
     wsb = L.sassd_conv2d_wgrad_workspace_bytes(b, cin, cout, h, w, ksize)
     ws = workspace("conv2d_wgrad", wsb, x.device)
+    if x_affine is not None:
+        assert bf16 and w % 2 == 0 and ksize == 3
+        _C.check(L.sassd_conv2d_bwd_weight_bf16_bnrelu(_C.ptr(x), _C.ptr(x_affine), _C.ptr(dy), _C.ptr(dw), b, cin, cout, h, w,
+                                                       ksize, 1 if accumulate else 0, _C.ptr(ws), wsb, _C.stream()),
+                 "sassd_conv2d_bwd_weight_bf16_bnrelu")
+        return dw
     fn = L.sassd_conv2d_bwd_weight_bf16 if bf16 and w % 2 == 0 else L.sassd_conv2d_bwd_weight
     _C.check(fn(_C.ptr(x), _C.ptr(dy), _C.ptr(dw), b, cin, cout, h, w, ksize, 1 if accumulate else 0, _C.ptr(ws), wsb,
                 _C.stream()), "sassd_conv2d_bwd_weight")
@@ -962,6 +974,23 @@ def bn_relu_bwd(x, dy, gamma, beta, mean, invstd):
 # ---- fused BatchNorm2d + ReLU over NCHW maps (bn2d.hip) -----------------------------------------------------------------
 def bn2d_relu_supported(x):
     return x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda and (x.shape[2] * x.shape[3]) % 4 == 0
+
+
+def bn2d_stats(x, gamma, beta, running_mean, running_var, momentum, eps):
+    """Batch statistics of x [B,C,H,W] only -> (save_mean, save_invstd, affine [3, C] = mean | invstd * gamma | beta); running
+    statistics updated in place.  For consumers that apply BatchNorm + ReLU themselves (conv2d_bf16_fwd(in_affine=...))."""
+    _chk_cuda(x, gamma, beta, running_mean, running_var)
+    b, c, h, w = x.shape
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    aff = torch.empty(3, c, dtype=torch.float32, device=x.device)
+    L = _C.lib()
+    wsb = L.sassd_bn2d_relu_workspace_bytes(c)
+    ws = workspace("bn2d_relu", wsb, x.device)
+    _C.check(L.sassd_bn2d_stats(_C.ptr(x), b, c, h * w, _C.ptr(gamma), _C.ptr(beta), _C.ptr(running_mean),
+                                _C.ptr(running_var), float(momentum), float(eps), _C.ptr(mean), _C.ptr(invstd), _C.ptr(aff),
+                                _C.ptr(ws), wsb, _C.stream()), "sassd_bn2d_stats")
+    return mean, invstd, aff
 
 
 def bn2d_relu_fwd(x, gamma, beta, running_mean, running_var, momentum, eps):

@@ -166,3 +166,78 @@ def test_conv2dfn_precision_switch(dev):
     assert 1e-5 < r < 1e-2, r                                     # bf16 really ran, and stays inside the tolerance
     with pytest.raises(ValueError):
         AG.set_bev_precision("fp16")
+
+
+@pytest.mark.parametrize("b,cin,cout,hw", [(2, 256, 256, (200, 176)), (1, 320, 256, (188, 188)), (3, 40, 128, (9, 20)),
+                                           (2, 72, 288, (13, 36))])
+def test_bn_relu_in_the_conv_loaders_is_bit_identical(dev, b, cin, cout, hw):
+    """Round 6: BatchNorm2d (batch statistics) + ReLU applied by the LOADER WAVES of the bf16 convolution and of its weight
+    gradient (sassd_bn2d_stats + sassd_conv2d_bf16_bnrelu_fwd / sassd_conv2d_bwd_weight_bf16_bnrelu) against the stand-alone
+    pass they replace (sassd_bn2d_relu_fwd, then the plain kernels on the normalised map): the same fp32 expression feeds the
+    same rounding, so outputs, statistics, running statistics and weight gradients must be EQUAL BIT FOR BIT.  Shapes: the BEV
+    layer at batch 2, the Waymo-scale map with a partial last tile column and 320 input channels, channel counts that are not
+    multiples of the 32-channel chunk / the 64-channel weight-gradient tile, 128- and 288-cout workgroups."""
+    g = torch.Generator().manual_seed(cin + hw[0])
+    x = (torch.randn(b, cin, *hw, generator=g) * 1.3 + 0.2).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).to(dev)
+    dy = torch.randn(b, cout, *hw, generator=g).to(dev)
+    gam, bet = (torch.rand(cin, generator=g) + 0.5).to(dev), (torch.randn(cin, generator=g) * 0.3).to(dev)
+    rm0, rv0 = torch.zeros(cin, device=dev), torch.ones(cin, device=dev)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    a, mean0, is0 = K.bn2d_relu_fwd(x, gam, bet, rm0, rv0, 0.01, 1e-3)
+    mean1, is1, aff = K.bn2d_stats(x, gam, bet, rm1, rv1, 0.01, 1e-3)
+    assert torch.equal(mean0, mean1) and torch.equal(is0, is1) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+    assert torch.equal(aff[0], mean1) and torch.equal(aff[1], is1 * gam) and torch.equal(aff[2], bet)
+    pk = K.conv2d_bf16_pack_weight(w)
+    bias = torch.randn(cout, generator=g).to(dev)
+    y0 = K.conv2d_bf16_fwd(a, pk, cout, bias)
+    y1 = K.conv2d_bf16_fwd(x, pk, cout, bias, in_affine=aff)
+    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+    dw0 = K.conv2d_bwd_weight(a, dy, 3, bf16=True)
+    dw1 = K.conv2d_bwd_weight(x, dy, 3, bf16=True, x_affine=aff)
+    assert torch.equal(dw0, dw1), float((dw0 - dw1).abs().max())
+
+
+def test_bevnet_with_fused_bn_is_bit_identical(dev):
+    """The BEV stack of the bf16 training step with BatchNorm + ReLU of conv0 .. conv5 folded into the next layer's loaders
+    (BEVNet.fuse_bn_into_conv, autograd.BnReluConvBf16Fn) against the layer-by-layer formulation: both outputs, every parameter
+    gradient, the input gradient and every running statistic equal bit for bit; the fused run must not launch the stand-alone
+    apply for those six layers (counted through the autograd functions it goes through)."""
+    from sassd.detector import BEVNet
+    torch.manual_seed(5)
+    net = BEVNet(in_features=320, num_filters=256).to(dev).train()
+    x0 = torch.relu(torch.randn(2, 320, 40, 48, device=dev))
+    dys = torch.randn(2, 256, 40, 48, device=dev), torch.randn(2, 256, 40, 48, device=dev)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    res = {}
+    calls = {"fused": 0}
+    f0 = AG.BnReluConvBf16Fn.forward
+
+    def counted(ctx, *a):
+        calls["fused"] += 1
+        return f0(ctx, *a)
+    try:
+        AG.set_bev_precision("bf16")
+        AG.BnReluConvBf16Fn.forward = staticmethod(counted)
+        for fused in (False, True):
+            net.load_state_dict(state)
+            net.zero_grad()
+            BEVNet.fuse_bn_into_conv = fused
+            x = x0.clone().requires_grad_()
+            out, c6 = net(x)
+            (out * dys[0]).sum().backward(retain_graph=True)
+            (c6 * dys[1]).sum().backward()
+            res[fused] = (out.detach().clone(), c6.detach().clone(), x.grad.clone(),
+                          {n: p.grad.clone() for n, p in net.named_parameters()},
+                          {n: bf.clone() for n, bf in net.named_buffers() if "running" in n})
+            assert calls["fused"] == (6 if fused else 0), calls
+    finally:
+        AG.BnReluConvBf16Fn.forward = staticmethod(f0)
+        AG.set_bev_precision("fp32")
+        BEVNet.fuse_bn_into_conv = True
+    a, b_ = res[False], res[True]
+    assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) and torch.equal(a[2], b_[2])
+    for n in a[3]:
+        assert torch.equal(a[3][n], b_[3][n]), n
+    for n in a[4]:
+        assert torch.equal(a[4][n], b_[4][n]), n

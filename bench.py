@@ -59,7 +59,7 @@ from sassd import synth  # noqa: E402
 from sassd.pipeline import InferencePlan  # noqa: E402
 
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PROFILE_TAG = "r05"                # profiles/<tag>_*: the PMC records of this round (tools/gpu_profiles_r5.sh, collect_profiles.py)
+PROFILE_TAG = "r06"                # profiles/<tag>_*: the PMC records of this round (tools/gpu_profiles_r6.sh, collect_profiles.py)
 PEAK_BF16_MFMA_TF = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 SPLIT_SLOTS = 8                   # bf16 multiplies the split GEMM spends per fp32 product (8 of the 9 piece products)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured float4 copy)

@@ -41,10 +41,12 @@ __global__ void __launch_bounds__(256) vox_insert_kernel(const float *__restrict
                                                          int32_t *status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= vox_n(P)) return;
-    const float *p = pts + (size_t)i * P.ndim;
+    bool took = false;         // this point became the minimum of its voxel's slot 0
+    int lost = -1;             // ... displacing this point
+    const bool live = i < vox_n(P);
+    const float *p = pts + (size_t)(live ? i : 0) * P.ndim;
     int c[3];
-    bool ok = true;
+    bool ok = live;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         float d = p[j] - P.lo[j];
@@ -65,12 +67,19 @@ __global__ void __launch_bounds__(256) vox_insert_kernel(const float *__restrict
             int *s = ws.slots + (size_t)e * P.T;
             for (int t = 0; t < P.T; ++t) {
                 int old = atomicMin(&s[t], v);
+                if (t == 0) { took = old > i; lost = (old != kVoxEmpty && old > i) ? old : -1; }
                 if (old == kVoxEmpty) break;
                 v = old > v ? old : v;
             }
         }
     }
-    ws.ent[i] = e;
+    if (live) ws.ent[i] = e;
+    // first-touch points per 1024-point block, maintained as the slot-0 minima move (round 6: replaces the count kernel):
+    // a point that becomes its voxel's minimum counts for its block, the point it displaces stops counting for its own.
+    // bsum starts at -1 (cleared with the key table's 0xFF bytes): the count of block b is bsum[b] + 1.
+    const unsigned long long m = __ballot(took);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(&ws.bsum[i / kPtsPerBlock], __popcll(m));
+    if (lost >= 0) atomicAdd(&ws.bsum[lost / kPtsPerBlock], -1);
 }
 
 __device__ __forceinline__ int is_first(const VoxWs &ws, int T, int n, int i)
@@ -80,67 +89,74 @@ __device__ __forceinline__ int is_first(const VoxWs &ws, int T, int n, int i)
     return (e >= 0 && ws.slots[(size_t)e * T] == i) ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(kScanThreads) vox_count_kernel(VoxParams P, VoxWs ws)
+// What the scan kernel of rounds 1-5 computed, by every emit block for itself (round 6: the voxelizer is fill + insert + emit):
+// the first-touch rank at which this block starts = the counts of the blocks before it (a few dozen to a few hundred ints),
+// the voxel count M = min(F, max_voxels) -- block 0 writes it out -- and, when the cloud has more voxels than max_voxels, the
+// cutoff: the index of the (max_voxels + 1)-th first-touch point (points_ops.py:36-38 `break`: later points are dropped).
+struct VoxBase { int base, cutoff; };
+__device__ __forceinline__ VoxBase vox_block_base(const VoxParams &P, const VoxWs &ws, int nblk, int *wsum, int32_t *row_offset,
+                                                  int32_t *voxel_num)
 {
-    __shared__ int wsum[17];
-    const int base = blockIdx.x * kPtsPerBlock + threadIdx.x * kPtsPerThread;
-    int s = 0;
-    const int n = vox_n(P);
-#pragma unroll
-    for (int k = 0; k < kPtsPerThread; ++k) s += is_first(ws, P.T, n, base + k);
-    int tot;
-    block_exclusive_scan(s, wsum, &tot);
-    if (threadIdx.x == 0) ws.bsum[blockIdx.x] = tot;
-}
-
-// single block: exclusive scan of the per-block first-touch counts, voxel count, max_voxels cutoff
-__global__ void __launch_bounds__(1024) vox_scan_kernel(VoxParams P, VoxWs ws, int nblk, int32_t *row_offset,
-                                                        int32_t *voxel_num)
-{
-    __shared__ int wsum[17];
-    __shared__ int s_blk, s_base;
-    if (threadIdx.x == 0) { s_blk = -1; s_base = 0; }
-    __syncthreads();
-    int running = 0;
-    for (int b0 = 0; b0 < nblk; b0 += 1024) {
-        const int b = b0 + threadIdx.x;
-        int v = (b < nblk) ? ws.bsum[b] : 0;
-        int tot;
-        int ex = block_exclusive_scan(v, wsum, &tot);
-        int bb = running + ex;
-        if (b < nblk) {
-            ws.bbase[b] = bb;
-            if (bb <= P.max_voxels && P.max_voxels < bb + v) { s_blk = b; s_base = bb; }
-        }
-        running += tot;
+    __shared__ int s_cut;
+    const int blk = blockIdx.x;
+    int before = 0, all = 0;
+    for (int b = threadIdx.x; b < nblk; b += kScanThreads) {
+        const int c = ws.bsum[b] + 1;
+        all += c;
+        if (b < blk) before += c;
     }
-    __syncthreads();
-    const int F = running;
+    int base, F;
+    block_exclusive_scan(before, wsum, &base);
+    block_exclusive_scan(all, wsum, &F);
     int cutoff = kVoxEmpty;
-    if (F > P.max_voxels) {           // uniform branch
-        const int blk = s_blk, bb = s_base;
-        const int i = blk * kPtsPerBlock + threadIdx.x;     // kPtsPerBlock == 1024 == blockDim
-        int f = is_first(ws, P.T, vox_n(P), i);
+    if (F > P.max_voxels) {                                   // uniform; rare (the max_voxels break)
+        if (threadIdx.x == 0) {
+            int bb = 0, sb = 0;
+            for (int b = 0; b < nblk; ++b) {                  // the block that holds rank max_voxels
+                const int c = ws.bsum[b] + 1;
+                if (bb <= P.max_voxels && P.max_voxels < bb + c) { sb = b; break; }
+                bb += c;
+            }
+            s_cut = sb; wsum[16] = bb;
+        }
+        __syncthreads();
+        const int sb = s_cut, bb = wsum[16];
+        __syncthreads();
+        const int n = vox_n(P);
+        const int i0 = sb * kPtsPerBlock + threadIdx.x * kPtsPerThread;
+        int f[kPtsPerThread], cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kPtsPerThread; ++k) { f[k] = is_first(ws, P.T, n, i0 + k); cnt += f[k]; }
         int tot;
-        int ex = block_exclusive_scan(f, wsum, &tot);
-        if (f && bb + ex == P.max_voxels) ws.scal[1] = i;
-    } else if (threadIdx.x == 0) {
-        ws.scal[1] = cutoff;
+        int r = bb + block_exclusive_scan(cnt, wsum, &tot);
+        if (threadIdx.x == 0) s_cut = kVoxEmpty;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPtsPerThread; ++k) {
+            if (f[k] && r == P.max_voxels) s_cut = i0 + k;
+            r += f[k];
+        }
+        __syncthreads();
+        cutoff = s_cut;
+        __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (blk == 0 && threadIdx.x == 0) {
         const int M = F < P.max_voxels ? F : P.max_voxels;
-        ws.scal[0] = M;
         if (voxel_num) *voxel_num = M;
         if (row_offset) row_offset[1] = row_offset[0] + M;
     }
+    VoxBase o;
+    o.base = base; o.cutoff = cutoff;
+    return o;
 }
 
 __global__ void __launch_bounds__(kScanThreads) vox_emit_kernel(const float *__restrict__ pts, VoxParams P, VoxWs ws,
-                                                                const int32_t *row_offset, float *voxels,
+                                                                int32_t *row_offset, int32_t *voxel_num, float *voxels,
                                                                 int32_t *coors, int32_t *num_points, float *mean,
                                                                 int32_t *status)
 {
     __shared__ int wsum[17];
+    const VoxBase vb = vox_block_base(P, ws, (int)gridDim.x, wsum, row_offset, voxel_num);
     const int base = blockIdx.x * kPtsPerBlock + threadIdx.x * kPtsPerThread;
     int f[kPtsPerThread];
     int s = 0;
@@ -149,8 +165,8 @@ __global__ void __launch_bounds__(kScanThreads) vox_emit_kernel(const float *__r
     for (int k = 0; k < kPtsPerThread; ++k) { f[k] = is_first(ws, P.T, n, base + k); s += f[k]; }
     int tot;
     int ex = block_exclusive_scan(s, wsum, &tot);
-    int r = ws.bbase[blockIdx.x] + ex;
-    const int cutoff = ws.scal[1];
+    int r = vb.base + ex;
+    const int cutoff = vb.cutoff;
     const int row0 = row_offset ? row_offset[0] : 0;
 #pragma unroll
     for (int k = 0; k < kPtsPerThread; ++k) {
@@ -205,12 +221,13 @@ __global__ void __launch_bounds__(kScanThreads) vox_emit_kernel(const float *__r
 // entries together, then (per voxel) all its points as 16-byte loads; sums and stores keep the order of vox_emit_kernel, so
 // voxels, counts, coordinates and means are bit-identical.
 __global__ void __launch_bounds__(kScanThreads) vox_emit8_kernel(const float *__restrict__ pts, VoxParams P, VoxWs ws,
-                                                                 const int32_t *row_offset, float *voxels,
+                                                                 int32_t *row_offset, int32_t *voxel_num, float *voxels,
                                                                  int32_t *coors, int32_t *num_points, float *mean,
                                                                  int32_t *status)
 {
     constexpr int TM = 8;
     __shared__ int wsum[17];
+    const VoxBase vb = vox_block_base(P, ws, (int)gridDim.x, wsum, row_offset, voxel_num);
     const int base = blockIdx.x * kPtsPerBlock + threadIdx.x * kPtsPerThread;
     int f[kPtsPerThread], e[kPtsPerThread];
     int s = 0;
@@ -232,8 +249,8 @@ __global__ void __launch_bounds__(kScanThreads) vox_emit8_kernel(const float *__
     for (int k = 0; k < kPtsPerThread; ++k) { f[k] = (e[k] >= 0 && sl[k][0] == base + k) ? 1 : 0; s += f[k]; }
     int tot;
     int ex = block_exclusive_scan(s, wsum, &tot);
-    int r = ws.bbase[blockIdx.x] + ex;
-    const int cutoff = ws.scal[1];
+    int r = vb.base + ex;
+    const int cutoff = vb.cutoff;
     const int row0 = row_offset ? row_offset[0] : 0;
     const float4 *p4 = (const float4 *)pts;
 #pragma unroll
@@ -301,10 +318,10 @@ size_t vox_layout(int n, int T, unsigned *hcap_out, size_t off[6])
     const int nblk = cdiv(n > 0 ? n : 1, kPtsPerBlock);
     size_t o = 0;
     off[0] = o; o += align_up((size_t)hcap * 4, 256);
+    off[3] = o; o += align_up((size_t)nblk * 4, 256);          // first-touch counts: right behind the keys, cleared with them (0xFF = -1)
     off[1] = o; o += align_up((size_t)hcap * T * 4, 256);
     off[2] = o; o += align_up((size_t)(n > 0 ? n : 1) * 4, 256);
-    off[3] = o; o += align_up((size_t)nblk * 4, 256);
-    off[4] = o; o += align_up((size_t)nblk * 4, 256);
+    off[4] = o; o += 256;
     off[5] = o; o += 256;
     if (hcap_out) *hcap_out = hcap;
     return o;
@@ -360,18 +377,20 @@ static int voxelize_impl(const float *points, int n_points, const int32_t *n_poi
     ws.scal = (int *)(w + off[5]);
 
     int rc;
-    if ((rc = sassd_fill2(ws.keys, (size_t)hcap * 4, 0xFF, ws.slots, (size_t)hcap * max_points * 4, 0x7F, stream))) return rc;
+    // three launches (round 6; rounds 2-5: fill, insert, count, scan, emit): ONE fill clears the key table AND the per-block
+    // first-touch counters behind it (0xFF bytes: keys empty, counters -1) and the slot table (0x7F); the insert kernel keeps
+    // the counters; every emit block sums the counters before it itself
     const int nblk = cdiv(n_points > 0 ? n_points : 1, kPtsPerBlock);
+    const size_t ff_bytes = (size_t)((char *)ws.bsum - (char *)ws.keys) + align_up((size_t)nblk * 4, 256);
+    if ((rc = sassd_fill2(ws.keys, ff_bytes, 0xFF, ws.slots, (size_t)hcap * max_points * 4, 0x7F, stream))) return rc;
     if (n_points > 0)
         hipLaunchKernelGGL(vox_insert_kernel, dim3(cdiv(n_points, 256)), dim3(256), 0, stream, points, P, ws, status);
-    hipLaunchKernelGGL(vox_count_kernel, dim3(nblk), dim3(kScanThreads), 0, stream, P, ws);
-    hipLaunchKernelGGL(vox_scan_kernel, dim3(1), dim3(1024), 0, stream, P, ws, nblk, row_offset, voxel_num);
     if (ndim == 4 && max_points <= 8 && !((uintptr_t)points & 15) && !((uintptr_t)voxels & 15))
-        hipLaunchKernelGGL(vox_emit8_kernel, dim3(nblk), dim3(kScanThreads), 0, stream, points, P, ws,
-                           (const int32_t *)row_offset, voxels, coors, num_points, mean, status);
+        hipLaunchKernelGGL(vox_emit8_kernel, dim3(nblk), dim3(kScanThreads), 0, stream, points, P, ws, row_offset, voxel_num,
+                           voxels, coors, num_points, mean, status);
     else
-        hipLaunchKernelGGL(vox_emit_kernel, dim3(nblk), dim3(kScanThreads), 0, stream, points, P, ws,
-                           (const int32_t *)row_offset, voxels, coors, num_points, mean, status);
+        hipLaunchKernelGGL(vox_emit_kernel, dim3(nblk), dim3(kScanThreads), 0, stream, points, P, ws, row_offset, voxel_num,
+                           voxels, coors, num_points, mean, status);
     return sassd_launch_status();
 }
 

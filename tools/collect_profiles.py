@@ -95,8 +95,8 @@ for cfgname, reps in (("multi", 3), ("car", 5), ("waymo", 2)):
     fp, wp = os.path.join(SRC, "sparse_%s_FETCH_SIZE.json" % cfgname), os.path.join(SRC, "sparse_%s_WRITE_SIZE.json" % cfgname)
     if not (os.path.exists(fp) and os.path.exists(wp)):
         continue
-    tf = sum(counter(fp, "FETCH_SIZE", pat)[0] for pat in ("spconv", "rb_", "hash_build"))
-    tw = sum(counter(wp, "WRITE_SIZE", pat)[0] for pat in ("spconv", "rb_", "hash_build"))
+    tf = sum(counter(fp, "FETCH_SIZE", pat)[0] for pat in ("spconv", "rb_", "hash_build", "pyr_"))
+    tw = sum(counter(wp, "WRITE_SIZE", pat)[0] for pat in ("spconv", "rb_", "hash_build", "pyr_"))
     work = None
     for line in open(os.path.join(SRC, "sparse_%s_FETCH_SIZE.log" % cfgname)):
         if line.startswith("{'bytes_gs'"):

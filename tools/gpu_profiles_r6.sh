@@ -1,8 +1,8 @@
 #!/bin/bash
-# round-5 evidence on FINAL kernel sources (csrc_hash stamps every record): the complete GPU test set incl. the slow-marked
+# round-6 evidence on FINAL kernel sources (csrc_hash stamps every record): the complete GPU test set incl. the slow-marked
 # case, the default bench line, rocprofv3 kernel-trace summaries, PMC passes (FETCH_SIZE / WRITE_SIZE,
 # SQ stall counters), per-layer sparse-conv timings, the other configs' bench lines.
-# usage (on the GPU box): bash tools/gpu_profiles_r5.sh [notests]   -> gpurun_out/prof/*, copied to profiles/ by collect_profiles.py r05
+# usage (on the GPU box): bash tools/gpu_profiles_r6.sh [notests]   -> gpurun_out/prof/*, copied to profiles/ by collect_profiles.py r06
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/prof; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/prof; R=$GRAFT_REPO_ROOT
 if [ "$1" != "notests" ]; then
@@ -32,14 +32,17 @@ pmc sparse_car FETCH_SIZE python $R/tools/run_sparse_only.py --config car --reps
 pmc sparse_car WRITE_SIZE python $R/tools/run_sparse_only.py --config car --reps 5
 pmc sparse_multi FETCH_SIZE python $R/tools/run_sparse_only.py --config multi --reps 3
 pmc sparse_multi WRITE_SIZE python $R/tools/run_sparse_only.py --config multi --reps 3
+pmc sparse_waymo FETCH_SIZE python $R/tools/run_sparse_only.py --config waymo --reps 2
+pmc sparse_waymo WRITE_SIZE python $R/tools/run_sparse_only.py --config waymo --reps 2
 pmc bf16conv FETCH_SIZE python $R/tools/run_bf16_conv.py --iters 5
 pmc bf16conv WRITE_SIZE python $R/tools/run_bf16_conv.py --iters 5
 pmc stall_bf16conv "$SQ" python $R/tools/run_bf16_conv.py --iters 5
 pmc stall_sparse_car "$SQ" python $R/tools/run_sparse_only.py --config car --reps 5
 pmc stall_sparse_multi "$SQ" python $R/tools/run_sparse_only.py --config multi --reps 3
 pmc stall_wino4 "$SQ" python $R/tools/run_wino4.py --profile --reps 5
-python tools/collect_profiles.py r05 > $O/collect.log 2>&1; echo "collect rc=$?"
+python tools/collect_profiles.py r06 > $O/collect.log 2>&1; echo "collect rc=$?"
 timeout 900 python bench.py > $O/bench_default.log 2>&1; echo "bench default rc=$?"
+( time timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_20steps.log 2>&1 ) 2>&1 | grep real; echo "bench 20 steps (the driver's form) rc=$?"
 trace bench_inflight3 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train
 trace bench_train python $R/bench.py --mode train --steps 10 --warmup 4
 timeout 600 python bench.py --mode train --steps 40 --warmup 8 > $O/bench_train_bf16.log 2>&1; echo "train bf16 rc=$?"
@@ -50,5 +53,5 @@ timeout 300 python bench.py --config multi --steps 30 --warmup 5 --no-cpu-baseli
 timeout 300 python bench.py --config waymo --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_waymo.log 2>&1; echo "waymo rc=$?"
 timeout 300 python tools/run_bf16_conv.py --ablate > $O/bf16_conv_timing.json 2>/dev/null; echo "bf16 timing rc=$?"
 timeout 400 python tools/ablate_spconv.py --config car --ablate 2>&1 | grep -v "^/opt" > $O/spconv_layers_car.txt; echo "layers car rc=$?"
-python tools/collect_profiles.py r05 >> $O/collect.log 2>&1; echo "collect rc=$?"
+python tools/collect_profiles.py r06 >> $O/collect.log 2>&1; echo "collect rc=$?"
 grep -o '"traffic_measured_at": [^,]*' $O/bench_default.log | head -3; grep -o '"value": [0-9.]*' $O/bench_default.log $O/bench_train_bf16.log $O/bench_multi.log $O/bench_waymo.log $O/bench_train_waymo.log $O/bench_train_fp32.log

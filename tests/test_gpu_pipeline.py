@@ -37,16 +37,15 @@ def _abs_err(a, b):
     return float(np.abs(a - b).max()) if a.size else 0.0
 
 
-def _box_ok(got, want, unbounded):
-    """1e-4 ABSOLUTE on every box field (north_star).  `unbounded` (the Waymo-scale random-weight model only, whose
-    activations grow with the 37 % BEV occupancy until regressions decode to 1e13 m boxes): fp32-relative 2e-5 on
-    fields larger than 5 m."""
+def _box_ok(got, want):
+    """1e-4 ABSOLUTE on every box field (north_star), every workload.  (Rounds 1-5 carried an fp32-relative escape for the
+    Waymo-scale random-weight model; its boxes measure 4.8e-7 absolute since the synthetic regression head was scaled: deleted in
+    round 6)"""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
-    tol = np.maximum(1e-4, 2e-5 * np.abs(want)) if unbounded else 1e-4
-    return bool(np.all(np.abs(got - want) <= tol))
+    return bool(np.all(np.abs(got - want) <= 1e-4))
 
 
-def _check_sample(tag, plan, res, ref, b, errs, unbounded=False):
+def _check_sample(tag, plan, res, ref, b, errs):
     """One sample against the oracle: guided anchors (same order), PSWarp logits, final boxes / scores / labels.
     ABSOLUTE 1e-4 on every box field and score (north_star), no skipped cases: the thresholds handed to the plan were
     chosen away from every oracle score (helpers.oracle_forward_safe)."""
@@ -59,7 +58,7 @@ def _check_sample(tag, plan, res, ref, b, errs, unbounded=False):
         errs["guided_by_field(x,y,z,w,l,h,r)"] = np.maximum(errs.get("guided_by_field(x,y,z,w,l,h,r)", 0.0), fe)
     e = _abs_err(got, gb.numpy())
     errs["guided_boxes"] = max(errs.get("guided_boxes", 0.0), e)
-    assert _box_ok(got, gb.numpy(), unbounded), (tag, "guided anchors", e)
+    assert _box_ok(got, gb.numpy()), (tag, "guided anchors", e)
     assert np.array_equal(plan.df["labels"][b, :k].cpu().numpy(), gl.numpy())
     e = _abs_err(plan.logits[b, :k].cpu().numpy(), ref["logits"][b].numpy())
     errs["pswarp_logits"] = max(errs.get("pswarp_logits", 0.0), e)
@@ -74,7 +73,7 @@ def _check_sample(tag, plan, res, ref, b, errs, unbounded=False):
     eb, es = _abs_err(res[b][0], d[0]), _abs_err(res[b][1], d[1])
     errs["det_boxes"] = max(errs.get("det_boxes", 0.0), eb)
     errs["det_scores"] = max(errs.get("det_scores", 0.0), es)
-    assert _box_ok(res[b][0], d[0], unbounded) and es <= 1e-4, (tag, "detections", eb, es)
+    assert _box_ok(res[b][0], d[0]) and es <= 1e-4, (tag, "detections", eb, es)
     assert np.array_equal(res[b][2], d[2])
     return len(d[0])
 
@@ -244,7 +243,7 @@ def test_waymo_scale_frame(dev, batch):
     assert e < 2e-5 * mx, (e, mx)
     assert np.array_equal(plan.mask.cpu().numpy().astype(bool), ref["masks"])
     res = plan.results()
-    ndet = sum(_check_sample("waymo", plan, res, ref, b, errs, unbounded=True) for b in range(batch))
+    ndet = sum(_check_sample("waymo", plan, res, ref, b, errs) for b in range(batch))
     print("max abs errors vs the CPU oracle (waymo-scale, batch %d): %s" % (batch, {k: (["%.1e" % x for x in v] if isinstance(v, np.ndarray) else "%.2e" % v) for k, v in errs.items()}))
     assert ndet >= 1
 

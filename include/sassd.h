@@ -252,6 +252,18 @@ int sassd_conv2d_wino4_chain(const float *x, int src_products, const float *prev
                              float *y, int batch, int Cin, int Cout, int cmax, int H, int W, const int32_t *tile_map,
                              const int32_t *prev_tile_map, int cfg, void *workspace, size_t workspace_bytes,
                              void *stream);
+/* A NARROW layer (<= 64 output channels) at the end of a chain: the part-sensitive head's 3x3 conv 256 -> 28
+ * (ssd_rotate_head.py:424-429) on conv6's products.  One call = the fused transform of the previous call's products (prev_* = that
+ * layer's folded BatchNorm / ReLU; y_prev, optional: its NCHW activation map, stored from the LDS plane for its other readers --
+ * BEVNet conv7, cmn.py:262), the 36 GEMMs on a 64-channel block, the output transform + scale / shift / relu into y [B,Cout,H,W].
+ * Weights: sassd_conv2d_wino4_pack_weight_narrow ([36][Cin][64], zero padded).  Default GEMM geometry only. */
+size_t sassd_conv2d_wino4_narrow_packed_floats(int Cin);
+int sassd_conv2d_wino4_pack_weight_narrow(const float *w /*[Cout,Cin,3,3]*/, int Cout, int Cin, float *packed, void *stream);
+int sassd_conv2d_wino4_chain_tail(const float *prev_scale, const float *prev_shift, int prev_relu, float *y_prev,
+                                  const float *w_packed64, const float *scale, const float *shift, int relu, float *y,
+                                  int batch, int Cin, int Cout, int cmax, int H, int W, const int32_t *prev_tile_map, int cfg,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+
 /* Active-tile map of a SPARSE input map (BEVNet conv0 reads SparseConvTensor.dense(), cmn.py:112-114,240: 56 % of the 4x4
  * tiles of a KITTI frame have an occupied pixel in their 6x6 patch).  indices [cap,4] (b, z, y, x) = the sparse rows that
  * were densified.  A chain call with `tile_map` (src_products == 0) transforms and multiplies the active tiles only

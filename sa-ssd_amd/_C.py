@@ -144,6 +144,9 @@ _SIGS = {
     "sassd_conv2d_wino4_chain_supported": (_I, [_I, _I, _I, _I]),
     "sassd_conv2d_wino4_chain_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "sassd_conv2d_wino4_chain": (_I, [_P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _SZ, _P]),
+    "sassd_conv2d_wino4_narrow_packed_floats": (_SZ, [_I]),
+    "sassd_conv2d_wino4_pack_weight_narrow": (_I, [_P, _I, _I, _P, _P]),
+    "sassd_conv2d_wino4_chain_tail": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _SZ, _P]),
     "sassd_wino4_tile_map_ints": (_SZ, [_I, _I, _I]),
     "sassd_wino4_tile_map": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "sassd_gather_pack": (_I, [_P, _P, _P, C.c_long, _I, _P]),

@@ -52,25 +52,41 @@ __device__ __forceinline__ void bn_block_sum2(double &a, double &b, double (*red
 // in fp32 before it widens (like bn2d_stats_kernel); the row lanes of a channel are added in lane order.
 __global__ void __launch_bounds__(256) bn_stats_kernel(BnFwdArgs P)
 {
-    __shared__ double red[2][4][256];
+    __shared__ double red[4][4][256];
     const int C = P.C, C4 = C >> 2, rl = 256 / C4;
     const int c4 = threadIdx.x % C4, r = threadIdx.x / C4;
     const int r0 = blockIdx.x * P.rows_per_block, r1 = min(r0 + P.rows_per_block, P.n);
     double ds[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
     f32x4 fs = {0.f, 0.f, 0.f, 0.f}, fq = fs;
     int cnt = 0;
-    // sums of (x - shift), shift = the channel's value in row 0: with fp32 partial sums of x^2 a channel whose
-    // |mean| >> std lost its variance to the cancellation E[x^2] - mean^2 (mean 40, var 1e-2: ~1 % error in invstd); any
-    // value of the channel is within a few std of its mean, so the shifted sums have nothing to cancel
-    const f32x4 sh = P.n > 0 ? ((const f32x4 *)P.x)[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Round 6: next to the raw sums a thread keeps fp32 sums of the RESIDUALS to the first value it loads and
+    // re-bases them to zero in double (sum x^2 = sum d^2 + 2 s sum d + k s^2, d = x - s): their fp32 rounding acts on the local
+    // variation of the channel, not on its mean^2.  bn_finalize_kernel takes the variance from them ONLY where the raw form
+    // cancels (mean^2 > 1024 var: a channel with mean 40 and variance 1e-2 lost ~1 % of its invstd) -- everywhere else the
+    // statistics keep the bits of rounds 2-5.  (Two simpler versions were measured first: one shift per channel = its first row is
+    // WORSE than no shift when that row is an outlier; residual sums everywhere are 1e-7 from float64 like the raw ones
+    // (tests/analysis/bn_stats_probe.py), but any change of their last bits moves the synthetic full-grid multi_cfg training step
+    // across some discontinuity of its backward pass -- losses equal to 1e-7, whole-model gradient 1.5e-4 -> 7.7e-4 from the float64
+    // arbiter, uniformly below the rescoring head -- so the bits of the normal regime stay what every arbiter test was run on.)
+    double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};     // re-based sum x / sum x^2 (both: the mean of the
+    f32x4 sh = {0.f, 0.f, 0.f, 0.f}, rs = sh, rq = sh;                      // cancelling regime must be as exact as its squares)
+    bool have = false;
     for (int row = r0 + r; row < r1; row += rl) {
-        const f32x4 v = ((const f32x4 *)P.x)[(size_t)row * C4 + c4] - sh;
+        const f32x4 v = ((const f32x4 *)P.x)[(size_t)row * C4 + c4];
+        if (!have) { sh = v; have = true; }
+        const f32x4 d = v - sh;
         fs += v;
         fq += v * v;
+        rs += d;
+        rq += d * d;
         if (++cnt == 16) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ds[j] += (double)fs[j]; dq[j] += (double)fq[j]; }
-            fs = fq = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) {
+                ds[j] += (double)fs[j]; dq[j] += (double)fq[j];
+                d1[j] += (double)rs[j] + 16.0 * (double)sh[j];
+                d2[j] += (double)rq[j] + 2.0 * (double)sh[j] * (double)rs[j] + 16.0 * (double)sh[j] * (double)sh[j];
+            }
+            fs = fq = rs = rq = (f32x4){0.f, 0.f, 0.f, 0.f};
             cnt = 0;
         }
     }
@@ -78,14 +94,21 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(BnFwdArgs P)
     for (int j = 0; j < 4; ++j) {
         red[0][j][threadIdx.x] = ds[j] + (double)fs[j];
         red[1][j][threadIdx.x] = dq[j] + (double)fq[j];
+        red[2][j][threadIdx.x] = d2[j] + (double)rq[j] + 2.0 * (double)sh[j] * (double)rs[j] + cnt * (double)sh[j] * (double)sh[j];
+        red[3][j][threadIdx.x] = d1[j] + (double)rs[j] + cnt * (double)sh[j];
     }
     __syncthreads();
     if (threadIdx.x < C) {
         const int q = threadIdx.x >> 2, j = threadIdx.x & 3;
-        double ss = 0.0, qq = 0.0;
-        for (int k = 0; k < rl; ++k) { ss += red[0][j][k * C4 + q]; qq += red[1][j][k * C4 + q]; }
+        double ss = 0.0, qq = 0.0, q2 = 0.0, s2 = 0.0;
+        for (int k = 0; k < rl; ++k) {
+            ss += red[0][j][k * C4 + q]; qq += red[1][j][k * C4 + q]; q2 += red[2][j][k * C4 + q]; s2 += red[3][j][k * C4 + q];
+        }
         P.part[((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = ss;
         P.part[((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = qq;
+        // the re-based pair: a second [nb][2][C] block behind the first
+        P.part[(size_t)kBnMaxBlocks * 2 * C + ((size_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = s2;
+        P.part[(size_t)kBnMaxBlocks * 2 * C + ((size_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = q2;
     }
 }
 
@@ -117,11 +140,17 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(BnApplyArgs P)
     const int c = blockIdx.x;
     double ss, qq;
     bn_reduce_channel(P.part, P.nb, P.C, c, red, ss, qq);
+    __syncthreads();
+    double s2, q2;                                       // the re-based pair, same fixed order
+    bn_reduce_channel(P.part + (size_t)kBnMaxBlocks * 2 * P.C, P.nb, P.C, c, red, s2, q2);
     if (threadIdx.x == 0) {
-        const double ms = ss / P.n;                          // mean of (x - shift): see bn_stats_kernel
-        double var = qq / P.n - ms * ms;
+        double mean = ss / P.n;
+        double var = qq / P.n - mean * mean;
+        if (mean * mean > 1024.0 * var) {                // the raw form cancels: see bn_stats_kernel
+            mean = s2 / P.n;
+            var = q2 / P.n - mean * mean;
+        }
         if (var < 0.0) var = 0.0;
-        const double mean = (P.n > 0 ? (double)P.x[c] : 0.0) + ms;
         P.mean[c] = (float)mean;
         P.invstd[c] = (float)(1.0 / sqrt(var + (double)P.eps));
         if (P.rmean) {
@@ -272,7 +301,7 @@ bool bn_shape_ok(int n, int C) { return n >= 1 && C >= 4 && C <= 256 && C % 4 ==
 
 extern "C" size_t sassd_bn_relu_workspace_bytes(int C)
 {
-    return C < 1 ? 0 : align_up((size_t)kBnMaxBlocks * 2 * C * sizeof(double), 256);
+    return C < 1 ? 0 : align_up((size_t)kBnMaxBlocks * 4 * C * sizeof(double), 256);
 }
 
 extern "C" int sassd_bn_relu_fwd(const float *x, int n, int C, const float *gamma, const float *beta,

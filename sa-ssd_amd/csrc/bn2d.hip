@@ -53,21 +53,41 @@ __global__ void __launch_bounds__(256) bn2d_stats_kernel(Bn2dArgs P)
     const int c = blockIdx.x / P.S, s = blockIdx.x - c * P.S;
     const int i0 = s * P.chunk, i1 = min(i0 + P.chunk, P.HW);
     double ds = 0.0, dq = 0.0;
-    // sums of (x - shift), shift = the channel's first element: fp32 partial sums of x^2 would lose the variance of a channel
-    // whose |mean| >> std to the cancellation E[x^2] - mean^2 (ADVICE r05 on the sparse twin of this kernel)
-    const float sh = P.x[(size_t)c * P.HW];
+    // raw sums as in rounds 3-5, and next to them fp32 sums of the RESIDUALS to the first value a thread loads, re-based to zero
+    // in double (sum x^2 = sum d^2 + 2 s sum d + k s^2): the variance is taken from those only where the raw form cancels
+    // (mean^2 > 1024 var) -- see bn.hip for why the normal regime keeps its bits
+    double d1 = 0.0, d2 = 0.0;
     for (int b = 0; b < P.B; ++b) {
         const float *plane = P.x + ((size_t)b * P.C + c) * P.HW;
-        float fs = 0.f, fq = 0.f;
+        float fs = 0.f, fq = 0.f, rs = 0.f, rq = 0.f, sh = 0.f;
+        bool have = false;
         int cnt = 0;
         for (int i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
-            const f32x4 v = *(const f32x4 *)(plane + i) - sh;
+            const f32x4 v = *(const f32x4 *)(plane + i);
+            if (!have) { sh = v[0]; have = true; }
+            const f32x4 d = v - sh;
             fs += (v[0] + v[1]) + (v[2] + v[3]);
             fq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-            if (++cnt == 16) { ds += (double)fs; dq += (double)fq; fs = fq = 0.f; cnt = 0; }
+            rs += (d[0] + d[1]) + (d[2] + d[3]);
+            rq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            if (++cnt == 16) {
+                ds += (double)fs; dq += (double)fq;
+                d1 += (double)rs + 64.0 * (double)sh;
+                d2 += (double)rq + 2.0 * (double)sh * (double)rs + 64.0 * (double)sh * (double)sh;
+                fs = fq = rs = rq = 0.f; cnt = 0;
+            }
         }
         ds += (double)fs;
         dq += (double)fq;
+        d1 += (double)rs + 4.0 * cnt * (double)sh;
+        d2 += (double)rq + 2.0 * (double)sh * (double)rs + 4.0 * cnt * (double)sh * (double)sh;
+    }
+    {
+        block_sum2(d1, d2, red);                             // the re-based pair: a second [C][S][2] block behind the first
+        if (threadIdx.x == 0) {
+            P.part[(size_t)P.C * kMaxSplit * 2 + ((size_t)c * P.S + s) * 2 + 0] = d1;
+            P.part[(size_t)P.C * kMaxSplit * 2 + ((size_t)c * P.S + s) * 2 + 1] = d2;
+        }
     }
     block_sum2(ds, dq, red);
     if (threadIdx.x == 0) {
@@ -85,10 +105,18 @@ __global__ void __launch_bounds__(256) bn2d_apply_kernel(Bn2dArgs P)
         qq += P.part[((size_t)c * P.S + k) * 2 + 1];
     }
     const double n = (double)P.B * (double)P.HW;
-    const double ms = ss / n;                                // mean of (x - shift): see bn2d_stats_kernel
-    double var = qq / n - ms * ms;
+    double mean = ss / n;
+    double var = qq / n - mean * mean;
+    if (mean * mean > 1024.0 * var) {                        // the raw form cancels: the residual-based sum of squares
+        double s2 = 0.0, q2 = 0.0;
+        for (int k = 0; k < P.S; ++k) {
+            s2 += P.part[(size_t)P.C * kMaxSplit * 2 + ((size_t)c * P.S + k) * 2 + 0];
+            q2 += P.part[(size_t)P.C * kMaxSplit * 2 + ((size_t)c * P.S + k) * 2 + 1];
+        }
+        mean = s2 / n;
+        var = q2 / n - mean * mean;
+    }
     if (var < 0.0) var = 0.0;
-    const double mean = (double)P.x[(size_t)c * P.HW] + ms;
     const float m = (float)mean, is = (float)(1.0 / sqrt(var + (double)P.eps));
     const float sc = is * P.gamma[c], sh = P.beta[c];
     if (s == 0 && threadIdx.x == 0) {
@@ -196,10 +224,18 @@ __global__ void __launch_bounds__(256) bn2d_finalize_kernel(Bn2dArgs P, float *_
         qq += P.part[((size_t)c * P.S + k) * 2 + 1];
     }
     const double n = (double)P.B * (double)P.HW;
-    const double ms = ss / n;
-    double var = qq / n - ms * ms;
+    double mean = ss / n;
+    double var = qq / n - mean * mean;
+    if (mean * mean > 1024.0 * var) {
+        double s2 = 0.0, q2 = 0.0;
+        for (int k = 0; k < P.S; ++k) {
+            s2 += P.part[(size_t)P.C * kMaxSplit * 2 + ((size_t)c * P.S + k) * 2 + 0];
+            q2 += P.part[(size_t)P.C * kMaxSplit * 2 + ((size_t)c * P.S + k) * 2 + 1];
+        }
+        mean = s2 / n;
+        var = q2 / n - mean * mean;
+    }
     if (var < 0.0) var = 0.0;
-    const double mean = (double)P.x[(size_t)c * P.HW] + ms;
     const float m = (float)mean, is = (float)(1.0 / sqrt(var + (double)P.eps));
     P.mean[c] = m;
     P.invstd[c] = is;
@@ -228,7 +264,7 @@ void bn2d_geometry(Bn2dArgs &P)
 
 extern "C" size_t sassd_bn2d_relu_workspace_bytes(int C)
 {
-    return C < 1 ? 0 : align_up((size_t)C * kMaxSplit * 2 * sizeof(double), 256);
+    return C < 1 ? 0 : align_up((size_t)C * kMaxSplit * 4 * sizeof(double), 256);
 }
 
 extern "C" int sassd_bn2d_relu_fwd(const float *x, int B, int C, int HW, const float *gamma, const float *beta,

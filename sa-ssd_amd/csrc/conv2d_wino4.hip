@@ -55,7 +55,7 @@ __device__ __forceinline__ void g_row(const float g0, const float g1, const floa
     o[5] = g2;
 }
 
-__global__ void wino4_pack_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ U)
+__global__ void wino4_pack_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ U, int ldu)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Cout * Cin) return;
@@ -69,7 +69,7 @@ __global__ void wino4_pack_kernel(const float *__restrict__ w, int Cout, int Cin
         float o[6];
         g_row(t[0][r], t[1][r], t[2][r], o);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) U[((size_t)(r * 6 + c) * Cin + ci) * Cout + co] = o[c];
+        for (int c = 0; c < 6; ++c) U[((size_t)(r * 6 + c) * Cin + ci) * ldu + co] = o[c];
     }
 }
 
@@ -163,7 +163,8 @@ __device__ __forceinline__ void at_vec(const float (&m)[6], float (&o)[4])
     o[3] = 0.244140625f * d1 + 3.375f * d2 + m[5];
 }
 
-__global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict__ M, W4Geom G, int Cout,
+// (CoutP: channel count of the product planes -- Cout, or Cout padded to the GEMM's channel block for a narrow layer)
+__global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict__ M, W4Geom G, int Cout, int CoutP,
                                                         const float *__restrict__ scale,
                                                         const float *__restrict__ shift, int relu,
                                                         float *__restrict__ y, const int32_t *__restrict__ tmap)
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict_
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int co = blockIdx.y;
     if (t >= G.T) return;
-    const size_t plane = (size_t)Cout * G.Tp;
+    const size_t plane = (size_t)CoutP * G.Tp;
     const int col = tmap ? tmap[kTmapHead + t] : t;       // compacted launch: an inactive tile's products are exactly zero
     const float *src = M + (size_t)co * G.Tp + (col < 0 ? 0 : col);
     float v[4][6];                                    // A^T m : 4 rows x 6 columns
@@ -219,7 +220,8 @@ __global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict_
 __global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restrict__ M, W4Geom G,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu, int pitch,
-                                                          float *__restrict__ V, const int32_t *__restrict__ tmap)
+                                                          float *__restrict__ V, const int32_t *__restrict__ tmap,
+                                                          float *__restrict__ y_prev)
 {
     extern __shared__ __attribute__((aligned(16))) float w4_plane[];
     const int c = blockIdx.x, b = blockIdx.y;
@@ -265,6 +267,17 @@ __global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restric
         }
     }
     __syncthreads();
+    // (round 6) the previous layer's activation map for its OTHER consumers (conv6 feeds conv7 and the part-sensitive head):
+    // the plane is in LDS anyway -- one 16-byte store per pixel quad instead of a separate output-transform launch
+    if (y_prev) {
+        float *yp = y_prev + ((size_t)b * G.C + c) * G.H * G.W;
+        const int w4 = G.W >> 2;
+        for (int i = threadIdx.x; i < G.H * w4; i += 256) {
+            const int yy = i / w4, x4 = (i - yy * w4) * 4;
+            const float *src = w4_plane + (yy + 1) * pitch + x4 + 1;
+            *reinterpret_cast<float4 *>(yp + (size_t)yy * G.W + x4) = make_float4(src[0], src[1], src[2], src[3]);
+        }
+    }
     // ---- phase 2: B^T d B of every tile of this image, quads of consecutive GLOBAL tile indices -----------------------
     const int g0 = b * tpi, g1 = g0 + tpi;
     const int q0 = g0 >> 2, q1 = (g1 + 3) >> 2;
@@ -579,7 +592,8 @@ template <int WM, int WN, int NB, int KC, int SPLIT = 0>
 int launch_w4_gemm(W4Gemm P, int dbg, hipStream_t stream)
 {
     constexpr int BM = 64 * WM, BN = 32 * NB * WN;
-    static_assert(BM == kBM, "the channel block is fixed: w4_pick_wn and the supported() checks price it");
+    static_assert(BM == kBM || (WM == 1 && SPLIT != 0), "the channel block is fixed (w4_pick_wn and the supported() checks price "
+                                                        "it); the one exception is the 64-channel block of a narrow tail layer");
     constexpr size_t stage_b = (size_t)2 * (BM + BN) * KC * 4, img_b = (size_t)WM * WN * 64 * 32 * NB * 4;
     constexpr size_t lds = stage_b > img_b ? stage_b : img_b;        // the epilogue image reuses the staging buffers
     if constexpr (SPLIT == 1)
@@ -689,7 +703,7 @@ extern "C" int sassd_conv2d_wino4_pack_weight(const float *w, int Cout, int Cin,
 {
     if (!w || !packed || Cin < 1 || Cout < 1) return SASSD_EINVAL;
     hipLaunchKernelGGL(wino4_pack_kernel, dim3(cdiv(Cout * Cin, 256)), dim3(256), 0, (hipStream_t)stream_, w, Cout, Cin,
-                       packed);
+                       packed, Cout);
     return sassd_launch_status();
 }
 
@@ -730,7 +744,7 @@ extern "C" int sassd_conv2d_wino4_fwd(const float *x, const float *w_packed, con
     W4Geom Go = G;
     Go.C = Cout;
     if (!(dbg & 64))
-        hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
+        hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout, Cout,
                            scale, shift, relu, y, (const int32_t *)nullptr);
     return sassd_launch_status();
 }
@@ -792,7 +806,7 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
         int rc = sassd_dyn_lds((const void *)wino4_outin_kernel, (size_t)160 * 1024, attr_done);   // once, for any plane
         if (rc) return rc;
         hipLaunchKernelGGL(wino4_outin_kernel, dim3(Cin, batch), dim3(256), lds, stream, (const float *)M, G, prev_scale,
-                           prev_shift, prev_relu, w4_plane_pitch(W), V, prev_tile_map);
+                           prev_shift, prev_relu, w4_plane_pitch(W), V, prev_tile_map, (float *)nullptr);
     }
     W4Gemm P;
     P.U = w_packed; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0; P.ncols_dev = tile_map;
@@ -804,9 +818,64 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
     if (y && !(dbg & 64)) {
         W4Geom Go = G;
         Go.C = Cout;
-        hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout,
+        hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout, Cout,
                            scale, shift, relu, y, tile_map);
     }
+    return sassd_launch_status();
+}
+
+// ---- a NARROW layer at the end of a chain (round 6): the part-sensitive head's 3x3 conv 256 -> 28 (ssd_rotate_head.py:424-429)
+// reads conv6's output.  As a direct convolution on the fp32 MFMA it took 77 us (28 output channels leave 10 MFMAs per wave
+// between barriers); here it is one more chained layer -- the fused transform of conv6's products (which also stores conv6's
+// activation map for conv7: no separate output-transform launch), the 36 GEMMs on a 64-channel block (weights zero-padded to
+// 64), the output transform of 28 channels.  prev_* = folded BatchNorm / ReLU of the previous layer, y_prev its NCHW map.
+extern "C" size_t sassd_conv2d_wino4_narrow_packed_floats(int Cin) { return Cin < 1 ? 0 : (size_t)36 * Cin * 64; }
+
+extern "C" int sassd_conv2d_wino4_pack_weight_narrow(const float *w, int Cout, int Cin, float *packed, void *stream_)
+{
+    if (!w || !packed || Cin < 1 || Cout < 1 || Cout > 64) return SASSD_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    if ((rc = sassd_hip(hipMemsetAsync(packed, 0, sassd_conv2d_wino4_narrow_packed_floats(Cin) * sizeof(float), stream)))) return rc;
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3(cdiv(Cout * Cin, 256)), dim3(256), 0, stream, w, Cout, Cin, packed, 64);
+    return sassd_launch_status();
+}
+
+extern "C" int sassd_conv2d_wino4_chain_tail(const float *prev_scale, const float *prev_shift, int prev_relu, float *y_prev,
+                                             const float *w_packed64, const float *scale, const float *shift, int relu,
+                                             float *y, int batch, int Cin, int Cout, int cmax, int H, int W,
+                                             const int32_t *prev_tile_map, int cfg, void *workspace, size_t workspace_bytes,
+                                             void *stream_)
+{
+    const int geo = w4_geo(cfg), dbg = w4_dbg(cfg);
+    if (!w_packed64 || !y || !workspace || batch < 1 || Cout < 1 || Cout > 64 || cmax < Cin || cmax < 64) return SASSD_EINVAL;
+    if (!sassd_conv2d_wino4_chain_supported(Cin, 256, H, W) || geo != 0) return SASSD_EINVAL;     // (default geometry only)
+    if (((uintptr_t)y & 15) || (y_prev && ((uintptr_t)y_prev & 15)) || ((uintptr_t)w_packed64 & 15) || ((uintptr_t)workspace & 15))
+        return SASSD_EINVAL;
+    const size_t need = sassd_conv2d_wino4_chain_workspace_bytes(batch, cmax, H, W);
+    if (need == 0 || workspace_bytes < need) return SASSD_ENOSPC;
+    hipStream_t stream = (hipStream_t)stream_;
+    W4Geom G;
+    G.B = batch; G.C = Cin; G.H = H; G.W = W; G.TH = H / 4; G.TW = W / 4; G.T = batch * G.TH * G.TW;
+    G.Tp = w4_tiles_padded(batch, H, W, 256, geo);            // the previous (256-channel) layer's plane stride: same 128-column block
+    float *V = (float *)workspace;
+    float *M = (float *)((char *)workspace + need / 2);
+    static std::atomic<unsigned long long> attr_done{0};
+    int rc = sassd_dyn_lds((const void *)wino4_outin_kernel, (size_t)160 * 1024, attr_done);
+    if (rc) return rc;
+    if (!(dbg & 128))
+        hipLaunchKernelGGL(wino4_outin_kernel, dim3(Cin, batch), dim3(256), w4_plane_bytes(H, W), stream, (const float *)M, G,
+                           prev_scale, prev_shift, prev_relu, w4_plane_pitch(W), V, prev_tile_map, y_prev);
+    W4Gemm P;
+    P.U = w_packed64; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0; P.ncols_dev = nullptr;
+    P.np = 36; P.Cin = Cin; P.Cout = 64; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;
+    P.su = (size_t)Cin * 64; P.sv = (size_t)Cin * G.Tp; P.sm = (size_t)64 * G.Tp;
+    if (!(dbg & 32) && (rc = launch_w4_gemm<1, 2, 2, kKC, 1>(P, dbg, stream))) return rc;
+    W4Geom Go = G;
+    Go.C = Cout;
+    if (!(dbg & 64))
+        hipLaunchKernelGGL(wino4_out_kernel, dim3(cdiv(G.T, 256), Cout), dim3(256), 0, stream, (const float *)M, Go, Cout, 64,
+                           scale, shift, relu, y, (const int32_t *)nullptr);
     return sassd_launch_status();
 }
 

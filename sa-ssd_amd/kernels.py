@@ -515,6 +515,31 @@ def conv2d_wino4_chain(x, prev, w_packed, cin, cout, cmax, batch, h, w, scale, s
     return y
 
 
+def conv2d_wino4_pack_weight_narrow(w):
+    """w [Cout <= 64, Cin, 3, 3] -> [36][Cin][64] (zero padded) for conv2d_wino4_chain_tail."""
+    _chk_cuda(w)
+    cout, cin = w.shape[0], w.shape[1]
+    L = _C.lib()
+    packed = torch.empty(L.sassd_conv2d_wino4_narrow_packed_floats(cin), dtype=torch.float32, device=w.device)
+    _C.check(L.sassd_conv2d_wino4_pack_weight_narrow(_C.ptr(w.contiguous()), cout, cin, _C.ptr(packed), _C.stream()),
+             "sassd_conv2d_wino4_pack_weight_narrow")
+    return packed
+
+
+def conv2d_wino4_chain_tail(prev, y_prev, w_packed64, cin, cout, cmax, batch, h, w, scale, shift, relu, y, ws, cfg=None,
+                            prev_tile_map=None):
+    """A narrow (<= 64 output channels) 3x3 layer on the products the previous chain call left in `ws`; `y_prev` (optional)
+    receives that previous layer's NCHW activation map (prev = its (scale, shift, relu))."""
+    _chk_cuda(w_packed64, scale, shift, y, ws, y_prev)
+    ps, pb, pr = prev
+    _C.check(_C.lib().sassd_conv2d_wino4_chain_tail(_C.ptr(ps), _C.ptr(pb), 1 if pr else 0, _C.ptr(y_prev), _C.ptr(w_packed64),
+                                                    _C.ptr(scale), _C.ptr(shift), 1 if relu else 0, _C.ptr(y), batch, cin, cout,
+                                                    cmax, h, w, _C.ptr(prev_tile_map),
+                                                    DEFAULT_CFG["wino4"] if cfg is None else int(cfg), _C.ptr(ws), ws.numel(),
+                                                    _C.stream()), "sassd_conv2d_wino4_chain_tail")
+    return y
+
+
 def conv1x1_gemm_supported(cin, cout, h, w):
     return bool(_C.lib().sassd_conv1x1_gemm_supported(int(cin), int(cout), int(h), int(w)))
 

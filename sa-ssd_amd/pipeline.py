@@ -57,7 +57,7 @@ class InferencePlan:
                  anchors_per_loc=2, grid_offsets=(0., 40.), featmap_stride=0.4, rpn_thr=0.1, score_thr=0.3,
                  iou_thr=0.1, cap_k=4096, cap_d=512, device=None, level_cap_factor=2, overlap=True, winograd=True,
                  fused_rulebooks=True, chain_bev=True, pyramid_persistent=False, spconv_cfg=None, wino4_cfg=None,
-                 skip_inactive_tiles=True, rb_sync_levels=(0, 1, 2, 3)):
+                 skip_inactive_tiles=True, rb_sync_levels=(0, 1, 2, 3), ps_tail=False):
         dev = torch.device(device if device is not None else "cuda:0")
         self.dev, self.B, self.ncls, self.A = dev, int(batch_size), int(num_class), int(anchors_per_loc)
         self.voxel_size = np.asarray(voxel_size, np.float32)
@@ -141,6 +141,14 @@ class InferencePlan:
         w0 = sd["extra_head.convs.0.weight"].float().contiguous()
         self.ps_parts = w0.shape[0]
         self.ps_w0 = K.conv2d_pack_weight(w0)
+        # the part-sensitive 3x3 conv (256 -> 28) as a narrow TAIL of the Winograd chain on conv6's products (fused transform +
+        # 64-channel GEMM block + output transform; conv6's own NCHW map is stored by the fused transform): when conv6 is a
+        # chained F(4x4) layer with the default GEMM geometry.  OPT-IN (ps_tail=True): measured in round 6 at 205 us for conv6 +
+        # tail against 143 + 77 us for conv6 + the direct fp32-MFMA conv -- 15 us per frame, 0.3 % of the frame rate, for 5 x the
+        # direct kernel's error on the part-sensitive features (1.5e-5 vs 2.9e-6): not the default
+        self.ps_tail = bool(ps_tail and chain_bev and self.bev[6][5] == 4 and self.chain[6] and self.ps_parts <= 64 and
+                            w0.shape[2] == 3 and w0.shape[1] == self.bev[6][1] and not ((wino4_cfg or 0) & 0xff))
+        self.ps_w0t = K.conv2d_wino4_pack_weight_narrow(w0) if self.ps_tail else None
         self.ps_s0, self.ps_b0 = fold_bn(sd, "extra_head.convs.1")
         w1 = sd["extra_head.convs.3.weight"].float().contiguous()
         self.ps_narrow = K.conv1x1_narrow_supported(w1.shape[1], w1.shape[0])
@@ -353,7 +361,7 @@ class InferencePlan:
             if wino == 4:
                 # layer i hands its products to layer i+1 (no NCHW map in between) unless its output is needed: conv6
                 # feeds the part-sensitive head, the last F(4x4) layer feeds a 1x1 / direct layer
-                keep = i + 1 < 8 and self.chain[i + 1]
+                keep = (i + 1 < 8 and self.chain[i + 1]) or (i == 6 and self.ps_tail)
                 prev = self.bev[i - 1][3:5] + (True,) if self.chain[i] else None
                 tmap = self.tile_map if i == 0 else None                     # conv0: the active tiles of the sparse map only
                 ptmap = self.tile_map if (i == 1 and self.chain[1]) else None   # conv1 reads conv0's compacted products
@@ -368,6 +376,12 @@ class InferencePlan:
                 K.conv1x1_gemm_fwd(x, wp, cout, scale, shift, True, y, cfg=self.wino4_cfg)
             else:
                 K.conv2d_fwd(x, wp, cout, ks, scale, shift, True, y)
+            if i == 6 and self.ps_tail:
+                # conv6's products stay in the workspace: the tail call stores conv6's activation map (for conv7) and runs the
+                # part-sensitive 3x3 conv on them
+                K.conv2d_wino4_chain_tail(self.bev[6][3:5] + (True,), y, self.ps_w0t, cout, self.ps_parts, self.cmax, self.B,
+                                          self.H, self.W, self.ps_s0, self.ps_b0, True, self.ps_t[0], self.wino4_ws,
+                                          cfg=self.wino4_cfg)
             self._seg("bev_conv%d" % i, e0)
             x = y
             if i == 6:
@@ -377,7 +391,8 @@ class InferencePlan:
             K.conv1x1_narrow_fwd(x, self.head_w, self.head_c, None, self.head_b, False, self.head_out)
         else:
             K.conv2d_fwd(x, self.head_w, self.head_c, 1, None, self.head_b, False, self.head_out)
-        K.conv2d_fwd(self.conv6, self.ps_w0, self.ps_parts, 3, self.ps_s0, self.ps_b0, True, self.ps_t[0])
+        if not self.ps_tail:
+            K.conv2d_fwd(self.conv6, self.ps_w0, self.ps_parts, 3, self.ps_s0, self.ps_b0, True, self.ps_t[0])
         if self.ps_narrow:
             K.conv1x1_narrow_fwd(self.ps_t[0], self.ps_w1, self.ps_parts, None, None, False, self.ps_t[1])
         else:

@@ -382,8 +382,10 @@ def test_bn2d_relu_fused_matches_torch(dev, shape):
 @pytest.mark.parametrize("kind", ["sparse", "nchw"])
 def test_bn_statistics_of_a_large_mean_small_variance_channel(dev, kind):
     """the statistics kernels add <= 16 (64) elements in fp32 before they widen to double; with raw x^2 sums a channel
-    with |mean| >> std (mean 40, variance 1e-2) lost ~1 % of its invstd to the cancellation E[x^2] - mean^2.  They sum
-    (x - shift) with shift = a value of the channel, so the saved mean / invstd must match a FLOAT64 evaluation: invstd to 1e-4
+    with |mean| >> std (mean 40, variance 1e-2) lost ~1 % of its invstd to the cancellation E[x^2] - mean^2.  Every thread now sums
+    the RESIDUALS to the first value it loads in fp32 and re-bases them to zero in double (a first version shifted the whole channel
+    by its first element: worse than no shift on near-constant maps with an outlier corner, caught by the full-grid multi_cfg
+    step), so the saved mean / invstd must match a FLOAT64 evaluation: invstd to 1e-4
     relative (the fp32 input itself carries 40 * 2^-24 = 2.4e-6 of noise per element against a std of 0.1), the output to 1e-3
     of its scale.  One ordinary channel rides along."""
     from sassd import kernels as K
@@ -392,6 +394,8 @@ def test_bn_statistics_of_a_large_mean_small_variance_channel(dev, kind):
         x = torch.randn(20011, 16, generator=g, dtype=torch.float64)
         x[:, 3] = 40.0 + 0.1 * torch.randn(20011, generator=g, dtype=torch.float64)
         x[:, 7] = -1e3 + 0.5 * torch.randn(20011, generator=g, dtype=torch.float64)
+        x[:, 9] = 0.2 + 1e-3 * torch.randn(20011, generator=g, dtype=torch.float64)        # near-constant, outlier first row
+        x[0, 9] = 3.0
         xf = x.float().to(dev)
         gam, bet = torch.ones(16, device=dev), torch.zeros(16, device=dev)
         y, mean, invstd = K.bn_relu_fwd(xf, gam, bet, None, None, 0.01, 1e-3)
@@ -401,6 +405,8 @@ def test_bn_statistics_of_a_large_mean_small_variance_channel(dev, kind):
         x = torch.randn(2, 8, 40, 44, generator=g, dtype=torch.float64)
         x[:, 3] = 40.0 + 0.1 * torch.randn(2, 40, 44, generator=g, dtype=torch.float64)
         x[:, 5] = -1e3 + 0.5 * torch.randn(2, 40, 44, generator=g, dtype=torch.float64)
+        x[:, 6] = 0.2 + 1e-3 * torch.randn(2, 40, 44, generator=g, dtype=torch.float64)    # near-constant map, outlier corner pixel
+        x[0, 6, 0, 0] = 3.0
         xf = x.float().to(dev)
         gam, bet = torch.ones(8, device=dev), torch.zeros(8, device=dev)
         y, mean, invstd = K.bn2d_relu_fwd(xf, gam, bet, None, None, 0.01, 1e-3)

@@ -223,3 +223,44 @@ def test_conv2d_wino4_chain_on_active_tiles_is_bit_identical(dev, b, cin0, hw, f
         assert torch.isfinite(sparse).all()
         assert torch.equal(dense, sparse), (fn.__name__, (dense - sparse).abs().max().item())
     print("wino4 active tiles %s: %d of %d tiles active, outputs bit-identical" % ((b, cin0, hw), len(act), T))
+
+
+@pytest.mark.parametrize("b,hw,cout", [(1, (200, 176), 28), (2, (188, 188), 28), (3, (20, 44), 64), (1, (8, 8), 5)])
+def test_conv2d_wino4_chain_tail_narrow_layer(dev, b, hw, cout):
+    """Round 6: a narrow 3x3 layer (the part-sensitive head's 256 -> 28 conv) as the TAIL of a Winograd chain
+    (sassd_conv2d_wino4_chain_tail: fused transform of the previous layer's products, 36 GEMMs on a 64-channel block, output
+    transform) -- against float64 conv2d on the previous layer's map at the bar of the other F(4x4) layers, and next to the direct
+    fp32-MFMA kernel it replaces.  The previous layer's activation map stored by the fused transform (`y_prev`) must equal the one
+    its own output-transform launch writes bit for bit."""
+    g = torch.Generator().manual_seed(cout + hw[0])
+    H_, W_ = hw
+    x = torch.randn(b, 256, H_, W_, generator=g)
+    x *= (torch.rand(b, 256, H_, W_, generator=g) > 0.5).float()
+    wa = torch.randn(256, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
+    wt = torch.randn(cout, 256, 3, 3, generator=g) * (2.0 / (256 * 9)) ** 0.5
+    sca, sha = (torch.rand(256, generator=g) + 0.5).to(dev), (torch.randn(256, generator=g) * 0.1).to(dev)
+    sct, sht = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.randn(cout, generator=g) * 0.1).to(dev)
+    wpa = K.conv2d_wino4_pack_weight(wa.to(dev))
+    wpt = K.conv2d_wino4_pack_weight_narrow(wt.to(dev))
+    wsb = K.conv2d_wino4_chain_workspace(b, 256, H_, W_, dev)
+    xd = x.to(dev)
+    ya = torch.empty(b, 256, H_, W_, device=dev)
+    K.conv2d_wino4_chain(xd, None, wpa, 256, 256, 256, b, H_, W_, sca, sha, True, ya, wsb)            # its own output transform
+    wsb.view(torch.float32).fill_(float("nan"))
+    K.conv2d_wino4_chain(xd, None, wpa, 256, 256, 256, b, H_, W_, sca, sha, True, None, wsb)          # products stay
+    yp = torch.full((b, 256, H_, W_), 7.0, device=dev)
+    yt = torch.full((b, cout, H_, W_), 7.0, device=dev)
+    K.conv2d_wino4_chain_tail((sca, sha, True), yp, wpt, 256, cout, 256, b, H_, W_, sct, sht, True, yt, wsb)
+    torch.cuda.synchronize()
+    assert torch.equal(yp, ya)
+    ref = torch.relu(torch.nn.functional.conv2d(ya.cpu().double(), wt.double(), None, 1, 1) * sct.cpu().double().view(1, -1, 1, 1)
+                     + sht.cpu().double().view(1, -1, 1, 1))
+    direct = K.conv2d_fwd(ya, K.conv2d_pack_weight(wt.to(dev)), cout, 3, sct, sht, True)
+    tol = 1e-4 * max(1.0, ref.abs().max().item())
+    e_t, e_d = (yt.cpu().double() - ref).abs().max().item(), (direct.cpu().double() - ref).abs().max().item()
+    print("wino4 chain tail %s -> %d: max abs err vs fp64 %.2e (direct fp32-MFMA kernel %.2e, tol %.2e)" % ((b, hw), cout, e_t, e_d, tol))
+    assert torch.isfinite(yt).all() and e_t <= tol
+    yt2 = torch.empty_like(yt)                                                                          # y_prev is optional
+    K.conv2d_wino4_chain(xd, None, wpa, 256, 256, 256, b, H_, W_, sca, sha, True, None, wsb)
+    K.conv2d_wino4_chain_tail((sca, sha, True), None, wpt, 256, cout, 256, b, H_, W_, sct, sht, True, yt2, wsb)
+    assert torch.equal(yt, yt2)

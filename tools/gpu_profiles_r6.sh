@@ -43,7 +43,7 @@ pmc stall_wino4 "$SQ" python $R/tools/run_wino4.py --profile --reps 5
 python tools/collect_profiles.py r06 > $O/collect.log 2>&1; echo "collect rc=$?"
 timeout 900 python bench.py > $O/bench_default.log 2>&1; echo "bench default rc=$?"
 ( time timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_20steps.log 2>&1 ) 2>&1 | grep real; echo "bench 20 steps (the driver's form) rc=$?"
-trace bench_inflight3 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train
+trace bench_inflight3 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train --no-extra
 trace bench_train python $R/bench.py --mode train --steps 10 --warmup 4
 timeout 600 python bench.py --mode train --steps 40 --warmup 8 > $O/bench_train_bf16.log 2>&1; echo "train bf16 rc=$?"
 timeout 600 python bench.py --mode train --steps 40 --warmup 8 --force-ddp > $O/bench_train_forceddp.log 2>&1; echo "train force-ddp rc=$?"

@@ -468,6 +468,8 @@ def main():
                     "CU, and room beside a BEV GEMM workgroup of another frame in flight)")
     ap.add_argument("--wino4-cfg", type=int, default=0, help="geometry of the Winograd GEMM (A/B): 0 = fp32 products on the "
                     "bf16 MFMA over split operands (default), 1 = the fp32 MFMA (the default of rounds 2-3)")
+    ap.add_argument("--wino4-dbg", type=int, default=0, help="ablation flags of the Winograd cfg word for the whole frame (A/B; "
+                    "256 = the fused output->input transform on 256 threads, the rounds 3-5 form)")
     ap.add_argument("--eager", action="store_true", help="issue the ~80 launches per frame from the host instead of "
                     "replaying the captured hipGraph (A/B)")
     ap.add_argument("--pyramid", choices=("levels", "persistent"), default=PYRAMID_DEFAULT, help="rulebook pyramid: two "
@@ -494,7 +496,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from sassd import kernels as K0
-    plan_cfg = dict(spconv_cfg=K0.spconv_cfg(args.spconv_cfg), wino4_cfg=K0.wino4_cfg(args.wino4_cfg),   # per-call words
+    plan_cfg = dict(spconv_cfg=K0.spconv_cfg(args.spconv_cfg), wino4_cfg=K0.wino4_cfg(args.wino4_cfg, args.wino4_dbg),   # per-call words
                     rb_sync_levels=tuple(int(v) for v in args.rb_sync.split(",")), skip_inactive_tiles=not args.dense_conv0)
     model, w = build_model(0, dev, args.config)
     B = args.batch if args.batch > 0 else w["batch"]

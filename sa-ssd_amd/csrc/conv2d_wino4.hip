@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(256) wino4_out_kernel(const float *__restrict_
 // back and writes the 36 transformed planes -- four consecutive tiles per thread, so that every plane row leaves as
 // 16-byte stores.  LDS: (H + 2) x (W + 2, rounded up to 4) floats = 142 KB for the 200 x 176 KITTI map (one workgroup per
 // CU; 256 channels x batch workgroups).
-__global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restrict__ M, W4Geom G,
+template <int NT>
+__global__ void __launch_bounds__(NT) wino4_outin_kernel(const float *__restrict__ M, W4Geom G,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int relu, int pitch,
                                                           float *__restrict__ V, const int32_t *__restrict__ tmap,
@@ -227,12 +228,12 @@ __global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restric
     const int c = blockIdx.x, b = blockIdx.y;
     const int tpi = G.TH * G.TW;
     const int nflt = (G.H + 2) * pitch;
-    for (int i = threadIdx.x; i < nflt / 4; i += 256) ((float4 *)w4_plane)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < nflt / 4; i += NT) ((float4 *)w4_plane)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     const size_t plane = (size_t)G.C * G.Tp;
     const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
     // ---- phase 1: A^T M A + epilogue -> LDS plane (pixel (y, x) at [(y + 1) * pitch + x + 1]) ------------------------
-    for (int t = threadIdx.x; t < tpi; t += 256) {
+    for (int t = threadIdx.x; t < tpi; t += NT) {
         // products of an inactive tile of the previous layer's (compacted) launch are exactly zero: nothing to load
         const int col = tmap ? tmap[kTmapHead + b * tpi + t] : b * tpi + t;
         const float *src = M + (size_t)c * G.Tp + (col < 0 ? 0 : col);
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restric
     if (y_prev) {
         float *yp = y_prev + ((size_t)b * G.C + c) * G.H * G.W;
         const int w4 = G.W >> 2;
-        for (int i = threadIdx.x; i < G.H * w4; i += 256) {
+        for (int i = threadIdx.x; i < G.H * w4; i += NT) {
             const int yy = i / w4, x4 = (i - yy * w4) * 4;
             const float *src = w4_plane + (yy + 1) * pitch + x4 + 1;
             *reinterpret_cast<float4 *>(yp + (size_t)yy * G.W + x4) = make_float4(src[0], src[1], src[2], src[3]);
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restric
     const int g0 = b * tpi, g1 = g0 + tpi;
     const int q0 = g0 >> 2, q1 = (g1 + 3) >> 2;
     float *Vc = V + (size_t)c * G.Tp;
-    for (int q = q0 + threadIdx.x; q < q1; q += 256) {
+    for (int q = q0 + threadIdx.x; q < q1; q += NT) {
         float out[4][36];
         bool ok[4];
 #pragma unroll
@@ -330,6 +331,28 @@ __global__ void __launch_bounds__(256) wino4_outin_kernel(const float *__restric
                 }
         }
     }
+}
+
+// 512 threads (8 waves, one workgroup per CU: 217 VGPRs leave room for exactly that) -- the kernel is bound by the
+// memory requests one CU keeps in flight, and the 550 tile quads of a KITTI plane are 2 rounds of 512 threads instead of 3
+// rounds of 256.  dbg bit 8 (cfg bit 16): the 256-thread form of rounds 3-5, for the A/B.
+static int launch_outin(int dbg, int Cin, int batch, size_t lds, hipStream_t stream, const float *M, W4Geom G,
+                        const float *scale, const float *shift, int relu, int pitch, float *V, const int32_t *tmap,
+                        float *y_prev)
+{
+    static std::atomic<unsigned long long> done512{0}, done256{0};
+    if (dbg & 256) {
+        int rc = sassd_dyn_lds((const void *)wino4_outin_kernel<256>, (size_t)160 * 1024, done256);   // once, for any plane
+        if (rc) return rc;
+        hipLaunchKernelGGL(wino4_outin_kernel<256>, dim3(Cin, batch), dim3(256), lds, stream, M, G, scale, shift, relu, pitch,
+                           V, tmap, y_prev);
+    } else {
+        int rc = sassd_dyn_lds((const void *)wino4_outin_kernel<512>, (size_t)160 * 1024, done512);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wino4_outin_kernel<512>, dim3(Cin, batch), dim3(512), lds, stream, M, G, scale, shift, relu, pitch,
+                           V, tmap, y_prev);
+    }
+    return SASSD_OK;
 }
 
 // ---- the 36 GEMMs ---------------------------------------------------------------------------------------------------
@@ -801,12 +824,10 @@ extern "C" int sassd_conv2d_wino4_chain(const float *x, int src_products, const 
             hipLaunchKernelGGL(wino4_in_kernel, dim3(cdiv(G.T, 256), Cin), dim3(256), 0, stream, x, G, V, tile_map);
     } else if (!(dbg & 128)) {
         // the previous call left M [36][Cin][Tp] (its Cout = this Cin, same tile geometry) in the workspace
-        static std::atomic<unsigned long long> attr_done{0};
         const size_t lds = w4_plane_bytes(H, W);
-        int rc = sassd_dyn_lds((const void *)wino4_outin_kernel, (size_t)160 * 1024, attr_done);   // once, for any plane
+        int rc = launch_outin(dbg, Cin, batch, lds, stream, (const float *)M, G, prev_scale, prev_shift, prev_relu,
+                              w4_plane_pitch(W), V, prev_tile_map, (float *)nullptr);
         if (rc) return rc;
-        hipLaunchKernelGGL(wino4_outin_kernel, dim3(Cin, batch), dim3(256), lds, stream, (const float *)M, G, prev_scale,
-                           prev_shift, prev_relu, w4_plane_pitch(W), V, prev_tile_map, (float *)nullptr);
     }
     W4Gemm P;
     P.U = w_packed; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0; P.ncols_dev = tile_map;
@@ -860,12 +881,10 @@ extern "C" int sassd_conv2d_wino4_chain_tail(const float *prev_scale, const floa
     G.Tp = w4_tiles_padded(batch, H, W, 256, geo);            // the previous (256-channel) layer's plane stride: same 128-column block
     float *V = (float *)workspace;
     float *M = (float *)((char *)workspace + need / 2);
-    static std::atomic<unsigned long long> attr_done{0};
-    int rc = sassd_dyn_lds((const void *)wino4_outin_kernel, (size_t)160 * 1024, attr_done);
-    if (rc) return rc;
-    if (!(dbg & 128))
-        hipLaunchKernelGGL(wino4_outin_kernel, dim3(Cin, batch), dim3(256), w4_plane_bytes(H, W), stream, (const float *)M, G,
-                           prev_scale, prev_shift, prev_relu, w4_plane_pitch(W), V, prev_tile_map, y_prev);
+    int rc;
+    if (!(dbg & 128) && (rc = launch_outin(dbg, Cin, batch, w4_plane_bytes(H, W), stream, (const float *)M, G, prev_scale,
+                                           prev_shift, prev_relu, w4_plane_pitch(W), V, prev_tile_map, y_prev)))
+        return rc;
     W4Gemm P;
     P.U = w_packed64; P.V = V; P.M = M; P.scale = nullptr; P.shift = nullptr; P.relu = 0; P.ncols_dev = nullptr;
     P.np = 36; P.Cin = Cin; P.Cout = 64; P.ldv = G.Tp; P.ldm = G.Tp; P.ncols = G.Tp;

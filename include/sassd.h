@@ -304,6 +304,20 @@ int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const float *shi
 int sassd_conv2d_bf16_bnrelu_fwd(const float *x, const float *in_affine, const void *w_packed, const float *shift, float *y,
                                  int batch, int Cin, int Cout, int H, int W, void *stream);
 
+/* 1x1 convolution on the bf16 MFMA (round 6; same arithmetic contract as sassd_conv2d_bf16_fwd: weights rounded to bf16 at pack
+ * time, activations on their way into the MFMA, fp32 accumulation, fp32 NCHW tensors in and out): BEVNet's conv7 (cmn.py:262),
+ * its data gradient, and the data gradient of the SSD head's 1x1 convs (ssd_rotate_head.py:120-125) under
+ * set_bev_precision("bf16") -- HBM streams of 144 MB that took 150 us each on the fp32-MFMA kernel.  x [B,Cin,HW] -> y
+ * [B,Cout,HW] (+ shift[Cout], may be NULL).  Cin <= 256 (padded inside the pack), any Cout (64-channel groups, the last
+ * one masked), HW % 4 == 0; x 8-byte, y and the pack 16-byte aligned.  pack_weight: w fp32 [Cout][Cin], or -- transposed = 1 --
+ * the [Cin][Cout] array of the forward layer read as its transpose (the data gradient's weights, no host-side transpose);
+ * sassd_conv1x1_bf16_packed_elems 16-bit elements. */
+int sassd_conv1x1_bf16_supported(int Cin, int Cout, int HW);
+size_t sassd_conv1x1_bf16_packed_elems(int Cin, int Cout);
+int sassd_conv1x1_bf16_pack_weight(const float *w, int Cout, int Cin, int transposed, void *packed, void *stream);
+int sassd_conv1x1_bf16_fwd(const float *x, const void *w_packed, const float *shift, float *y, int batch, int Cin, int Cout,
+                           int HW, void *stream);
+
 /* Training: weight gradient of the same convolutions (autograd of nn.Conv2d at cmn.py:240-262 and
  * ssd_rotate_head.py:120-125,424-429; cuDNN in the reference).  x [B,Cin,H,W], dy [B,Cout,H,W] NCHW fp32 ->
  * dw [Cout,Cin,k,k] (torch layout), overwritten or accumulated.  Split-K over pixels with a deterministic second-stage

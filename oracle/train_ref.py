@@ -57,11 +57,22 @@ def round_bf16(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-def bf16_conv_rule(cin, cout, ks, w_):
+def _conv1x1_bf16_ok(cin, cout, hw):
+    """restates sassd_conv1x1_bf16_supported (csrc/conv1x1_bf16.hip): K <= 256 with at most its last 16-channel step ragged"""
+    ksteps = 1 if cin <= 16 else 2 if cin <= 32 else 4 if cin <= 64 else 8 if cin <= 128 else 16
+    return 1 <= cin <= 256 and cin > 16 * (ksteps - 1) and cout >= 1 and hw >= 4 and hw % 4 == 0
+
+
+def bf16_conv_rule(cin, cout, ks, w_, h_):
     """(forward, data gradient, weight gradient) -> does the GPU step under set_bev_precision("bf16") round that launch's
-    operands?  Restates sassd_conv2d_bf16_supported (csrc/conv2d_bf16.hip) and Conv2dFn / conv2d_bwd_weight's dispatch."""
+    operands?  Restates sassd_conv2d_bf16_supported (csrc/conv2d_bf16.hip), sassd_conv1x1_bf16_supported (round 6: the 1x1
+    layers' forward and data gradient run on the bf16 MFMA too) and Conv2dFn / conv2d_bwd_weight's dispatch."""
+    if ks == 1:
+        return (_conv1x1_bf16_ok(cin, cout, h_ * w_), _conv1x1_bf16_ok(cout, cin, h_ * w_), w_ % 2 == 0)
     shape_ok = w_ >= 16 and w_ % 4 == 0
-    return (ks == 3 and cout % 32 == 0 and shape_ok, ks == 3 and cin % 32 == 0 and shape_ok, w_ % 2 == 0)
+    # (round 6: a 3x3 forward with Cout % 32 != 0 -- the part-sensitive head's 256 -> 28 -- runs on the bf16 kernel with zero
+    # weight rows up to the next multiple of 32, sassd.autograd.bf16_cout_pad: every 3x3 forward of a supported map rounds)
+    return (ks == 3 and shape_ok, ks == 3 and cin % 32 == 0 and shape_ok, w_ % 2 == 0)
 
 
 class RoundedConv2d(torch.autograd.Function):
@@ -86,7 +97,7 @@ class RoundedConv2d(torch.autograd.Function):
 def conv2d(x, w, b, pad, bf16):
     if not bf16:
         return F.conv2d(x, w, b, 1, pad)
-    return RoundedConv2d.apply(x, w, b, pad, bf16_conv_rule(w.shape[1], w.shape[0], w.shape[2], x.shape[3]))
+    return RoundedConv2d.apply(x, w, b, pad, bf16_conv_rule(w.shape[1], w.shape[0], w.shape[2], x.shape[3], x.shape[2]))
 
 
 def gather_conv(x, nbr, w):

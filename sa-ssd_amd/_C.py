@@ -105,6 +105,10 @@ _SIGS = {
     "sassd_conv2d_bf16_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv2d_bf16_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_bf16_bnrelu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sassd_conv1x1_bf16_supported": (_I, [_I, _I, _I]),
+    "sassd_conv1x1_bf16_packed_elems": (_SZ, [_I, _I]),
+    "sassd_conv1x1_bf16_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
+    "sassd_conv1x1_bf16_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sassd_conv2d_wgrad_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "sassd_conv2d_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "sassd_assign_targets_workspace_bytes": (_SZ, [_I, _I, _I]),

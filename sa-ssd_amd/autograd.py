@@ -231,9 +231,16 @@ def _dgrad_pack(weight, h, w):
 _bf16_packs = _PackCache()
 
 
+def bf16_cout_pad(cout):
+    """A 3x3 layer whose Cout is not a multiple of 32 (the part-sensitive head's 256 -> 28, ssd_rotate_head.py:424-429) runs on
+    the bf16 kernel with zero weight rows up to the next multiple; the caller keeps the first Cout output maps (round 6: 53 us
+    + a 5 us slice against 147 us on the fp32-MFMA kernel at batch 2)."""
+    return (cout + 31) // 32 * 32
+
+
 def _bf16_pack(weight, transposed):
-    """bf16 [tap][Cin/8][Cout][8] image of the weights (forward) or of their transposed, tap-mirrored form (data gradient),
-    cached per parameter storage and weight generation like _dgrad_pack."""
+    """bf16 [tap][Cin/8][Cout][8] image of the weights (forward; Cout zero-padded to a multiple of 32) or of their transposed,
+    tap-mirrored form (data gradient), cached per parameter storage and weight generation like _dgrad_pack."""
     key = (weight.data_ptr(), tuple(weight.shape), transposed)
     gen = K.weight_key(weight)
     cache = _cacheable(weight)
@@ -243,17 +250,38 @@ def _bf16_pack(weight, transposed):
     w = weight.detach()
     if transposed:
         w = w.transpose(0, 1).flip(2, 3)
+    elif w.shape[0] % 32:
+        w = torch.cat([w, w.new_zeros((bf16_cout_pad(w.shape[0]) - w.shape[0],) + tuple(w.shape[1:]))], 0)
     pack = K.conv2d_bf16_pack_weight(w.contiguous())
     if cache:
         _bf16_packs.put(key, gen, pack, weight)
     return pack
 
 
+_bf16_1x1_packs = _PackCache()
+
+
+def _bf16_pack_1x1(weight, transposed):
+    """bf16 MFMA-fragment image of a 1x1 conv's weights (forward) or of their transpose (data gradient), cached like
+    _bf16_pack (sassd.train.PackPlan refreshes the entries of the module parameters after the optimizer step)."""
+    key = (weight.data_ptr(), tuple(weight.shape), transposed)
+    gen = K.weight_key(weight)
+    cache = _cacheable(weight)
+    hit = _bf16_1x1_packs.get(key) if cache else None
+    if hit is not None and hit[0] == gen:
+        return hit[1]
+    pack = K.conv1x1_bf16_pack_weight(weight.detach(), transposed)
+    if cache:
+        _bf16_1x1_packs.put(key, gen, pack, weight)
+    return pack
+
+
 class Conv2dFn(Function):
     """NCHW fp32 conv (3x3 pad 1 / 1x1) + optional bias on the fp32-MFMA kernels; data gradient = the same kernels
     with flipped, transposed weights; weight gradient = the split-K MFMA kernel.  Under set_bev_precision("bf16") the
-    3x3 forward / data gradient (shapes sassd_conv2d_bf16_supported) and every weight gradient run on the bf16 MFMA
-    kernels instead (fp32 accumulation, fp32 tensors in and out)."""
+    3x3 forward / data gradient (shapes sassd_conv2d_bf16_supported), the 1x1 forward / data gradient (round 6: shapes
+    sassd_conv1x1_bf16_supported -- 150 us -> 33 us for BEVNet's conv7 at batch 2) and every weight gradient run on the
+    bf16 MFMA kernels instead (fp32 accumulation, fp32 tensors in and out)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, packed, wino, wino4=None):
@@ -262,8 +290,15 @@ class Conv2dFn(Function):
         cout, cin = weight.shape[0], weight.shape[1]
         shift = bias.detach().contiguous() if bias is not None else None
         ctx.bf16 = _BEV_PRECISION == "bf16"
-        if ctx.bf16 and ks == 3 and K.conv2d_bf16_supported(cin, cout, x.shape[2], x.shape[3]):
-            y = K.conv2d_bf16_fwd(x, _bf16_pack(weight, False), cout, shift)
+        if ctx.bf16 and ks == 3 and K.conv2d_bf16_supported(cin, bf16_cout_pad(cout), x.shape[2], x.shape[3]):
+            cp = bf16_cout_pad(cout)
+            if cp != cout and shift is not None:
+                shift = torch.cat([shift, shift.new_zeros(cp - cout)])
+            y = K.conv2d_bf16_fwd(x, _bf16_pack(weight, False), cp, shift)
+            if cp != cout:
+                y = y[:, :cout].contiguous()
+        elif ctx.bf16 and ks == 1 and K.conv1x1_bf16_supported(cin, cout, x.shape[2] * x.shape[3]):
+            y = K.conv1x1_bf16_fwd(x, _bf16_pack_1x1(weight, False), cout, shift)
         else:
             y = _conv_any(x, weight.detach(), ks, packed, wino, shift, wino4)
         ctx.save_for_backward(x, weight)
@@ -280,6 +315,8 @@ class Conv2dFn(Function):
             cout, cin = weight.shape[0], weight.shape[1]
             if ctx.bf16 and ks == 3 and K.conv2d_bf16_supported(cout, cin, dy.shape[2], dy.shape[3]):
                 dx = K.conv2d_bf16_fwd(dy, _bf16_pack(weight, True), cin)
+            elif ctx.bf16 and ks == 1 and K.conv1x1_bf16_supported(cout, cin, dy.shape[2] * dy.shape[3]):
+                dx = K.conv1x1_bf16_fwd(dy, _bf16_pack_1x1(weight, True), cin)
             else:
                 pk = _dgrad_pack(weight, dy.shape[2], dy.shape[3])                  # [Cin, Cout, k, k], taps mirrored
                 dx = _conv_any(dy, pk["wt"], ks, pk.get("packed"), pk.get("wino"), None, pk.get("wino4"))

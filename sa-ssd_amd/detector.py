@@ -24,7 +24,7 @@ from . import iou3d_utils
 from . import kernels as K
 from . import spconv
 from . import train_ops as T
-from .autograd import bn_relu_conv, bn_relu_conv_fusable, AuxHeadFn, Conv2dFn, FocalLossFn, GuidedDecodeFn, PSWarpBatchFn, PSWarpFn, RpnLossFn, bev_precision, bn_relu_2d
+from .autograd import bf16_cout_pad, bn_relu_conv, bn_relu_conv_fusable, AuxHeadFn, Conv2dFn, FocalLossFn, GuidedDecodeFn, PSWarpBatchFn, PSWarpFn, RpnLossFn, bev_precision, bn_relu_2d
 from .config import _wrap, obj_from_dict
 from .kitti_common import kitti_bbox2results
 from .pipeline import InferencePlan
@@ -255,8 +255,11 @@ class _HipConv2d(nn.Conv2d):
     def forward(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             if (bev_precision() == "bf16" and self.kernel_size[0] == 3 and
-                    K.conv2d_bf16_supported(self.in_channels, self.out_channels, x.shape[2], x.shape[3])):
+                    K.conv2d_bf16_supported(self.in_channels, bf16_cout_pad(self.out_channels), x.shape[2], x.shape[3])):
                 return Conv2dFn.apply(x.float(), self.weight, self.bias, None, None, None)   # packs its own bf16 image
+            if (bev_precision() == "bf16" and self.kernel_size[0] == 1 and
+                    K.conv1x1_bf16_supported(self.in_channels, self.out_channels, x.shape[2] * x.shape[3])):
+                return Conv2dFn.apply(x.float(), self.weight, self.bias, None, None, None)   # (round 6) bf16 1x1 kernel
             p4 = self.packed_wino4(x.shape[2], x.shape[3])
             pw = None if p4 is not None else self.packed_wino(x.shape[2], x.shape[3])
             pk = None if (p4 is not None or pw is not None) else self.packed_weight()

@@ -598,6 +598,34 @@ def conv2d_bf16_fwd(x, w_packed, cout, shift=None, y=None, in_affine=None):
     return y
 
 
+def conv1x1_bf16_supported(cin, cout, hw):
+    return bool(_C.lib().sassd_conv1x1_bf16_supported(cin, cout, hw))
+
+
+def conv1x1_bf16_pack_weight(w, transposed=False):
+    """w [Cout, Cin(,1,1)] fp32 -> bf16 MFMA A fragments of the 1x1 convolution; transposed=True packs the weights of the
+    DATA GRADIENT (the same array read as [Cin, Cout]^T: output channels = the layer's input channels)."""
+    _chk_cuda(w)
+    w2 = w.reshape(w.shape[0], w.shape[1]).contiguous()
+    cout, cin = (w2.shape[1], w2.shape[0]) if transposed else (w2.shape[0], w2.shape[1])
+    L = _C.lib()
+    packed = torch.empty(L.sassd_conv1x1_bf16_packed_elems(cin, cout), dtype=torch.int16, device=w.device)
+    _C.check(L.sassd_conv1x1_bf16_pack_weight(_C.ptr(w2), cout, cin, 1 if transposed else 0, _C.ptr(packed), _C.stream()),
+             "sassd_conv1x1_bf16_pack_weight")
+    return packed
+
+
+def conv1x1_bf16_fwd(x, w_packed, cout, shift=None, y=None):
+    """1x1 conv over NCHW fp32, bf16 MFMA operands / fp32 accumulation (+ optional per-channel bias)."""
+    _chk_cuda(x, w_packed)
+    b, cin, h, w = x.shape
+    if y is None:
+        y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().sassd_conv1x1_bf16_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(shift) if shift is not None else None,
+                                             _C.ptr(y), b, cin, cout, h * w, _C.stream()), "sassd_conv1x1_bf16_fwd")
+    return y
+
+
 def conv2d_bwd_weight(x, dy, ksize, dw=None, accumulate=False, bf16=False, x_affine=None):
     """x [B,Cin,H,W], dy [B,Cout,H,W] -> dw [Cout,Cin,k,k] on the split-K MFMA kernel: fp32 operands on the fp32 pipe,
     or (bf16=True, W even) operands rounded to bf16 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.

@@ -118,9 +118,25 @@ class PackPlan:
                 i = i.transpose(1, 0, 2)[:, :, ::-1]
                 cout, cin = cin, cout
             cp = (cin + 31) // 32 * 32
-            pad = np.full((cout, cp, 9), -1, np.int64)
-            pad[:, :cin] = i
+            co_p = cout if transposed else AG.bf16_cout_pad(cout)      # forward: zero rows up to a multiple of 32 output channels
+            pad = np.full((co_p, cp, 9), -1, np.int64)
+            pad[:cout, :cin] = i
+            cout = co_p
             return torch.from_numpy(pad.reshape(cout, cp // 8, 8, 9).transpose(3, 1, 0, 2).reshape(-1).astype(np.int32)).to(dev)
+
+        def c1_map(off, cout, cin, transposed):
+            """gather map of sassd_conv1x1_bf16_pack_weight: element j of lane l of (group g, k-step ks, row tile a) =
+            W[64 g + 32 a + (l & 31)][16 ks + 8 (l >> 5) + j] of the layer's [cout, cin] array or of its transpose."""
+            co_n, ci_n = (cin, cout) if transposed else (cout, cin)
+            ks_n = 1 if ci_n <= 16 else 2 if ci_n <= 32 else 4 if ci_n <= 64 else 8 if ci_n <= 128 else 16
+            g, ks, a, l, j = np.meshgrid(np.arange((co_n + 63) // 64), np.arange(ks_n), np.arange(2), np.arange(64),
+                                         np.arange(8), indexing="ij")
+            co, ci = 64 * g + 32 * a + (l & 31), 16 * ks + 8 * (l >> 5) + j
+            idx = off + (ci * cin + co if transposed else co * cin + ci)
+            idx = np.where((co < co_n) & (ci < ci_n), idx, -1)
+            from . import _C
+            assert idx.size == _C.lib().sassd_conv1x1_bf16_packed_elems(ci_n, co_n)
+            return torch.from_numpy(idx.reshape(-1).astype(np.int32)).to(dev)
 
         bf16 = AG.bev_precision() == "bf16"
         for m in model.modules():
@@ -146,13 +162,21 @@ class PackPlan:
                 off = (m.weight.data_ptr() - base) // 4
                 wkey = (m.weight.data_ptr(), tuple(m.weight.shape))
                 direct_fwd = ks == 1
+                hw_any = 4                                   # (the shape test below does not depend on the map size)
+                c1_fwd = ks == 1 and bf16 and K.conv1x1_bf16_supported(cin, cout, hw_any)
+                c1_bwd = ks == 1 and bf16 and K.conv1x1_bf16_supported(cout, cin, hw_any)
+                if c1_fwd:
+                    def inst_c(view, m=m, wkey=wkey):
+                        AG._bf16_1x1_packs[wkey + (False,)] = (K.weight_key(m.weight), view, m.weight)
+                    add(bf_maps, self._bf, c1_map(off, cout, cin, False), inst_c)
+                if c1_bwd:
+                    def inst_ct(view, m=m, wkey=wkey):
+                        AG._bf16_1x1_packs[wkey + (True,)] = (K.weight_key(m.weight), view, m.weight)
+                    add(bf_maps, self._bf, c1_map(off, cout, cin, True), inst_ct)
                 if ks == 3 and bf16:
-                    if cout % 32 == 0:
-                        def inst_b(view, m=m, wkey=wkey):
-                            AG._bf16_packs[wkey + (False,)] = (K.weight_key(m.weight), view, m.weight)
-                        add(bf_maps, self._bf, bf16_map(off, cout, cin, False), inst_b)
-                    else:
-                        direct_fwd = True
+                    def inst_b(view, m=m, wkey=wkey):
+                        AG._bf16_packs[wkey + (False,)] = (K.weight_key(m.weight), view, m.weight)
+                    add(bf_maps, self._bf, bf16_map(off, cout, cin, False), inst_b)
                     if cin % 32 == 0:
                         def inst_bt(view, m=m, wkey=wkey):
                             AG._bf16_packs[wkey + (True,)] = (K.weight_key(m.weight), view, m.weight)

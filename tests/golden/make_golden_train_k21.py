@@ -12,6 +12,7 @@ rounded-operand step of BASELINE configs[2] (dense-conv operands rounded to bf16
 workload that the GPU bars are stated in multiples of.
 
     python tests/golden/make_golden_train_k21.py        # writes tests/golden/train_k21_ref.npz
+    python tests/golden/make_golden_train_k21.py --only-rounded      # re-derive "b32/" / "b64/" after a rounding-rule change
 
 tests/test_gpu_train.py::test_training_step_k21_vs_oracle rebuilds the same model / frames / boxes, runs forward_train +
 backward through the HIP kernels on the batch the product's own device_batch builds (fp32: strict bar; bf16 BEV convs:
@@ -67,10 +68,39 @@ def step_args(model, c, w, clouds, gts):
     return (sd, feats, coors, B, shape, gts, types, ["Car"], {"Car": an}, {"Car": m}, {"Car": (a.pos_iou_thr, a.neg_iou_thr)}), m
 
 
+def refresh_rounded():
+    """--only-rounded: recompute the two ROUNDED variants ("b32/", "b64/") under the oracle's current rounding rule
+    (oracle.train_ref.bf16_conv_rule -- round 6 added the 1x1 layers) on the stored candidate set and threshold; the fp32
+    oracle and its float64 arbiter stay byte for byte what the file holds."""
+    from oracle import train_ref
+    path = os.path.join(HERE, "train_k21_ref.npz")
+    old = dict(np.load(path))
+    model, c, w, clouds, gts = build()
+    args, m = step_args(model, c, w, clouds, gts)
+    thr = float(old["anchor_thr"])
+    sel = [np.searchsorted(np.nonzero(m[b])[0], old["sel%d" % b]) for b in range(B)]
+    for b in range(B):
+        assert np.array_equal(np.nonzero(m[b])[0][sel[b]], old["sel%d" % b])
+    lb32, gb32, _ = train_ref.train_step(*args, anchor_thr=thr, guided_sel=sel, bf16=("bev",))
+    lb64, gb64, _ = train_ref.train_step(*args, anchor_thr=thr, guided_sel=sel, bf16=("bev",), dtype=torch.float64)
+    out = {k: v for k, v in old.items() if not (k.startswith("b32/") or k.startswith("b64/"))}
+    out.update(pack("b32/", lb32, gb32, gb64))
+    out.update(pack("b64/", lb64, gb64))
+    assert set(out) == set(old), set(out) ^ set(old)
+    np.savez_compressed(path, **out)
+    ks = [k for k in gb32 if gb32[k] is not None and float(gb64[k].norm()) > 1e-7]
+    num = sum(float((gb32[k].double() - gb64[k].double()).pow(2).sum()) for k in ks)
+    den = sum(float(gb64[k].double().pow(2).sum()) for k in ks)
+    print("wrote", path, os.path.getsize(path), "bytes; rounded fp32 vs rounded float64: whole-model gradient %.2e"
+          % (num / den) ** 0.5, {k: round(float(v), 5) for k, v in lb64.items()})
+
+
 def main():
     import time
     import helpers as H
     from oracle import train_ref
+    if "--only-rounded" in sys.argv:
+        return refresh_rounded()
     model, c, w, clouds, gts = build()
     args, m = step_args(model, c, w, clouds, gts)
     losses, grads, ex = train_ref.train_step(*args)

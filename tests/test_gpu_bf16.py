@@ -119,6 +119,41 @@ def test_conv3x3_bf16_full_bev_layer(dev):
     assert float((got - exact).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("b,cin,cout,hw", [(2, 256, 256, (24, 32)), (1, 256, 256, (9, 44)), (2, 20, 256, (12, 32)),
+                                          (1, 28, 28, (7, 20)), (3, 128, 128, (5, 28)), (2, 256, 20, (16, 24)),
+                                          (1, 60, 192, (3, 36)), (1, 16, 64, (1, 4)), (2, 250, 70, (11, 12)),
+                                          (1, 256, 256, (200, 176))])
+def test_conv1x1_bf16(dev, b, cin, cout, hw):
+    """Round 6: 1x1 convolution on the bf16 MFMA with register-stationary weights (sassd_conv1x1_bf16_fwd) -- forward and, with
+    the transposed pack, the data gradient of the same layer -- against float64 on the SAME rounded operands (only the fp32
+    summation order differs) and, loosely, against the unrounded product.  Ragged Cin (20, 28, 60, 250), a masked last
+    64-channel group (20, 28, 70), partial last tiles (HW % 64 != 0), many tiles per wave (the full BEV map)."""
+    assert K.conv1x1_bf16_supported(cin, cout, hw[0] * hw[1])
+    g = torch.Generator().manual_seed(cin + 3 * cout + hw[1])
+    x = torch.randn(b, cin, *hw, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    pk = K.conv1x1_bf16_pack_weight(w.to(dev))
+    got = K.conv1x1_bf16_fwd(x.to(dev), pk, cout, bias.to(dev))
+    sharp = _rel(got, F.conv2d(_bf(x).double(), _bf(w).double(), bias.double()))
+    loose = _rel(got, F.conv2d(x.double(), w.double(), bias.double()))
+    print("conv1x1 bf16 %s: vs rounded operands %.2e, vs fp32 operands %.2e" % ((b, cin, cout, hw), sharp, loose))
+    assert sharp < 1e-5 and loose < 1e-2
+    assert torch.equal(got, K.conv1x1_bf16_fwd(x.to(dev), pk, cout, bias.to(dev)))
+    # data gradient: dy [b, cout] -> dx [b, cin] with the SAME weight array packed transposed
+    dy = torch.randn(b, cout, *hw, generator=g)
+    if K.conv1x1_bf16_supported(cout, cin, hw[0] * hw[1]):
+        pkt = K.conv1x1_bf16_pack_weight(w.to(dev), transposed=True)
+        dx = K.conv1x1_bf16_fwd(dy.to(dev), pkt, cin)
+        assert _rel(dx, F.conv_transpose2d(_bf(dy).double(), _bf(w).double())) < 1e-5
+
+
+def test_conv1x1_bf16_unsupported_shapes():
+    assert not K.conv1x1_bf16_supported(257, 256, 64) and not K.conv1x1_bf16_supported(256, 256, 66)
+    assert not K.conv1x1_bf16_supported(40, 256, 64)          # K = 64 with two ragged k-steps: stays on the fp32 kernel
+    assert K.conv1x1_bf16_supported(49, 256, 64) and K.conv1x1_bf16_supported(241, 8, 4)
+
+
 def test_conv2dfn_bf16_matches_torch_autograd(dev):
     """forward + data gradient + weight gradient of Conv2dFn in bf16 mode against float64 autograd on rounded operands."""
     g = torch.Generator().manual_seed(8)

@@ -454,7 +454,7 @@ def test_bf16_step_launches_vs_rounded_reference(dev):
     for e in log:
         x, w = e[1].cpu(), e[2].cpu()
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        rf, rd, rw = train_ref.bf16_conv_rule(cin, cout, ks, x.shape[3])
+        rf, rd, rw = train_ref.bf16_conv_rule(cin, cout, ks, x.shape[3], x.shape[2])
         tagk = "%dx%d %d->%d" % (ks, ks, cin, cout)
         if e[0] == "fwd":
             ref = F.conv2d(rb(x) if rf else x, rb(w) if rf else w, None if e[3] is None else e[3].cpu(), 1, ks // 2)
@@ -762,8 +762,12 @@ def test_bf16_and_fp32_training_trajectories_agree(dev):
     not bit-equal -- the auxiliary head scatters with float atomics -- and 200 steps amplify that, so the yardstick is the
     fp32 run-to-run spread.  Measured on an MI355X (mean of the last 20 steps): total loss 1.522 / 1.588 / 1.466 -- fp32
     run-to-run 4.3 %, bf16 vs fp32 3.7 %; worst single term bf16 vs fp32: aux_loss_reg 15 % (fp32 run-to-run: rpn_dir_loss
-    12 %, rpn_loc_loss 11 %); step 0: 105.5128 / 105.5128 / 105.5209.  Bands: total within 10 %, every one of the six terms
-    within 25 % of the fp32 run, step-0 losses within 1e-3, and both runs must have LEARNED (loss under 5 % of its start; measured 1.4-1.5 %)."""
+    12 %, rpn_loc_loss 11 %); step 0: 105.5128 / 105.5128 / 105.5209.  Later boxes of the round gave fp32 pairs 1.422 / 1.629
+    (14.6 % apart) and bf16 1.545 / 1.466 (the 1x1 layers and the 256 -> 28 layer on the bf16 MFMA as well): over all runs seen,
+    fp32 ends at 1.42 .. 1.63 (mean 1.56, sigma 6 %), bf16 at 1.47 .. 1.55 -- inside the fp32 spread.  Two single draws from
+    distributions 6 % wide differ by more than 10 % one time in five, so the bands are 3 sigma of that difference: total within
+    25 % of the fp32 run (or 1.5 x the fp32 pair's own distance, if larger), every one of the six terms within 45 %, step-0 losses
+    within 1e-3, and both runs must have LEARNED (loss under 5 % of its start; measured 1.4-1.5 %)."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "analysis"))
@@ -779,7 +783,7 @@ def test_bf16_and_fp32_training_trajectories_agree(dev):
         rr, bf = abs(f[t] - g[t]) / abs(f[t]), abs(h[t] - f[t]) / abs(f[t])
         line.append("%s %.4g/%.4g/%.4g (fp32 run-to-run %.1f%%, bf16 %.1f%%)" % (t, f[t], g[t], h[t], 100 * rr, 100 * bf))
         assert np.isfinite(h[t]) and np.isfinite(f[t])
-        assert bf <= (0.10 if t == "loss" else 0.25), (t, f[t], h[t], bf)
+        assert bf <= max(0.25 if t == "loss" else 0.45, 1.5 * rr), (t, f[t], g[t], h[t], bf)
     print("training trajectories after %d steps, mean of the last 20 (fp32 / fp32 again / bf16): %s" % (steps, "; ".join(line)))
     l0 = [runs[k]["loss"][0] for k in ("fp32", "fp32_again", "bf16")]
     assert abs(l0[0] - l0[1]) <= 1e-3 * l0[0] and abs(l0[2] - l0[0]) <= 1e-3 * l0[0], l0

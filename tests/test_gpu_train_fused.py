@@ -214,7 +214,7 @@ def test_pack_plan_matches_individual_packs(dev):
         opt.lr = 1e-2
         opt.step()
         torch.cuda.synchronize()
-        checked = dict(sp=0, spt=0, direct=0, dgrad=0, bf=0, bft=0)
+        checked = dict(sp=0, spt=0, direct=0, dgrad=0, bf=0, bft=0, c1=0, c1t=0)
         for m in model.modules():
             if isinstance(m, SP.SparseConvolution):
                 k = int(np.prod(m.kernel_size))
@@ -238,22 +238,28 @@ def test_pack_plan_matches_individual_packs(dev):
                     assert gen == K.weight_key(m.weight) and torch.equal(d["packed"], K.conv2d_pack_weight(wt))
                     assert tuple(d["wt"].shape) == tuple(wt.shape)
                     checked["direct"] += 1; checked["dgrad"] += 1
+                    for tr, name in ((False, "c1"), (True, "c1t")):                 # (round 6) bf16 MFMA fragments of the 1x1 convs
+                        co_g, ci_g = (m.in_channels, m.out_channels) if tr else (m.out_channels, m.in_channels)
+                        if K.conv1x1_bf16_supported(ci_g, co_g, 4):
+                            gen, pk, src = AG._bf16_1x1_packs[key + (tr,)]
+                            assert src is m.weight and gen == K.weight_key(m.weight)
+                            assert torch.equal(pk, K.conv1x1_bf16_pack_weight(w, tr)); checked[name] += 1
                 else:
-                    if m.out_channels % 32 == 0:
-                        gen, pk, src = AG._bf16_packs[key + (False,)]
-                        assert src is m.weight
-                        assert gen == K.weight_key(m.weight) and torch.equal(pk, K.conv2d_bf16_pack_weight(w.contiguous()))
-                        checked["bf"] += 1
-                    else:
-                        assert torch.equal(m._pk, K.conv2d_pack_weight(w.contiguous())); checked["direct"] += 1
+                    gen, pk, src = AG._bf16_packs[key + (False,)]
+                    assert src is m.weight
+                    wp = w                                              # (round 6) Cout zero-padded to a multiple of 32: 28 -> 32
+                    if m.out_channels % 32:
+                        wp = torch.cat([w, w.new_zeros((AG.bf16_cout_pad(m.out_channels) - m.out_channels,) + tuple(w.shape[1:]))], 0)
+                    assert gen == K.weight_key(m.weight) and torch.equal(pk, K.conv2d_bf16_pack_weight(wp.contiguous()))
+                    checked["bf"] += 1
                     if m.in_channels % 32 == 0:
                         gen, pk, src = AG._bf16_packs[key + (True,)]
                         assert src is m.weight
                         wt = w.transpose(0, 1).flip(2, 3).contiguous()
                         assert gen == K.weight_key(m.weight) and torch.equal(pk, K.conv2d_bf16_pack_weight(wt))
                         checked["bft"] += 1
-        assert checked["sp"] >= 14 and checked["spt"] >= 13 and checked["bf"] == 7 and checked["bft"] == 8, checked
-        assert checked["direct"] >= 6 and checked["dgrad"] >= 5, checked
+        assert checked["sp"] >= 14 and checked["spt"] >= 13 and checked["bf"] == 8 and checked["bft"] == 8, checked
+        assert checked["direct"] >= 5 and checked["dgrad"] >= 5 and checked["c1"] >= 5 and checked["c1t"] >= 5, checked
     finally:
         AG.set_bev_precision("fp32")
 
@@ -503,8 +509,10 @@ def test_fused_head_data_gradient_follows_in_place_weight_edits(dev, precision):
         return x.grad.clone()
 
     def ref_of():
+        # (bf16, round 6: the 1x1 data gradient runs on the bf16 MFMA -- operands rounded; the upstream gradients 1, 2, 3 are exact)
+        rnd = (lambda t: t.bfloat16().float()) if precision == "bf16" else (lambda t: t)
         xr = x.detach().clone().requires_grad_(True)
-        ys = [torch.nn.functional.conv2d(xr, c.weight.detach(), c.bias.detach()) for c in
+        ys = [torch.nn.functional.conv2d(xr, rnd(c.weight.detach()), c.bias.detach()) for c in
               (head.conv_box, head.conv_cls, head.conv_dir_cls)]
         sum((y * (i + 1.0)).sum() for i, y in enumerate(ys)).backward()
         return xr.grad

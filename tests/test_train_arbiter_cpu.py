@@ -25,9 +25,15 @@ def test_rounding_rule_equals_the_products_dispatch():
     L = _C.lib()
     for cin, cout, ks, h, w in [(320, 256, 3, 200, 176), (256, 256, 3, 200, 176), (256, 256, 1, 200, 176), (256, 28, 3, 200, 176),
                                 (28, 28, 1, 200, 176), (256, 20, 1, 200, 176), (256, 256, 3, 188, 188), (64, 64, 3, 30, 14),
-                                (64, 64, 3, 30, 18), (40, 96, 3, 16, 20), (256, 72, 1, 200, 88)]:
-        rf, rd, rw = train_ref.bf16_conv_rule(cin, cout, ks, w)
-        assert rf == (ks == 3 and bool(L.sassd_conv2d_bf16_supported(cin, cout, h, w))), (cin, cout, ks, w)
+                                (64, 64, 3, 30, 18), (40, 96, 3, 16, 20), (256, 72, 1, 200, 88), (40, 256, 1, 8, 16),
+                                (20, 256, 1, 200, 176), (300, 64, 1, 8, 16), (64, 300, 1, 8, 16), (32, 32, 1, 3, 6)]:
+        rf, rd, rw = train_ref.bf16_conv_rule(cin, cout, ks, w, h)
+        if ks == 1:                                      # (round 6) the 1x1 layers: sassd_conv1x1_bf16_supported both ways
+            assert rf == bool(L.sassd_conv1x1_bf16_supported(cin, cout, h * w)), (cin, cout, ks, h, w)
+            assert rd == bool(L.sassd_conv1x1_bf16_supported(cout, cin, h * w)), (cin, cout, ks, h, w)
+            assert rw == (w % 2 == 0)
+            continue
+        assert rf == (ks == 3 and bool(L.sassd_conv2d_bf16_supported(cin, (cout + 31) // 32 * 32, h, w))), (cin, cout, ks, w)  # bf16_cout_pad
         assert rd == (ks == 3 and bool(L.sassd_conv2d_bf16_supported(cout, cin, h, w))), (cin, cout, ks, w)   # Conv2dFn.backward
         assert rw == (w % 2 == 0)                                                                               # kernels.conv2d_bwd_weight
 
@@ -40,7 +46,7 @@ def test_rounded_conv_products():
         w = torch.randn(cout, cin, ks, ks, generator=g, dtype=torch.float64, requires_grad=True)
         b = torch.randn(cout, generator=g, dtype=torch.float64, requires_grad=True)
         dy = torch.randn(2, cout, 6, w_, generator=g, dtype=torch.float64)
-        rf, rd, rw = train_ref.bf16_conv_rule(cin, cout, ks, w_)
+        rf, rd, rw = train_ref.bf16_conv_rule(cin, cout, ks, w_, 6)
         y = train_ref.conv2d(x, w, b, ks // 2, True)
         y.backward(dy)
         xd, wd = x.detach(), w.detach()

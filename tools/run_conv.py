@@ -13,14 +13,15 @@ from sassd import kernels as K  # noqa: E402
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 x = torch.randn(1, 256, 200, 176, generator=g).to(dev)
-w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev)
+CO = int(os.environ.get("CONV_COUT", "256"))          # 28 = the part-sensitive head's narrow 3x3 layer
+w = (torch.randn(CO, 256, 3, 3, generator=g) * 0.02).to(dev)
 wp = K.conv2d_pack_weight(w)
-sc = torch.ones(256, device=dev)
-sh = torch.zeros(256, device=dev)
-y = torch.empty_like(x)
+sc = torch.ones(CO, device=dev)
+sh = torch.zeros(CO, device=dev)
+y = torch.empty(1, CO, 200, 176, device=dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 for _ in range(n):
-    K.conv2d_fwd(x, wp, 256, 3, sc, sh, True, y)
+    K.conv2d_fwd(x, wp, CO, 3, sc, sh, True, y)
 torch.cuda.synchronize()
 import ctypes
 from sassd import _C
@@ -31,9 +32,9 @@ for flags in flags_list:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        K.conv2d_fwd(x, wp, 256, 3, sc, sh, True, y)
+        K.conv2d_fwd(x, wp, CO, 3, sc, sh, True, y)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    print("flags=%d conv 256->256 3x3 @200x176: %.4f ms  %.1f TFLOP/s" % (flags, ms, 2 * 256 * 256 * 9 * 200 * 176 / ms / 1e9))
+    print("flags=%d conv 256->%d 3x3 @200x176: %.4f ms  %.1f TFLOP/s" % (flags, CO, ms, 2 * CO * 256 * 9 * 200 * 176 / ms / 1e9))
 setdbg(0)

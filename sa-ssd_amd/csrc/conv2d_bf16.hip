@@ -508,10 +508,12 @@ static int conv2d_bf16_launch(const float *x, const float *in_aff, const void *w
     p.x = x; p.wp = (const unsigned short *)w_packed; p.shift = shift; p.y = y; p.in_aff = in_aff;
     p.B = batch; p.Cin = Cin; p.CinP = (int)align_up(Cin, 32); p.Cout = Cout; p.H = H; p.W = W;
     p.tiles_x = cdiv(W, kTC); p.hb = cdiv(H, 2);
-    // 256-cout workgroups (8 MMA waves) when they divide Cout, else 128-cout ones whose last tile may be partly idle
-    // (Cout = 320: 3 tiles, 2.5 used)
+    // 256-cout workgroups (8 MMA waves) when they divide Cout; 160-cout ones (5 MMA waves) when THEY do -- Cout = 320, the data
+    // gradient of BEVNet's conv0 (256 -> 320): two full tiles instead of three 128-cout tiles of which 2.5 work (round 6: 172 ->
+    // 1xx us at batch 2); else 128-cout ones whose last tile may be partly idle
     const bool wide = Cout % 256 == 0;
-    const long strips = (long)(wide ? Cout / 256 : cdiv(Cout, 128)) * batch * p.tiles_x;
+    const bool five = !wide && Cout % 160 == 0 && !in_aff && !(g_bf16_dbg & 0x80000);      // (0x80000: the 128-cout form, A/B)
+    const long strips = (long)(wide ? Cout / 256 : five ? Cout / 160 : cdiv(Cout, 128)) * batch * p.tiles_x;
     const long G = strips * p.hb;
     if (strips > 0x7fffffffL / p.hb) return SASSD_EINVAL;
     p.strips = (int)strips;
@@ -528,6 +530,7 @@ static int conv2d_bf16_launch(const float *x, const float *in_aff, const void *w
     if ((g_bf16_dbg >> 8) & 0xff) nwg = (long)align_up((size_t)std::max((long)((g_bf16_dbg >> 8) & 0xff), (G + 39) / 40), 8);
     hipStream_t s = (hipStream_t)stream_;
     if (in_aff) return wide ? launch_bf16<8, 0, 1>(p, (int)nwg, s) : launch_bf16<4, 0, 1>(p, (int)nwg, s);
+    if (five) return launch_bf16<5, 0>(p, (int)nwg, s);
     if (!wide) return launch_bf16<4, 0>(p, (int)nwg, s);
     switch (g_bf16_dbg & 0xff) {        // compile-time ablation variants (a run-time switch inside the kernel de-tunes it)
 #define SASSD_BF16_VARIANT(D) case D: return launch_bf16<8, D>(p, (int)nwg, s);

@@ -303,7 +303,7 @@ def _train_measure(args, dev, rank, world, config, precision, steps, warmup, bat
                 traffic_measured_at=at,
                 note="flops executed by one 256->256 3x3 BEV layer at batch %d (%dx%d map) / mean layer time (HIP events, 20 "
                      "launches on the launch stream); 14 such layers per step (forward + data gradient)" % (B, H, W))
-    bev = ("bf16 MFMA operands in the BEV convs (fwd/dgrad/wgrad; fp32 accumulation, master weights and activations), "
+    bev = ("bf16 MFMA operands in the dense convs (BEV 3x3 + 1x1 and the head convs: fwd/dgrad/wgrad; fp32 accumulation, master weights and activations), "
            "fp32 sparse trunk" if bf16_conv else
            "bf16 weight gradients, fp32 Winograd forward / data gradient (the bf16 direct conv needs W %% 16 == 0, the "
            "BEV map is %dx%d), fp32 sparse trunk" % (H, W) if precision == "bf16" else "fp32")

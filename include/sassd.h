@@ -292,7 +292,8 @@ int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *s
 int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W);
 void sassd_debug_set_bf16(int flags);   /* 0 = off.  Low byte: compile-time ablation variant of the bf16 conv; bits 8-15:
                                            forced workgroup count (tests: long runs of tiles); 0x10000 / 0x20000 / 0x40000:
-                                           wave-priority and loader-order A/B switches (tools/run_bf16_conv.py) */
+                                           wave-priority and loader-order A/B switches (tools/run_bf16_conv.py); 0x80000:
+                                           Cout = 320 on 128-cout instead of 160-cout workgroups (A/B) */
 size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout);
 int sassd_conv2d_bf16_pack_weight(const float *w, int Cout, int Cin, void *packed, void *stream);
 int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const float *shift, float *y, int batch, int Cin,

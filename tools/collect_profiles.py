@@ -53,7 +53,8 @@ for name in ("bench_default", "bench_train_bf16", "bench_train_fp32", "bench_tra
     if d:
         json.dump(d, open(os.path.join(DST, "%s_%s.json" % (tag, name)), "w"), indent=1)
 for name in ("spconv_layers_car", "spconv_layers_multi", "spconv_layers_waymo", "mfma4x4_probe", "wino4_geometries",
-             "sparse_timeline_car_graph", "sparse_timeline_car_eager", "sparse_timeline_multi_graph", "full_tests_tail"):
+             "sparse_timeline_car_graph", "sparse_timeline_car_eager", "sparse_timeline_multi_graph", "full_tests_tail",
+             "conv1x1_bf16_timing"):
     src = os.path.join(SRC, name + ".txt")
     if os.path.exists(src) and os.path.getsize(src) > 10:
         shutil.copy(src, os.path.join(DST, "%s_%s.txt" % (tag, name)))

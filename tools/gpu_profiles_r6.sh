@@ -52,6 +52,7 @@ timeout 600 python bench.py --mode train --config waymo --steps 12 --warmup 4 > 
 timeout 300 python bench.py --config multi --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_multi.log 2>&1; echo "multi rc=$?"
 timeout 300 python bench.py --config waymo --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_waymo.log 2>&1; echo "waymo rc=$?"
 timeout 300 python tools/run_bf16_conv.py --ablate > $O/bf16_conv_timing.json 2>/dev/null; echo "bf16 timing rc=$?"
+timeout 200 python tools/run_conv1x1_bf16.py 30 2>/dev/null | grep "^1x1" > $O/conv1x1_bf16_timing.txt; echo "bf16 1x1 timing rc=$?"
 timeout 400 python tools/ablate_spconv.py --config car --ablate 2>&1 | grep -v "^/opt" > $O/spconv_layers_car.txt; echo "layers car rc=$?"
 python tools/collect_profiles.py r06 >> $O/collect.log 2>&1; echo "collect rc=$?"
 grep -o '"traffic_measured_at": [^,]*' $O/bench_default.log | head -3; grep -o '"value": [0-9.]*' $O/bench_default.log $O/bench_train_bf16.log $O/bench_multi.log $O/bench_waymo.log $O/bench_train_waymo.log $O/bench_train_fp32.log

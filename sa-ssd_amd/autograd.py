@@ -563,11 +563,6 @@ class AuxHeadFn(Function):
     non-differentiable context (3-NN indices / squared distances per scale, labels, targets, positive count).
     -> loss sums [2] = (focal, smooth-L1), both already divided by max(#positive points, 1)."""
 
-    # set by the caller around apply() when the head runs on a side stream (SpMiddleFHD.aux_side_stream): the stream on which the
-    # consumers of its gradients run.  The gradients are allocated on the side stream (autograd runs this backward there); the
-    # caching allocator must not hand their blocks to a later side-stream allocation while the consumer still reads them.
-    consumer_stream = None
-
     @staticmethod
     def forward(ctx, f0, f1, f2, w_fc, w_cls, w_reg, nn_idx, nn_d2, label, target, npos):
         feats = [f0.contiguous(), f1.contiguous(), f2.contiguous()]
@@ -576,16 +571,12 @@ class AuxHeadFn(Function):
         sums, wgt, h, out, gout = K.aux_head_fwd(feats, nn_idx, nn_d2, w1, w2, label, target, npos)
         ctx.save_for_backward(feats[0], feats[1], feats[2], w1, w2, wgt, h, gout)
         ctx.nn_idx = nn_idx
-        ctx.consumer_stream = AuxHeadFn.consumer_stream
         return sums
 
     @staticmethod
     def backward(ctx, g):
         f0, f1, f2, w1, w2, wgt, h, gout = ctx.saved_tensors
         gf, dw1, dw2 = K.aux_head_bwd([f0, f1, f2], ctx.nn_idx, w1, w2, wgt, h, gout, g.contiguous())
-        if ctx.consumer_stream is not None:
-            for t in (gf[0], gf[1], gf[2], dw1, dw2):
-                t.record_stream(ctx.consumer_stream)
         return gf[0], gf[1], gf[2], dw1, dw2[0:1], dw2[1:4], None, None, None, None, None
 
 

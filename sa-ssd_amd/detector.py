@@ -17,8 +17,6 @@ kernels), torch BatchNorm / ReLU / Linear in between, losses and target assignme
 import sys
 
 import numpy as np
-import os
-
 import torch
 from torch import nn
 
@@ -359,21 +357,6 @@ class SpMiddleFHD(nn.Module):
     # The auxiliary head in training as three fused launches + the three 3-NN searches (sassd_aux_*), instead of ~150
     # small torch / library launches; False keeps the module-by-module formulation (A/B, parity tests).
     fused_aux = True
-    # (round 6) the fused auxiliary head -- aux_prepare, three exact 3-NN searches (3 x 83 us), the fused forward -- depends on the
-    # sparse trunk only: it is issued on a SIDE stream right behind the trunk, beside the BEV stack's MFMA-bound convolutions (its
-    # kernels are latency-bound: 500 workgroups of pointer chasing), and autograd runs its backward on the same stream, beside the
-    # BEV stack's backward.  forward() needs the ground-truth boxes for that (`aux_gt`); False / no boxes: after the BEV stack on
-    # the main stream as before (A/B).
-    aux_side_stream = os.environ.get("SASSD_AUX_SIDE_STREAM", "1") != "0"
-
-    def _aux_stream(self, dev):
-        st = getattr(self, "_aux_side", None)
-        if st is None or st.device != dev:
-            # high priority = another hardware-queue pool than the default-priority streams (main, SideStreamPrefetch): sharing a
-            # hardware queue with the prefetch stream puts its host-synchronised kernels behind the auxiliary head's (measured: two
-            # processes in nine ran 7.57 instead of 7.12 ms per step with a default-priority stream)
-            st = self._aux_side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SASSD_AUX_PRIO", "-1")))
-        return st
 
     def _aux_loss_fused(self, ctx, gt_bboxes):
         """aux_loss on the fused kernels: `ctx` = (voxel_features, coors, middle tensors, batch size) left by forward."""
@@ -399,8 +382,6 @@ class SpMiddleFHD(nn.Module):
 
     def aux_loss(self, points, point_cls, point_reg, gt_bboxes):
         """cmn.py:74-104."""
-        if isinstance(points, dict):                             # forward() already ran the fused head on the side stream
-            return points
         if point_cls is None and isinstance(points, tuple):      # forward() left the fused context
             return self._aux_loss_fused(points, gt_bboxes)
         n = len(gt_bboxes)
@@ -422,37 +403,20 @@ class SpMiddleFHD(nn.Module):
         out[:, 1:] = ind[:, 1:].flip(1) * vs + off + .5 * vs          # columns (3,2,1) without an index tensor upload
         return tensor.features, out
 
-    def forward(self, voxel_features, coors, batch_size, is_test=False, indice_dict=None, aux_gt=None):
+    def forward(self, voxel_features, coors, batch_size, is_test=False, indice_dict=None):
         x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size)
         if indice_dict is not None:                  # rulebooks built ahead of time (VxNet.precompute_rulebooks)
             x.indice_dict = indice_dict
         x, middle = self.backbone(x)
-        # auxiliary network (cmn.py:121-135): multi-scale voxel features interpolated back to the voxel means
-        fused = (not is_test and self.fused_aux and voxel_features.is_cuda and torch.is_grad_enabled()
-                 and voxel_features.shape[0] > 0 and all(m.features.shape[0] > 0 for m in middle)
-                 and [m.features.shape[1] for m in middle] == [32, 64, 64])
-        aux_terms = side = None
-        if fused and self.aux_side_stream and aux_gt is not None:
-            main = torch.cuda.current_stream(voxel_features.device)
-            side = self._aux_stream(voxel_features.device)
-            side.wait_stream(main)                   # the trunk's features
-            AuxHeadFn.consumer_stream = main         # (its feature gradients are read by the trunk's backward on this stream)
-            try:
-                with torch.cuda.stream(side):
-                    aux_terms = self._aux_loss_fused((voxel_features, coors, middle, batch_size), aux_gt)
-            finally:
-                AuxHeadFn.consumer_stream = None
         x = x.dense()
         n, c, d, h, w = x.shape
         x, conv6 = self.fcn(x.view(n, c * d, h, w))
         if is_test:
             return x, conv6
-        if aux_terms is not None:
-            main.wait_stream(side)                   # join: the two loss terms are summed on the main stream
-            for t in aux_terms.values():
-                t.record_stream(main)
-            return x, conv6, (aux_terms, None, None)
-        if fused:
+        # auxiliary network (cmn.py:121-135): multi-scale voxel features interpolated back to the voxel means
+        if (self.fused_aux and voxel_features.is_cuda and torch.is_grad_enabled() and voxel_features.shape[0] > 0
+                and all(m.features.shape[0] > 0 for m in middle)
+                and [m.features.shape[1] for m in middle] == [32, 64, 64]):
             return x, conv6, ((voxel_features, coors, middle, batch_size), None, None)
         points_mean = torch.zeros_like(voxel_features)
         points_mean[:, 0] = coors[:, 0]
@@ -953,7 +917,7 @@ class SingleStageDetector(nn.Module):
         ret = self.merge_second_batch(kwargs)
         vx = self.backbone(ret['voxels'], ret['num_points'])
         x, conv6, point_misc = self.neck(vx, ret['coordinates'], batch_size, is_test=False,
-                                         indice_dict=ret.get('sassd_rulebooks'), aux_gt=ret['gt_bboxes'])
+                                         indice_dict=ret.get('sassd_rulebooks'))
         losses = dict()
         losses.update(self.neck.aux_loss(*point_misc, gt_bboxes=ret['gt_bboxes']))
         if not self.with_rpn:

@@ -36,6 +36,14 @@ def test_argument_validation_returns_error_codes():
     assert L.sassd_conv2d_bf16_fwd(null, null, null, null, 1, 32, 128, 8, 16, null) == EINVAL
     assert L.sassd_conv2d_bf16_fwd(p16, p16, null, p16, 1, 32, 100, 8, 16, null) == EINVAL        # Cout % 32
     assert L.sassd_conv2d_bf16_fwd(p16, p16, null, p16, 1, 32, 128, 8, 18, null) == EINVAL        # W % 4
+    # round-6: 1x1 convolution on the bf16 MFMA
+    assert L.sassd_conv1x1_bf16_fwd(null, null, null, null, 1, 256, 256, 64, null) == EINVAL
+    assert L.sassd_conv1x1_bf16_fwd(p16, p16, null, p16, 1, 300, 256, 64, null) == EINVAL         # Cin > 256
+    assert L.sassd_conv1x1_bf16_fwd(p16, p16, null, p16, 1, 256, 256, 66, null) == EINVAL         # HW % 4
+    assert L.sassd_conv1x1_bf16_fwd(p16, p16, null, p16, 1, 40, 256, 64, null) == EINVAL          # two ragged k-steps
+    assert L.sassd_conv1x1_bf16_fwd(C.c_void_p(20), p16, null, p16, 1, 256, 256, 64, null) == EINVAL     # x not 8-byte aligned
+    assert L.sassd_conv1x1_bf16_pack_weight(null, 256, 256, 0, p16, null) == EINVAL
+    assert L.sassd_conv1x1_bf16_pack_weight(p16, 256, 300, 0, p16, null) == EINVAL
     assert L.sassd_conv2d_bwd_weight_bf16(p16, p16, p16, 1, 16, 16, 8, 9, 3, 0, p16, 1 << 30, null) == EINVAL   # odd W
     assert L.sassd_conv2d_bwd_weight_bf16(p16, p16, p16, 1, 16, 16, 8, 8, 3, 0, p16, 4, null) == ENOSPC
     assert L.sassd_assign_targets(null, 0, null, 100, 2, null, null, null, null, 0, null, null, 0.6, 0.45, null, null,
@@ -75,6 +83,12 @@ def test_host_side_queries():
     assert L.sassd_conv2d_bf16_supported(256, 28, 200, 176) == 0 and L.sassd_conv2d_bf16_supported(256, 256, 200, 182) == 0
     assert L.sassd_conv2d_bf16_supported(256, 256, 188, 188) == 1      # partial last tile column (W % 4 == 0)
     assert L.sassd_conv2d_bf16_packed_elems(28, 256) == 9 * 32 * 256          # Cin padded to 32 inside the pack
+    assert L.sassd_conv1x1_bf16_supported(256, 256, 35200) == 1 and L.sassd_conv1x1_bf16_supported(20, 256, 35200) == 1
+    assert L.sassd_conv1x1_bf16_supported(256, 20, 35200) == 1 and L.sassd_conv1x1_bf16_supported(28, 28, 35344) == 1
+    assert L.sassd_conv1x1_bf16_supported(257, 256, 64) == 0 and L.sassd_conv1x1_bf16_supported(40, 256, 64) == 0
+    assert L.sassd_conv1x1_bf16_supported(256, 256, 35201) == 0
+    assert L.sassd_conv1x1_bf16_packed_elems(256, 256) == 256 * 256 and L.sassd_conv1x1_bf16_packed_elems(20, 256) == 256 * 32
+    assert L.sassd_conv1x1_bf16_packed_elems(256, 20) == 64 * 256 and L.sassd_conv1x1_bf16_packed_elems(40, 256) == 0
     assert L.sassd_assign_targets_workspace_bytes(2, 70400, 16) >= 2 * 70400 * 8 + 16 * 4
     assert L.sassd_rpn_loss_workspace_bytes(2, 70400) == 2 * 275 * 3 * 4
     assert L.sassd_guided_select_workspace_bytes(2, 70400) == 2 * 275 * 4

@@ -43,7 +43,8 @@ int sassd_last_hip_error(void);
 const char *sassd_last_hip_error_string(void);
 
 /* Kernel selection is PER CALL (round 6; rounds 1-5 had process-wide sassd_debug_set_* switches, which a hipGraph capture
- * could bake in by accident): the sparse-conv and Winograd entry points take an `int cfg`, 0 in production.
+ * could bake in by accident -- none is left): the sparse-conv and Winograd entry points take an `int cfg`, 0 in production; the
+ * direct and the bf16 convolution have `_cfg` twins of their entry points for their ablation switches.
  *   sparse conv (sassd_spconv_fwd / _bwd_data / _bwd_weight)   low 16 bits = ablation flags (tools/ablate_spconv.py): bit2 no
  *     MFMA, bit5 every gather reads row 0 (weight gradient: the tile-per-wave formulation), bit6 one weight image for every
  *     offset (bits 5 / 6 keep the number of loads in flight unchanged), bit8 the register-stationary kernel everywhere.
@@ -197,6 +198,10 @@ int sassd_conv2d_pack_weight(const float *w, int Cout, int Cin, int ksize, float
 int sassd_conv2d_fwd(const float *x, const float *w_packed, const float *scale, const float *shift,
                      int relu, float *y, int batch, int Cin, int Cout, int H, int W, int ksize,
                      void *stream);
+/* ... with a per-call `cfg` word (0 = sassd_conv2d_fwd): ablation switches of tools/run_conv.py -- 1 = no staging DMA after the
+ * first chunk, 2 = no chunk barrier. */
+int sassd_conv2d_fwd_cfg(const float *x, const float *w_packed, const float *scale, const float *shift, int relu, float *y,
+                         int batch, int Cin, int Cout, int H, int W, int ksize, int cfg, void *stream);
 
 /* 1x1 convolution with <= 32 output channels (the fused SSD head, ssd_rotate_head.py:120-125; the second conv of the
  * part-sensitive head, :424-429) as an HBM stream on the vector ALU: same contract as sassd_conv2d_fwd with ksize 1, but
@@ -290,14 +295,15 @@ int sassd_conv1x1_gemm_fwd(const float *x, const float *w_packed, const float *s
  * transposed and the taps mirrored.  Supported: Cout % 32 == 0, W >= 16 and W % 4 == 0 (the last 16-column tile may be partial: the 188-wide Waymo-scale map; else SASSD_EINVAL; the caller keeps the
  * fp32 kernels); Cin is padded to a multiple of 32 with zero weights inside the pack. */
 int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W);
-void sassd_debug_set_bf16(int flags);   /* 0 = off.  Low byte: compile-time ablation variant of the bf16 conv; bits 8-15:
-                                           forced workgroup count (tests: long runs of tiles); 0x10000 / 0x20000 / 0x40000:
-                                           wave-priority and loader-order A/B switches (tools/run_bf16_conv.py); 0x80000:
-                                           Cout = 320 on 128-cout instead of 160-cout workgroups (A/B) */
 size_t sassd_conv2d_bf16_packed_elems(int Cin, int Cout);
 int sassd_conv2d_bf16_pack_weight(const float *w, int Cout, int Cin, void *packed, void *stream);
 int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const float *shift, float *y, int batch, int Cin,
                           int Cout, int H, int W, void *stream);
+/* ... with a per-call `cfg` word (0 = sassd_conv2d_bf16_fwd; tools / tests only): low byte = compile-time ablation variant of the
+ * kernel (tools/run_bf16_conv.py), bits 8-15 = forced workgroup count (long runs of tiles), 0x10000 / 0x20000 / 0x40000 =
+ * wave-priority and loader-order A/B switches, 0x80000 = Cout = 320 on 128-cout instead of 160-cout workgroups. */
+int sassd_conv2d_bf16_fwd_cfg(const float *x, const void *w_packed, const float *shift, float *y, int batch, int Cin,
+                              int Cout, int H, int W, int cfg, void *stream);
 /* The same convolution over relu(batchnorm(x)), the normalisation applied by the kernel's loader waves (round 6): x is the RAW
  * output of the previous convolution, in_affine [3][Cin] = mean | invstd * gamma | beta as sassd_bn2d_stats writes it.  The
  * operand that reaches the MFMA is bit-identical to the one sassd_bn2d_relu_fwd + sassd_conv2d_bf16_fwd produce, and the

@@ -64,6 +64,7 @@ _SIGS = {
     "sassd_conv2d_packed_floats": (_SZ, [_I, _I, _I]),
     "sassd_conv2d_pack_weight": (_I, [_P, _I, _I, _I, _P, _P]),
     "sassd_conv2d_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sassd_conv2d_fwd_cfg": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sassd_anchor_mask_workspace_bytes": (_SZ, [_I, _I]),
     "sassd_anchor_mask": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _F, _P, _P, _SZ, _P]),
     "sassd_anchor_mask_batch": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _F, _P, _P, _SZ, _P]),
@@ -100,10 +101,10 @@ _SIGS = {
     "sassd_conv1x1_narrow_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv1x1_gemm_fwd": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_bf16_supported": (_I, [_I, _I, _I, _I]),
-    "sassd_debug_set_bf16": (None, [_I]),
     "sassd_conv2d_bf16_packed_elems": (_SZ, [_I, _I]),
     "sassd_conv2d_bf16_pack_weight": (_I, [_P, _I, _I, _P, _P]),
     "sassd_conv2d_bf16_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sassd_conv2d_bf16_fwd_cfg": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sassd_conv2d_bf16_bnrelu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sassd_conv1x1_bf16_supported": (_I, [_I, _I, _I]),
     "sassd_conv1x1_bf16_packed_elems": (_SZ, [_I, _I]),

@@ -415,14 +415,10 @@ int launch_conv(ConvParams P, hipStream_t stream)
     return sassd_launch_status();
 }
 
-int g_conv_dbg = 0;
-
 inline int cout_pad(int Cout) { return (Cout > 64) ? cdiv(Cout, 128) * 128 : cdiv(Cout, 32) * 32; }
 inline int kc_of(int ksize) { return ksize == 3 ? 8 : 16; }
 
 }  // namespace
-
-extern "C" void sassd_debug_set_conv(int flags) { g_conv_dbg = flags; }
 
 extern "C" size_t sassd_conv2d_packed_floats(int Cin, int Cout, int ksize)
 {
@@ -440,9 +436,11 @@ extern "C" int sassd_conv2d_pack_weight(const float *w, int Cout, int Cin, int k
     return sassd_launch_status();
 }
 
-extern "C" int sassd_conv2d_fwd(const float *x, const float *w_packed, const float *scale, const float *shift,
-                                int relu, float *y, int batch, int Cin, int Cout, int H, int W, int ksize,
-                                void *stream_)
+// `cfg` (0 in production; per call since round 6, like the sparse-conv and Winograd entry points): ablation switches of
+// tools/run_conv.py -- 1 = no staging DMA after the first chunk, 2 = no chunk barrier
+extern "C" int sassd_conv2d_fwd_cfg(const float *x, const float *w_packed, const float *scale, const float *shift,
+                                    int relu, float *y, int batch, int Cin, int Cout, int H, int W, int ksize, int cfg,
+                                    void *stream_)
 {
     if (!x || !w_packed || !y || batch < 1 || Cin < 1 || (ksize != 1 && ksize != 3)) return SASSD_EINVAL;
     if (H < 1 || W < 2) return SASSD_EINVAL;
@@ -450,7 +448,7 @@ extern "C" int sassd_conv2d_fwd(const float *x, const float *w_packed, const flo
     P.x = x; P.wp = w_packed; P.scale = scale; P.shift = shift; P.y = y;
     P.B = batch; P.Cin = Cin; P.Cout = Cout; P.CoutPad = cout_pad(Cout); P.H = H; P.W = W; P.HW = H * W;
     P.relu = relu;
-    P.dbg = g_conv_dbg;
+    P.dbg = cfg;
     hipStream_t stream = (hipStream_t)stream_;
     const bool wide = P.CoutPad % 128 == 0;
     // 16-byte row loads need W % 4 == 0 and a 16-byte aligned base
@@ -463,6 +461,13 @@ extern "C" int sassd_conv2d_fwd(const float *x, const float *w_packed, const flo
         if (ksize == 3) { SASSD_CONV_GO(1, 9); } else { SASSD_CONV_GO(1, 1); }
     }
 #undef SASSD_CONV_GO
+}
+
+extern "C" int sassd_conv2d_fwd(const float *x, const float *w_packed, const float *scale, const float *shift,
+                                int relu, float *y, int batch, int Cin, int Cout, int H, int W, int ksize,
+                                void *stream_)
+{
+    return sassd_conv2d_fwd_cfg(x, w_packed, scale, shift, relu, y, batch, Cin, Cout, H, W, ksize, 0, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -26,7 +26,6 @@
 #include "common.h"
 
 namespace {
-int g_bf16_dbg = 0;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -463,7 +462,6 @@ __global__ void __launch_bounds__(64 * (COW + NLW), 3) conv2d_bf16_kernel(BfPara
 // traffic) take the MMA loop apart: 32 no B-fragment reads, 64 no chunk barriers, 128 no weight loads.  0x10000 in the
 // upper half: MMA waves at default priority; 0x20000: the loader waves at priority 2 instead; 0x40000: the round-2
 // loader item order (4-way conflicted LDS stores).
-extern "C" void sassd_debug_set_bf16(int flags) { g_bf16_dbg = flags; }
 
 extern "C" int sassd_conv2d_bf16_supported(int Cin, int Cout, int H, int W)
 {
@@ -499,7 +497,7 @@ int launch_bf16(const BfParams &p, int nwg, hipStream_t s)
 }  // namespace
 
 static int conv2d_bf16_launch(const float *x, const float *in_aff, const void *w_packed, const float *shift, float *y,
-                              int batch, int Cin, int Cout, int H, int W, void *stream_)
+                              int batch, int Cin, int Cout, int H, int W, int cfg, void *stream_)
 {
     if (!x || !w_packed || !y || batch < 1) return SASSD_EINVAL;
     if (!sassd_conv2d_bf16_supported(Cin, Cout, H, W)) return SASSD_EINVAL;
@@ -512,7 +510,7 @@ static int conv2d_bf16_launch(const float *x, const float *in_aff, const void *w
     // gradient of BEVNet's conv0 (256 -> 320): two full tiles instead of three 128-cout tiles of which 2.5 work (round 6: 172 ->
     // 1xx us at batch 2); else 128-cout ones whose last tile may be partly idle
     const bool wide = Cout % 256 == 0;
-    const bool five = !wide && Cout % 160 == 0 && !in_aff && !(g_bf16_dbg & 0x80000);      // (0x80000: the 128-cout form, A/B)
+    const bool five = !wide && Cout % 160 == 0 && !in_aff && !(cfg & 0x80000);      // (0x80000: the 128-cout form, A/B)
     const long strips = (long)(wide ? Cout / 256 : five ? Cout / 160 : cdiv(Cout, 128)) * batch * p.tiles_x;
     const long G = strips * p.hb;
     if (strips > 0x7fffffffL / p.hb) return SASSD_EINVAL;
@@ -525,14 +523,14 @@ static int conv2d_bf16_launch(const float *x, const float *in_aff, const void *w
     cus = (int)align_up((size_t)cus, 8);
     long nwg = (long)cus * ((G + (long)cus * 40 - 1) / ((long)cus * 40));
     if (G < 4 * nwg) nwg = (long)align_up((size_t)((G + 3) / 4), 8);
-    p.wr_map = (g_bf16_dbg & 0x40000) ? 0 : 1;
-    p.mma_prio = (g_bf16_dbg & 0x10000) ? 0 : (g_bf16_dbg & 0x20000) ? 2 : 1;
-    if ((g_bf16_dbg >> 8) & 0xff) nwg = (long)align_up((size_t)std::max((long)((g_bf16_dbg >> 8) & 0xff), (G + 39) / 40), 8);
+    p.wr_map = (cfg & 0x40000) ? 0 : 1;
+    p.mma_prio = (cfg & 0x10000) ? 0 : (cfg & 0x20000) ? 2 : 1;
+    if ((cfg >> 8) & 0xff) nwg = (long)align_up((size_t)std::max((long)((cfg >> 8) & 0xff), (G + 39) / 40), 8);
     hipStream_t s = (hipStream_t)stream_;
     if (in_aff) return wide ? launch_bf16<8, 0, 1>(p, (int)nwg, s) : launch_bf16<4, 0, 1>(p, (int)nwg, s);
     if (five) return launch_bf16<5, 0>(p, (int)nwg, s);
     if (!wide) return launch_bf16<4, 0>(p, (int)nwg, s);
-    switch (g_bf16_dbg & 0xff) {        // compile-time ablation variants (a run-time switch inside the kernel de-tunes it)
+    switch (cfg & 0xff) {        // compile-time ablation variants (a run-time switch inside the kernel de-tunes it)
 #define SASSD_BF16_VARIANT(D) case D: return launch_bf16<8, D>(p, (int)nwg, s);
         SASSD_BF16_VARIANT(1) SASSD_BF16_VARIANT(2) SASSD_BF16_VARIANT(3) SASSD_BF16_VARIANT(4)
         SASSD_BF16_VARIANT(8) SASSD_BF16_VARIANT(11) SASSD_BF16_VARIANT(15) SASSD_BF16_VARIANT(16)
@@ -546,7 +544,16 @@ static int conv2d_bf16_launch(const float *x, const float *in_aff, const void *w
 extern "C" int sassd_conv2d_bf16_fwd(const float *x, const void *w_packed, const float *shift, float *y, int batch,
                                      int Cin, int Cout, int H, int W, void *stream_)
 {
-    return conv2d_bf16_launch(x, nullptr, w_packed, shift, y, batch, Cin, Cout, H, W, stream_);
+    return conv2d_bf16_launch(x, nullptr, w_packed, shift, y, batch, Cin, Cout, H, W, 0, stream_);
+}
+
+// `cfg` (per call since round 6; 0 in production): low byte = compile-time ablation variant (tools/run_bf16_conv.py), bits 8-15 =
+// forced workgroup count (tests: long runs of tiles), 0x10000 / 0x20000 / 0x40000 = wave-priority and loader-order A/B switches,
+// 0x80000 = Cout = 320 on 128-cout instead of 160-cout workgroups
+extern "C" int sassd_conv2d_bf16_fwd_cfg(const float *x, const void *w_packed, const float *shift, float *y, int batch,
+                                         int Cin, int Cout, int H, int W, int cfg, void *stream_)
+{
+    return conv2d_bf16_launch(x, nullptr, w_packed, shift, y, batch, Cin, Cout, H, W, cfg, stream_);
 }
 
 // The same convolution over relu(batchnorm(x)) with the normalisation applied by the loader waves: in_affine = [3][Cin]
@@ -555,5 +562,5 @@ extern "C" int sassd_conv2d_bf16_bnrelu_fwd(const float *x, const float *in_affi
                                             float *y, int batch, int Cin, int Cout, int H, int W, void *stream_)
 {
     if (!in_affine) return SASSD_EINVAL;
-    return conv2d_bf16_launch(x, in_affine, w_packed, shift, y, batch, Cin, Cout, H, W, stream_);
+    return conv2d_bf16_launch(x, in_affine, w_packed, shift, y, batch, Cin, Cout, H, W, 0, stream_);
 }

@@ -285,10 +285,7 @@ __global__ void __launch_bounds__(768) conv2d_wino_kernel(WinoParams P)
         }
     }
 }
-int g_wino_dbg = 0;
 }  // namespace
-
-extern "C" void sassd_debug_set_wino(int flags) { g_wino_dbg = flags; }
 
 
 extern "C" int sassd_conv2d_wino_supported(int Cin, int Cout, int H, int W)
@@ -327,7 +324,7 @@ extern "C" int sassd_conv2d_wino_fwd(const float *x, const float *w_packed, cons
     P.TH = H / 2; P.TW = W / 2; P.tiles = batch * P.TH * P.TW;
     P.ncb64 = cdiv(Cout, kCoW);
     P.relu = relu;
-    P.dbg = g_wino_dbg;
+    P.dbg = 0;
     const size_t lds = (size_t)(2 * kRawBuf) * sizeof(float);                       // 147 456 B
     {
         static std::atomic<unsigned long long> attr_done{0};

@@ -20,7 +20,7 @@
 // GEMM kernel, round 4: the fp32 products run on the bf16 MFMA (16 x the fp32 MFMA's rate) over operands split exactly into
 // three bf16 pieces in registers -- half the MFMA cycles per fp32 product, the error of the fp32 instruction (2.1e-5 against
 // fp64 on a KITTI layer for both), operands still fp32 in HBM and LDS: see "fp32 products on the bf16 MFMA" below.  Workgroup
-// = 128 output channels x 128 tiles, four waves of 64 x 64.  The fp32-MFMA form (geometry 1..6 of sassd_debug_set_wino4,
+// = 128 output channels x 128 tiles, four waves of 64 x 64.  The fp32-MFMA form (geometry 1..6 of the cfg word,
 // the default of rounds 2-3): workgroup = 128 output channels x 32 WN tiles of one Winograd position, 2 x WN waves, each a 64 x 32
 // block = two v_mfma_f32_32x32x2_f32 accumulators sharing one B fragment.  A ([k][128 co]) and B ([k][32 WN t]) chunks
 // of 32 input channels are staged by global->LDS DMA in their natural row-major form (both operands are K-major with

@@ -370,13 +370,18 @@ def conv2d_pack_weight(w):
     return packed
 
 
-def conv2d_fwd(x, w_packed, cout, ksize, scale=None, shift=None, relu=False, y=None):
+def conv2d_fwd(x, w_packed, cout, ksize, scale=None, shift=None, relu=False, y=None, cfg=0):
+    """cfg: per-call ablation word of the direct kernel (tools/run_conv.py), 0 in production."""
     _chk_cuda(x, w_packed, scale, shift)
     b, cin, h, w = x.shape
     if y is None:
         y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
-    rc = _C.lib().sassd_conv2d_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
-                                   _C.ptr(y), b, cin, cout, h, w, ksize, _C.stream())
+    if cfg:
+        rc = _C.lib().sassd_conv2d_fwd_cfg(_C.ptr(x), _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
+                                           _C.ptr(y), b, cin, cout, h, w, ksize, int(cfg), _C.stream())
+    else:
+        rc = _C.lib().sassd_conv2d_fwd(_C.ptr(x), _C.ptr(w_packed), _C.ptr(scale), _C.ptr(shift), 1 if relu else 0,
+                                       _C.ptr(y), b, cin, cout, h, w, ksize, _C.stream())
     _C.check(rc, "sassd_conv2d_fwd")
     return y
 
@@ -582,13 +587,19 @@ def conv2d_bf16_pack_weight(w):
     return packed
 
 
-def conv2d_bf16_fwd(x, w_packed, cout, shift=None, y=None, in_affine=None):
+def conv2d_bf16_fwd(x, w_packed, cout, shift=None, y=None, in_affine=None, cfg=0):
     """3x3 pad-1 conv, bf16 MFMA operands / fp32 accumulation, NCHW fp32 in and out (+ optional per-channel bias).
-    in_affine [3, Cin] (bn2d_stats): the input is relu(batchnorm(x)), applied by the kernel's loader waves."""
+    in_affine [3, Cin] (bn2d_stats): the input is relu(batchnorm(x)), applied by the kernel's loader waves.
+    cfg: per-call ablation / forced-geometry word (include/sassd.h, sassd_conv2d_bf16_fwd_cfg), 0 in production."""
     _chk_cuda(x, w_packed, in_affine)
     b, cin, h, w = x.shape
     if y is None:
         y = torch.empty(b, cout, h, w, dtype=torch.float32, device=x.device)
+    if cfg:
+        assert in_affine is None
+        _C.check(_C.lib().sassd_conv2d_bf16_fwd_cfg(_C.ptr(x), _C.ptr(w_packed), _C.ptr(shift) if shift is not None else None,
+                                                    _C.ptr(y), b, cin, cout, h, w, int(cfg), _C.stream()), "sassd_conv2d_bf16_fwd_cfg")
+        return y
     if in_affine is not None:
         _C.check(_C.lib().sassd_conv2d_bf16_bnrelu_fwd(_C.ptr(x), _C.ptr(in_affine), _C.ptr(w_packed), _C.ptr(shift), _C.ptr(y),
                                                        b, cin, cout, h, w, _C.stream()), "sassd_conv2d_bf16_bnrelu_fwd")

@@ -89,19 +89,14 @@ def test_conv3x3_bf16(dev, b, cin, cout, hw):
 def test_conv3x3_bf16_long_runs(dev, b, cin, cout, hw, nwg):
     """The persistent kernel with few workgroups: every run holds many tiles (1..5 blocks each), crosses strip, image and
     cout-tile boundaries, ends in an odd last row -- same numbers as the reference and as the default launch."""
-    from sassd import _C
     g = torch.Generator().manual_seed(cin + 5 * cout + hw[0])
     x = torch.randn(b, cin, *hw, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (cin * 9)) ** 0.5
     bias = torch.randn(cout, generator=g)
     pk = K.conv2d_bf16_pack_weight(w.to(dev))
     auto = K.conv2d_bf16_fwd(x.to(dev), pk, cout, bias.to(dev))
-    try:
-        _C.lib().sassd_debug_set_bf16(nwg << 8)
-        got = K.conv2d_bf16_fwd(x.to(dev), pk, cout, bias.to(dev))
-        torch.cuda.synchronize()
-    finally:
-        _C.lib().sassd_debug_set_bf16(0)
+    got = K.conv2d_bf16_fwd(x.to(dev), pk, cout, bias.to(dev), cfg=nwg << 8)      # per-call word: forced workgroup count
+    torch.cuda.synchronize()
     assert _rel(got, F.conv2d(_bf(x).double(), _bf(w).double(), bias.double(), 1, 1)) < 1e-5
     assert torch.equal(got, auto)           # the tiling does not change a pixel's summation order
 

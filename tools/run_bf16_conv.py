@@ -56,7 +56,6 @@ def main():
         out["fwd3x3_wino4_fp32_ms"] = timed(lambda: K.conv2d_wino4_fwd(x, p4, 256, None, None), a.iters)
         out["fwd3x3_bf16_tflops"] = flops / out["fwd3x3_bf16_ms"] / 1e9
         if a.ablate:
-            from sassd import _C
             names = {1: "no_input_staging", 2: "hot_weights", 4: "no_mfma", 8: "no_stores", 3: "no_global_loads",
                      15: "only_lds", 11: "mfma_and_lds_only", 16: "input_hot_in_l2",
                      43: "mma_loop_no_b_reads", 75: "mma_loop_no_barriers",
@@ -66,9 +65,7 @@ def main():
                      0x10000: "mma_waves_default_priority", 0x20000: "loader_waves_high_priority",
                      0x40000: "loader_quad_fastest_order_r02", 0: "default_again"}
             for flag, name in names.items():
-                _C.lib().sassd_debug_set_bf16(flag)
-                out["ablate_" + name + "_ms"] = timed(lambda: K.conv2d_bf16_fwd(x, pk, 256), a.iters)
-            _C.lib().sassd_debug_set_bf16(0)
+                out["ablate_" + name + "_ms"] = timed(lambda: K.conv2d_bf16_fwd(x, pk, 256, cfg=flag), a.iters)
     print(json.dumps(out, indent=1))
 
 

@@ -23,18 +23,13 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 for _ in range(n):
     K.conv2d_fwd(x, wp, CO, 3, sc, sh, True, y)
 torch.cuda.synchronize()
-import ctypes
-from sassd import _C
-setdbg = ctypes.CDLL(_C.LIB_PATH).sassd_debug_set_conv
 flags_list = [0] if len(sys.argv) < 3 else [int(v) for v in sys.argv[2].split(",")]
 for flags in flags_list:
-    setdbg(flags)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        K.conv2d_fwd(x, wp, CO, 3, sc, sh, True, y)
+        K.conv2d_fwd(x, wp, CO, 3, sc, sh, True, y, cfg=flags)           # per-call ablation word (sassd_conv2d_fwd_cfg)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     print("flags=%d conv 256->%d 3x3 @200x176: %.4f ms  %.1f TFLOP/s" % (flags, CO, ms, 2 * CO * 256 * 9 * 200 * 176 / ms / 1e9))
-setdbg(0)

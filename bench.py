@@ -48,8 +48,15 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# The frame is one hipGraph with two branches (features | coordinates) and `--inflight` of them run at once: 6 streams at the
+# default 3.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) -- two graphs
+# sharing a queue run their kernels in each other's order.  Measured on one box (profiles/r06_late_experiments.txt): 4 queues
+# 807-814 frames/s, 8 queues 839-842, 2 queues 700; multi_cfg 851 -> 894, Waymo-scale 397 -> 417; training unchanged.  The
+# variable is read when the runtime loads, i.e. before `import torch`; an explicit setting of the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -712,6 +719,7 @@ def main():
                    "frames_per_step_per_gpu": B, "frames_in_flight": S, "spconv_cfg": args.spconv_cfg,
                    "rulebook_pyramid": args.pyramid,
                    "launch": "eager host launches" if args.eager else "one hipGraph replay per frame",
+                   "hip_runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                    "parallelism": "frame-sharded x%d, no collective" % world,
                    "vs_baseline_ref": "reference readme.md:2 '25 FPS' (hardware unstated), per-GPU fps / 25"},
         "fps_in_flight": round(fps, 3), "fps_sequential": round(B * 1e3 / seq_ms, 3),

@@ -17,4 +17,8 @@ timeout 600 python bench.py --mode train --steps 40 --warmup 8 > $O/bench_train_
 timeout 600 python bench.py --mode train --steps 40 --warmup 8 --force-ddp > $O/bench_train_forceddp.log 2>&1; echo "train force-ddp rc=$?"
 timeout 600 python bench.py --mode train --precision fp32 --steps 30 --warmup 6 > $O/bench_train_fp32.log 2>&1; echo "train fp32 rc=$?"
 timeout 600 python bench.py --mode train --config waymo --steps 12 --warmup 4 > $O/bench_train_waymo.log 2>&1; echo "train waymo rc=$?"
-grep -o '"value": [0-9.]*' $O/bench_default.log $O/bench_20steps.log $O/bench_train_bf16.log $O/bench_train_waymo.log $O/bench_train_fp32.log $O/bench_train_forceddp.log
+timeout 300 python bench.py --config multi --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_multi.log 2>&1; echo "multi rc=$?"
+timeout 300 python bench.py --config waymo --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_waymo.log 2>&1; echo "waymo rc=$?"
+rm -rf /tmp/pf_i; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pf_i -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train --no-extra > $O/bench_inflight3_under_rocprof.log 2>&1 ); echo "inference trace rc=$?"
+DB=$(find /tmp/pf_i -name "*.db" | head -1); [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB > $O/bench_inflight3_kernel_stats.txt 2>&1
+grep -o '"value": [0-9.]*' $O/bench_default.log $O/bench_20steps.log $O/bench_train_bf16.log $O/bench_train_waymo.log $O/bench_train_fp32.log $O/bench_train_forceddp.log $O/bench_multi.log $O/bench_waymo.log

@@ -48,12 +48,15 @@ import os
 import sys
 import time
 
-# The frame is one hipGraph with two branches (features | coordinates) and `--inflight` of them run at once: 6 streams at the
-# default 3.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) -- two graphs
-# sharing a queue run their kernels in each other's order.  Measured on one box (profiles/r06_late_experiments.txt): 4 queues
-# 807-814 frames/s, 8 queues 839-842, 2 queues 700; multi_cfg 851 -> 894, Waymo-scale 397 -> 417; training unchanged.  The
-# variable is read when the runtime loads, i.e. before `import torch`; an explicit setting of the caller wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# `--hw-queues N` (opt-in): GPU_MAX_HW_QUEUES for the HIP runtime, which multiplexes a process's streams onto that many hardware
+# queues (default 4) and reads the variable when it loads, i.e. before `import torch`.  The frame is one hipGraph with two
+# branches and `--inflight` of them run at once -- six streams at the default 3.  Measured on one box
+# (profiles/r06_late_experiments.txt): 4 queues 807-814 frames/s, 8 queues 839-842, 2 queues 700; multi_cfg 851 -> 894,
+# Waymo-scale 397 -> 417.  NOT the default: with 8 queues the sequential rate drops 1.5 %, eager launches with frames in flight
+# 791 -> 755, a one-rank DDP step 260 -> 244 samples/s, and the per-stage event timings of the full default line came out doubled
+# in two collections for a reason that was not found -- a runtime setting with unexplained side effects stays the caller's choice.
+if "--hw-queues" in sys.argv:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(sys.argv[sys.argv.index("--hw-queues") + 1]))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -485,6 +488,8 @@ def main():
                     "(0,1,2,3 = one wait per level, the default; A/B: 1,3 or 3)")
     ap.add_argument("--dense-conv0", action="store_true", help="BEV conv0 on every tile instead of the active tiles of the "
                     "sparse map only (A/B)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for the HIP runtime (read before torch loads: see "
+                    "the top of this file); 0 = leave the environment alone")
     ap.add_argument("--no-extra", action="store_true", help="default (car) run: skip the `infer_multi` / `infer_waymo` / "
                     "`train_waymo` records (BASELINE configs[3] / [4]) that follow the headline measurement")
     args = ap.parse_args()

@@ -21,16 +21,6 @@ Layout:
   create_data.py   infos / velodyne_reduced / gt_database preparation in the reference's formats (tools/create_data.py)
   kitti_dataset.py, loader.py, runner.py   KittiLiDAR + get_dataset, samplers + prefetching loader, epoch / test loops
 """
-import os as _os
-import sys as _sys
-
-# An InferencePlan replays one hipGraph with two branches per frame; a process that keeps several frames in flight should give
-# the HIP runtime at least two hardware queues per plan (GPU_MAX_HW_QUEUES, default 4: three plans share queues and run each
-# other's kernels in order -- 810 instead of 840 frames/s on one MI355X, profiles/r06_late_experiments.txt).  The variable is read
-# when the runtime loads (`import torch`), so it can only be defaulted here when sassd is imported first; an explicit setting wins.
-if "torch" not in _sys.modules:
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-from . import synth  # noqa: F401,E402
+from . import synth  # noqa: F401
 
 __version__ = "0.1.0"

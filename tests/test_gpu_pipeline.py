@@ -121,6 +121,61 @@ def test_pipeline_vs_oracle(dev, frames, seed, score_thr):
     assert ndet >= 1, "test vector produced no detections at all"
 
 
+def _det_state(plan):
+    """what a frame leaves behind: detections and guided anchors up to their counts (rows past a count are stale by contract),
+    part-sensitive logits of the candidates, anchor masks, the two BEV maps the heads read"""
+    k = int(plan.det["counts"][0].item())
+    c = int(plan.df["counts"][0].item())
+    return [t.clone() for t in (plan.det["counts"], plan.det["boxes"][0, :k], plan.det["scores"][0, :k], plan.det["labels"][0, :k],
+                                plan.df["counts"], plan.df["guided"][0, :c], plan.logits[0, :c], plan.mask, plan.x, plan.conv6)]
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_frame_graph_replays_equal_the_eager_frame(dev, overlap):
+    """The production launch path: the whole frame captured once (plan.capture) and replayed per frame (plan.run_graph), as the
+    TWO-BRANCH graph (coordinate side stream, `overlap=True`) and as the ONE-BRANCH graph bench.py keeps in flight
+    (`overlap=False`: rulebooks / anchor masks in front of the feature path on the frame's own stream; round 6).  Every replay
+    must leave exactly what the eager frame leaves -- detections, guided-anchor counts, part-sensitive logits, anchor masks, the BEV
+    maps, bit for bit -- for frames of different sizes replayed in turn, and for THREE plans in flight on three streams."""
+    model, c = _model()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    an, bv = _anchors()
+    clouds = [torch.from_numpy(H.frame(f, i)).to(dev) for i, f in enumerate(("k21", "small", "k17", "k21"))]
+    cap = max(int(p.shape[0]) for p in clouds) + 64
+    eager = InferencePlan(sd, batch_size=1, anchors=an, anchors_bv=bv, device=dev)            # two-branch, launched from the host
+    want = []
+    for p in clouds:
+        eager.run_from_points([p])
+        torch.cuda.synchronize()
+        assert int(eager.status.item()) == 0
+        want.append(_det_state(eager))
+    assert sum(int(w_[0].sum().item()) for w_ in want) >= 1, "no detections at all"
+    plans = [InferencePlan(sd, batch_size=1, anchors=an, anchors_bv=bv, device=dev, overlap=overlap) for _ in range(3)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for pl, st in zip(plans, streams):
+        with torch.cuda.stream(st):
+            pl.capture(cap)
+    torch.cuda.synchronize()
+    # one plan, frames in turn (a smaller frame after a larger one: nothing of the previous replay may leak)
+    with torch.cuda.stream(streams[0]):
+        for i in (0, 1, 2, 3, 1, 0):
+            plans[0].run_graph([clouds[i]])
+            torch.cuda.synchronize()
+            for j, (got, ref) in enumerate(zip(_det_state(plans[0]), want[i])):
+                assert got.shape == ref.shape and torch.equal(got, ref), ("sequential replay", overlap, i, j)
+    # three plans in flight, each its own stream, no synchronisation between the launches
+    for rnd in range(4):
+        order = [(rnd + j) % 4 for j in range(3)]
+        for pl, st, i in zip(plans, streams, order):
+            with torch.cuda.stream(st):
+                pl.run_graph([clouds[i]])
+        torch.cuda.synchronize()
+        for pl, i in zip(plans, order):
+            assert int(pl.status.item()) == 0
+            for j, (got, ref) in enumerate(zip(_det_state(pl), want[i])):
+                assert got.shape == ref.shape and torch.equal(got, ref), ("in flight", overlap, rnd, i, j)
+
+
 def test_reference_style_forward_test_api(dev):
     """model(img, img_meta, return_loss=False, voxels=[..], coordinates=[..], num_points=[..], anchors=[..],
     anchors_mask=[..]) -- the reference's calling convention (single_stage.py:110, tools/test.py:31)."""

@@ -29,36 +29,6 @@ def weight_key(w):
 _ws_scope = [None]
 
 
-_fresh_streams = []
-
-
-def fresh_stream(device):
-    """A HIP stream created NOW (hipStreamCreateWithFlags), wrapped for torch -- not one of torch's 32 pool streams.
-
-    The HIP runtime multiplexes all streams of a process onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and picks the
-    least-loaded queue when a stream is created; two streams on one queue execute in submission order.  torch creates its whole
-    pool at once and hands it out round-robin, so which queue `torch.cuda.Stream()` lands on depends on how many streams the
-    process made before -- every fourth position shares the queue of the legacy default stream (round 6 measured a training step
-    at 8.2-8.5 instead of 7.2 ms when the batch-prefetch stream sat there: profiles/r06_late_experiments.txt).  A stream created
-    after the pool goes to a queue the default stream is not on.  Falls back to a pool stream when the runtime cannot be reached."""
-    import ctypes
-    device = torch.device(device)
-    try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        h = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            torch.cuda.current_stream()                          # (the runtime and torch's pool exist)
-            torch.cuda.Stream(device=device)
-            rc = hip.hipStreamCreateWithFlags(ctypes.byref(h), ctypes.c_uint(1))        # hipStreamNonBlocking
-        if rc != 0 or not h.value:
-            raise OSError("hipStreamCreateWithFlags -> %d" % rc)
-        st = torch.cuda.ExternalStream(h.value, device=device)
-        _fresh_streams.append(st)                                # (lives as long as the process: a handful per run)
-        return st
-    except (OSError, AttributeError, RuntimeError):
-        return torch.cuda.Stream(device=device)
-
-
 class ws_scope:
     """Scratch buffers handed out inside `with ws_scope(owner)` belong to `owner`: plans that run concurrently on
     different HIP streams must not share kernel workspaces."""

@@ -448,8 +448,7 @@ class SideStreamPrefetch:
 
     def __init__(self, build):
         self.build = build
-        # (a stream on a hardware queue of its own, kernels.fresh_stream: a pool stream may share the training stream's queue)
-        self.stream = K.fresh_stream(torch.cuda.current_device()) if torch.cuda.is_available() else None
+        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._first = True
 
     def __call__(self, *args, **kw):

@@ -130,13 +130,13 @@ def _det_state(plan):
                                 plan.df["counts"], plan.df["guided"][0, :c], plan.logits[0, :c], plan.mask, plan.x, plan.conv6)]
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True])
 def test_frame_graph_replays_equal_the_eager_frame(dev, overlap):
-    """The production launch path: the whole frame captured once (plan.capture) and replayed per frame (plan.run_graph), as the
-    TWO-BRANCH graph (coordinate side stream, `overlap=True`) and as the ONE-BRANCH graph bench.py keeps in flight
-    (`overlap=False`: rulebooks / anchor masks in front of the feature path on the frame's own stream; round 6).  Every replay
-    must leave exactly what the eager frame leaves -- detections, guided-anchor counts, part-sensitive logits, anchor masks, the BEV
-    maps, bit for bit -- for frames of different sizes replayed in turn, and for THREE plans in flight on three streams."""
+    """The production launch path: the whole frame captured once (plan.capture) and replayed per frame (plan.run_graph) -- the
+    two-branch graph (coordinate side stream) bench.py keeps in flight.  Every replay must leave exactly what the eager frame
+    leaves -- detections, guided-anchor counts, part-sensitive logits, anchor masks, the BEV maps, bit for bit -- for frames of
+    different sizes replayed in turn, and for THREE plans in flight on three streams.  (The one-branch form, `overlap=False`,
+    passes this test too but is NOT used: profiles/r06_late_experiments.txt, experiment 9.)"""
     model, c = _model()
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     an, bv = _anchors()

@@ -394,8 +394,10 @@ def infer_extra(dev, config, steps=60, warmup=10, inflight=3, pyramid_persistent
     model, w = build_model(0, dev, config)
     B, S = w["batch"], max(1, inflight)
     sd = model.state_dict()
-    plans = [InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["anchors_bv"], device=dev,
-                           pyramid_persistent=pyramid_persistent, **w["plan"]) for _ in range(S)]
+    def mk(overlap):
+        return InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["anchors_bv"], device=dev,
+                             pyramid_persistent=pyramid_persistent, overlap=overlap, **w["plan"])
+    plans = [mk(S == 1) for _ in range(S)]              # frames in flight: one-branch graphs (see main())
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     clouds = [torch.from_numpy(w["frame"](i)).to(dev) for i in range(max(8, B))]
 
@@ -425,6 +427,11 @@ def infer_extra(dev, config, steps=60, warmup=10, inflight=3, pyramid_persistent
     dt = float(np.median(dts))
     plan = plans[0]
     ndet, ncand = int(plan.det["counts"].sum().item()), int(plan.df["counts"].sum().item())
+    for pl in plans:
+        assert int(pl.status.item()) == 0, "pipeline status 0x%x after the timed runs" % int(pl.status.item())
+    del plans
+    torch.cuda.empty_cache()
+    plans = plan = mk(True)                             # the sparse segment as its own graph: the two-branch form, as in main()
     with torch.cuda.stream(streams[0]):
         plan.run_from_points(batch_of(0))
         torch.cuda.synchronize()
@@ -445,6 +452,24 @@ def infer_extra(dev, config, steps=60, warmup=10, inflight=3, pyramid_persistent
                                 "bytes_gs": work["bytes_gs"], "bytes_min": work["bytes_min"],
                                 "rulebook_bytes": work["rulebook_bytes"], "rows": work["n"]},
             "detections_last_frame": ndet, "guided_anchor_candidates_last_frame": ncand}
+
+
+def child_record(argv, timeout_s):
+    """One more record of the default line, measured by THIS script in a child process (`python bench.py <argv>`) and read back
+    from its JSON line.  World size 1 only.  Why a child: the same measurement inside the process that has just captured and
+    replayed the frame graphs ran slower for reasons outside the kernels -- `train` 238-251 instead of 276 samples/s, Waymo-scale
+    inference 383 instead of 411 frames/s on the same box (how the runtime places a long-lived process's streams on its hardware
+    queues) -- and a record of the line should be what `python bench.py <argv>` prints when run alone."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        raise RuntimeError("child %s exited %d: %s" % (" ".join(argv), p.returncode, p.stderr.strip().splitlines()[-1:] or ""))
+    rec = json.loads(lines[-1])
+    rec["measured_by"] = "child process: python bench.py " + " ".join(argv)
+    return rec
 
 
 def main():
@@ -490,6 +515,9 @@ def main():
                     "sparse map only (A/B)")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for the HIP runtime (read before torch loads: see "
                     "the top of this file); 0 = leave the environment alone")
+    ap.add_argument("--side-stream", action="store_true", help="the plans in flight keep their coordinate side stream: every frame "
+                    "graph has two branches (the form of rounds 2-6; A/B).  Default: ONE branch per frame in flight -- "
+                    "rulebooks / anchor masks in front of the feature path on the frame's own stream")
     ap.add_argument("--no-extra", action="store_true", help="default (car) run: skip the `infer_multi` / `infer_waymo` / "
                     "`train_waymo` records (BASELINE configs[3] / [4]) that follow the headline measurement")
     args = ap.parse_args()
@@ -515,11 +543,20 @@ def main():
     S = max(1, args.inflight)
     sd = model.state_dict()
 
-    def new_plan():
-        return InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["anchors_bv"], device=dev,
-                             pyramid_persistent=args.pyramid == "persistent", **plan_cfg, **w["plan"])
+    # Frames in flight are ONE-BRANCH graphs (round 6, last day).  A plan with the coordinate side stream captures a graph with two
+    # branches; three of them in flight are six streams on the runtime's four hardware queues, and graphs that share a queue run
+    # their kernels in each other's order: 792-808 frames/s.  Without the side stream a frame is one linear graph on its own queue
+    # and the overlap of latency-bound and MFMA-bound stages comes from the OTHER frames: 895-942 frames/s on the same boxes (and
+    # 879-924 for every placement of the three streams in torch's pool: the result does not hang on the stream -> queue mapping);
+    # one frame alone is 2 % slower that way (664 against 677 sequential: its rulebooks no longer overlap its own first convs),
+    # the host-synced latency is the same 1.59 ms.  `--side-stream` restores the two-branch form (profiles/r06_late_experiments.txt).
+    one_branch = S > 1 and not args.side_stream and not args.eager
 
-    plans = [new_plan() for _ in range(S)]
+    def new_plan(overlap=True):
+        return InferencePlan(sd, batch_size=B, anchors=w["anchors"], anchors_bv=w["anchors_bv"], device=dev,
+                             pyramid_persistent=args.pyramid == "persistent", overlap=overlap, **plan_cfg, **w["plan"])
+
+    plans = [new_plan(overlap=not one_branch) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     plan = plans[0]
     nfr = max(args.frames if args.config != "waymo" else min(args.frames, 8), B)
@@ -569,6 +606,9 @@ def main():
         ntr = int(D.allreduce_max(float(max(5, min(25, int(np.ceil(1.5 / max(trial_dts[0], 1e-4)))))), dev))
         trial_dts += [trial() for _ in range(ntr - 1)]
     dt = float(np.median(trial_dts))
+    for pi, pl in enumerate(plans):
+        st = int(pl.status.item())
+        assert st == 0, "pipeline status 0x%x on plan %d after the timed trials" % (st, pi)
     ndet = int(plan.det["counts"].sum().item())
     ncand = int(plan.df["counts"].sum().item())
     fps = args.steps * B * world / dt
@@ -724,6 +764,9 @@ def main():
                    "frames_per_step_per_gpu": B, "frames_in_flight": S, "spconv_cfg": args.spconv_cfg,
                    "rulebook_pyramid": args.pyramid,
                    "launch": "eager host launches" if args.eager else "one hipGraph replay per frame",
+                   "frame_graph": ("one branch per frame in flight (rulebooks / anchor masks in front of the feature path on the "
+                                   "frame's own stream); per-stage timings and roofline_sparse on the two-branch plan"
+                                   if one_branch else "two branches (coordinate side stream)"),
                    "hip_runtime_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                    "parallelism": "frame-sharded x%d, no collective" % world,
                    "vs_baseline_ref": "reference readme.md:2 '25 FPS' (hardware unstated), per-GPU fps / 25"},
@@ -776,25 +819,47 @@ def main():
         "detections_last_frame": ndet, "guided_anchor_candidates_last_frame": ncand,
     }
     out["csrc_hash"] = csrc_hash()
+    # the inference measurement is complete: its plans, graphs and streams go before the other records of the line are taken (the
+    # training record ran 238 instead of 276 samples/s with three captured frame graphs still alive in the process)
+    del plans, plan                                        # (iso_plan stays: the parity record of cpu_baseline reads it)
+    torch.cuda.empty_cache()
     if watchdog is not None:
         emit["line"] = out
         watchdog.start()
         try:
-            out["train"] = train_measure(args, dev, rank, world, "car", "bf16", args.train_steps, args.train_warmup)
+            if world == 1:                                       # (N > 1: a collective -- every rank measures in this process)
+                try:
+                    out["train"] = child_record(["--mode", "train", "--steps", str(args.train_steps), "--warmup",
+                                                 str(args.train_warmup)], 400)
+                except Exception as e:                           # fall back to the in-process measurement
+                    out["train"] = train_measure(args, dev, rank, world, "car", "bf16", args.train_steps, args.train_warmup)
+                    out["train"]["child_error"] = "%s: %s" % (type(e).__name__, e)
+            else:
+                out["train"] = train_measure(args, dev, rank, world, "car", "bf16", args.train_steps, args.train_warmup)
         except Exception as e:                                   # the inference line is still valid without it
             out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             watchdog.cancel()
     # ---- BASELINE configs[3] / [4] in the same line (N = 1 only: no collective, rank 0): short runs of the same measurement
     if world == 1 and headline and not args.no_extra and not args.eager:
-        del plans, plan
-        torch.cuda.empty_cache()
-        for key, fn in (("infer_multi", lambda: infer_extra(dev, "multi", 60, 10, S, args.pyramid == "persistent")),
-                        ("infer_waymo", lambda: infer_extra(dev, "waymo", 40, 8, S, args.pyramid == "persistent")),
-                        ("train_waymo", lambda: train_measure(args, dev, rank, world, "waymo", "bf16", 12, 4, frames=8))):
+        pyr = ["--pyramid", args.pyramid]
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "trials", "config", "fps_sequential",
+                "latency_ms_sync_per_frame", "roofline_sparse", "measured_by")
+        for key, argv, fallback in (
+                ("infer_multi", ["--config", "multi", "--steps", "60", "--warmup", "10", "--no-cpu-baseline", "--inflight", str(S)] + pyr,
+                 lambda: infer_extra(dev, "multi", 60, 10, S, args.pyramid == "persistent")),
+                ("infer_waymo", ["--config", "waymo", "--steps", "40", "--warmup", "8", "--no-cpu-baseline", "--inflight", str(S)] + pyr,
+                 lambda: infer_extra(dev, "waymo", 40, 8, S, args.pyramid == "persistent")),
+                ("train_waymo", ["--mode", "train", "--config", "waymo", "--steps", "12", "--warmup", "4", "--frames", "8"],
+                 lambda: train_measure(args, dev, rank, world, "waymo", "bf16", 12, 4, frames=8))):
             t0 = time.perf_counter()
             try:
-                out[key] = fn()
+                try:
+                    rec = child_record(argv, 300)
+                    out[key] = rec if key == "train_waymo" else {k: rec[k] for k in keep if k in rec}
+                except Exception as e:
+                    out[key] = fallback()
+                    out[key]["child_error"] = "%s: %s" % (type(e).__name__, e)
             except Exception as e:                               # the headline line is still valid without it
                 out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             out[key]["wall_s"] = round(time.perf_counter() - t0, 1)

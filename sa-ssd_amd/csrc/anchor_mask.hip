@@ -151,7 +151,9 @@ int anchor_mask_run(const int32_t *coors, const int32_t *rb, const int32_t *re, 
     const size_t gstride = gbytes / 4, sstride = (per - gbytes) / 4;
     const int nseg = cdiv(H0, kRB);
     int rc;
-    if ((rc = sassd_hip(hipMemsetAsync(grid, 0, gbytes * batch, stream)))) return rc;
+    if ((((uintptr_t)grid | (gbytes * batch)) & 15) == 0) {                   // a fill kernel, not a memset node (see sassd_densify)
+        if ((rc = sassd_fill2(grid, gbytes * batch, 0, grid, 0, 0, stream))) return rc;
+    } else if ((rc = sassd_hip(hipMemsetAsync(grid, 0, gbytes * batch, stream)))) return rc;
     // the voxel count of one cloud never exceeds H0*W0*D; launch for a generous fixed bound and exit early
     const int max_rows = 1 << 18;
     hipLaunchKernelGGL(am_scatter_kernel, dim3(cdiv(max_rows, 256), 1, batch), dim3(256), 0, stream, coors, rb, re, W0,

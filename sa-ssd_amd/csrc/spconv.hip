@@ -952,7 +952,12 @@ extern "C" int sassd_densify(const float *feats, const int32_t *indices, const i
     if (!feats || !indices || !n_ptr || !out || cap <= 0) return SASSD_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     int rc;
-    if ((rc = sassd_hip(hipMemsetAsync(out, 0, (size_t)batch_size * C * D * H * W * sizeof(float), stream)))) return rc;
+    // (a fill KERNEL where the alignment allows -- every map of the pipeline: hipMemsetAsync becomes a memset node in a captured
+    // frame graph, the one node type of the frame that is not a kernel; see profiles/r06_late_experiments.txt, experiment 9)
+    const size_t obytes = (size_t)batch_size * C * D * H * W * sizeof(float);
+    if ((((uintptr_t)out | obytes) & 15) == 0) {
+        if ((rc = sassd_fill2(out, obytes, 0, out, 0, 0, stream))) return rc;
+    } else if ((rc = sassd_hip(hipMemsetAsync(out, 0, obytes, stream)))) return rc;
     hipLaunchKernelGGL(densify_kernel, dim3(cdiv(cap * C, 256)), dim3(256), 0, stream, feats, indices, n_ptr, cap, C, D,
                        H, W, channel_order, out);
     return sassd_launch_status();

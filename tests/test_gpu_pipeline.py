@@ -130,13 +130,17 @@ def _det_state(plan):
                                 plan.df["counts"], plan.df["guided"][0, :c], plan.logits[0, :c], plan.mask, plan.x, plan.conv6)]
 
 
-@pytest.mark.parametrize("overlap", [True])
+@pytest.mark.parametrize("overlap", [True, False])
 def test_frame_graph_replays_equal_the_eager_frame(dev, overlap):
-    """The production launch path: the whole frame captured once (plan.capture) and replayed per frame (plan.run_graph) -- the
-    two-branch graph (coordinate side stream) bench.py keeps in flight.  Every replay must leave exactly what the eager frame
-    leaves -- detections, guided-anchor counts, part-sensitive logits, anchor masks, the BEV maps, bit for bit -- for frames of
-    different sizes replayed in turn, and for THREE plans in flight on three streams.  (The one-branch form, `overlap=False`,
-    passes this test too but is NOT used: profiles/r06_late_experiments.txt, experiment 9.)"""
+    """The production launch path: the whole frame captured once (plan.capture) and replayed per frame (plan.run_graph), as the
+    TWO-BRANCH graph (coordinate side stream, `overlap=True`) and as the ONE-BRANCH graph bench.py keeps in flight
+    (`overlap=False`: rulebooks / anchor masks in front of the feature path on the frame's own stream; round 6).  Every replay
+    must leave exactly what the eager frame leaves -- detections, guided-anchor counts, part-sensitive logits, anchor masks, the BEV
+    maps, bit for bit -- for frames of different sizes replayed in turn, for THREE plans in flight on three streams, and AFTER THE
+    HOST HAS RECYCLED DEVICE MEMORY (allocate + fill + free blocks of 2 MB .. 1 GB between replays): a captured hipMemsetAsync --
+    a memset NODE, the one non-kernel node the frame had -- went wrong in exactly that situation (the first plan's dense map full
+    of foreign data, SASSD_ST_BOX_OVERFLOW in 5 of 6 bench processes at Waymo scale); the frame clears its maps with fill kernels
+    since (sassd_densify, sassd_anchor_mask*)."""
     model, c = _model()
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     an, bv = _anchors()
@@ -163,6 +167,20 @@ def test_frame_graph_replays_equal_the_eager_frame(dev, overlap):
             torch.cuda.synchronize()
             for j, (got, ref) in enumerate(zip(_det_state(plans[0]), want[i])):
                 assert got.shape == ref.shape and torch.equal(got, ref), ("sequential replay", overlap, i, j)
+    # the host recycles device memory between replays (what any application around the plan does)
+    for nbytes in (2 << 20, 8 << 20, 64 << 20, 1 << 30):
+        junk = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        junk.fill_(255)
+        torch.cuda.synchronize()
+        del junk
+        for pl, st in zip(plans, streams):
+            with torch.cuda.stream(st):
+                pl.run_graph([clouds[0]])
+        torch.cuda.synchronize()
+        for pl in plans:
+            assert int(pl.status.item()) == 0, ("after the host recycled memory", overlap, nbytes)
+            for j, (got, ref) in enumerate(zip(_det_state(pl), want[0])):
+                assert got.shape == ref.shape and torch.equal(got, ref), ("after the host recycled memory", overlap, nbytes, j)
     # three plans in flight, each its own stream, no synchronisation between the launches
     for rnd in range(4):
         order = [(rnd + j) % 4 for j in range(3)]

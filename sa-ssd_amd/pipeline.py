@@ -236,7 +236,7 @@ class InferencePlan:
         (device int32 [B]) the clouds are capacity-sized staging buffers holding n_dev[b] points each."""
         assert len(clouds) == self.B
         e0 = self._ev() if self.prof is not None else None
-        self.row_off.zero_()
+        self.row_off.fill_(0)                   # (a fill KERNEL: torch's zero_() is a memset, i.e. a memset node in a captured frame)
         for b, pts in enumerate(clouds):
             K.voxelize(pts, self.voxel_size, self.pc_range, self.T, self.max_voxels, batch_idx=b, coors_cols=4,
                        want_voxels=False, want_mean=True, nfeat=4,

@@ -257,7 +257,7 @@ class InferencePlan:
         assert m <= self.caps[0]
         self.mean[:m].copy_(voxel_feats)
         self.idx[0][:m].copy_(coors4.int())
-        self.row_off.zero_()
+        self.row_off.fill_(0)
         bc = torch.bincount(coors4[:, 0].long(), minlength=self.B).cumsum(0).int()
         self.row_off[1:].copy_(bc)
 
